@@ -1,0 +1,820 @@
+/*
+ * hpfw_oracle.c -- CPU restatement of the hpfw index()/search() hot path.  See hpfw_oracle.h:
+ * TEST INFRASTRUCTURE ONLY, PARITY UNPINNED (no reference fixtures exist, reference unbuildable
+ * here).  Build: see oracle/Makefile (-O3 -mfma -ffp-contract=off, no fast-math: every rounding
+ * below is explicit; fmaf() is a single-rounding fused multiply-add).
+ *
+ * Reference map (all paths relative to /root/reference):
+ *   include/hpfw/spectrum/cqt.h:36-84          spectrogram(): MonoLoader + NSGConstantQ + |.| + /3
+ *   include/hpfw/spectrum/convert.h:7-25       power_to_db / amplitude_to_db
+ *   include/hpfw/core/hashprint_handle.h:79-142 calc_frames, calc_fingerprint, bool_col_to_num
+ *   include/hpfw/core/parallel_collector.h:54-59 calc_hashprint (filters * frames)
+ *   include/hpfw/audioproblems/live-song-id/storage.h:27-64 MemoryStorage::find
+ *   examples/python/liveid.ipynb cell 9        top-10 by (distance, label)
+ * NSGConstantQ itself lives in essentia (un-vendored, version unpinned; CMakeLists.txt:36);
+ * its published algorithm (Holighaus, Doerfler, Velasco, Grill: "A framework for invertible,
+ * real-time constant-Q transforms", IEEE TASLP 2013; essentia nsgconstantq.cpp) is restated in
+ * make_bands() / hpfw_oracle_cqmag() and in DESIGN.md appendix A.
+ */
+#include "hpfw_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    float r, i;
+} cf;
+
+/* ------------------------------------------------------------------------------------------ */
+/* complex helpers with a fixed rounding order (DESIGN.md "Arithmetic specification" S1)       */
+/* ------------------------------------------------------------------------------------------ */
+static inline cf c_add(cf a, cf b) { cf o = {a.r + b.r, a.i + b.i}; return o; }
+static inline cf c_sub(cf a, cf b) { cf o = {a.r - b.r, a.i - b.i}; return o; }
+/* a * w */
+static inline cf c_mul(cf a, cf w)
+{
+    float p = a.i * w.i;
+    float q = a.i * w.r;
+    cf o = {fmaf(a.r, w.r, -p), fmaf(a.r, w.i, q)};
+    return o;
+}
+/* a * conj(w) */
+static inline cf c_mulc(cf a, cf w)
+{
+    float p = a.i * w.i;
+    float q = a.r * w.i;
+    cf o = {fmaf(a.r, w.r, p), fmaf(a.i, w.r, -q)};
+    return o;
+}
+/* -i * a */
+static inline cf c_mulmi(cf a) { cf o = {a.i, -a.r}; return o; }
+/* real scalar times complex, then fused add: s * a + b */
+static inline cf c_fma_s(float s, cf a, cf b) { cf o = {fmaf(s, a.r, b.r), fmaf(s, a.i, b.i)}; return o; }
+static inline cf c_scale(float s, cf a) { cf o = {s * a.r, s * a.i}; return o; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* S2: twiddles.  e^{-2 pi i m/n} evaluated in double with exact octant symmetry, then rounded  */
+/* ------------------------------------------------------------------------------------------ */
+static void twiddle_d(int64_t m, int64_t n, double *re, double *im)
+{
+    m %= n;
+    if (m < 0) m += n;
+    int64_t a = 8 * m;
+    int oct = (int)(a / n);
+    int64_t r = a - (int64_t)oct * n;
+    int64_t t = (oct & 1) ? (n - r) : r;
+    double alpha = M_PI * (double)t / (double)(4 * n);
+    double ca = cos(alpha), sa = sin(alpha), c, s;
+    switch (oct) {
+    case 0: c = ca; s = sa; break;
+    case 1: c = sa; s = ca; break;
+    case 2: c = -sa; s = ca; break;
+    case 3: c = -ca; s = sa; break;
+    case 4: c = -ca; s = -sa; break;
+    case 5: c = -sa; s = -ca; break;
+    case 6: c = sa; s = -ca; break;
+    default: c = ca; s = -sa; break;
+    }
+    *re = c;
+    *im = -s;
+}
+
+void hpfw_oracle_twiddle(int64_t m, int64_t n, float *re, float *im)
+{
+    double c, s;
+    twiddle_d(m, n, &c, &s);
+    *re = (float)c;
+    *im = (float)s;
+}
+
+static cf *make_twiddle_table(int64_t n)
+{
+    cf *t = (cf *)malloc(sizeof(cf) * (size_t)n);
+    for (int64_t m = 0; m < n; ++m) hpfw_oracle_twiddle(m, n, &t[m].r, &t[m].i);
+    return t;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* S3: small forward DFT codelets, radix 2, 3, 4, 5, 7 (sign -).  In place on u[0..r).          */
+/* ------------------------------------------------------------------------------------------ */
+#define K3_S 0.86602540378443864676f /* sin(2pi/3) */
+#define K5_C1 0.30901699437494742410f
+#define K5_C2 (-0.80901699437494742410f)
+#define K5_S1 0.95105651629515357212f
+#define K5_S2 0.58778525229247312917f
+#define K7_C1 0.62348980185873353053f
+#define K7_C2 (-0.22252093395631440429f)
+#define K7_C3 (-0.90096886790241912624f)
+#define K7_S1 0.78183148246802980871f
+#define K7_S2 0.97492791218182360702f
+#define K7_S3 0.43388373911755812048f
+
+static inline void dft2(cf *u)
+{
+    cf a = u[0], b = u[1];
+    u[0] = c_add(a, b);
+    u[1] = c_sub(a, b);
+}
+
+static inline void dft3(cf *u)
+{
+    cf t1 = c_add(u[1], u[2]);
+    cf d = c_sub(u[1], u[2]);
+    cf m1 = c_fma_s(-0.5f, t1, u[0]);
+    cf jd = {K3_S * d.i, -(K3_S * d.r)}; /* -i * s * d */
+    u[0] = c_add(u[0], t1);
+    u[1] = c_add(m1, jd);
+    u[2] = c_sub(m1, jd);
+}
+
+static inline void dft4(cf *u)
+{
+    cf t0 = c_add(u[0], u[2]);
+    cf t1 = c_sub(u[0], u[2]);
+    cf t2 = c_add(u[1], u[3]);
+    cf t3 = c_mulmi(c_sub(u[1], u[3]));
+    u[0] = c_add(t0, t2);
+    u[2] = c_sub(t0, t2);
+    u[1] = c_add(t1, t3);
+    u[3] = c_sub(t1, t3);
+}
+
+static inline void dft5(cf *u)
+{
+    cf a1 = c_add(u[1], u[4]), a2 = c_add(u[2], u[3]);
+    cf b1 = c_sub(u[1], u[4]), b2 = c_sub(u[2], u[3]);
+    cf p1 = c_fma_s(K5_C2, a2, c_fma_s(K5_C1, a1, u[0]));
+    cf p2 = c_fma_s(K5_C1, a2, c_fma_s(K5_C2, a1, u[0]));
+    cf q1 = c_fma_s(K5_S2, b2, c_scale(K5_S1, b1));
+    cf q2 = c_fma_s(-K5_S1, b2, c_scale(K5_S2, b1));
+    cf jq1 = c_mulmi(q1), jq2 = c_mulmi(q2); /* -i q */
+    u[0] = c_add(c_add(u[0], a1), a2);
+    u[1] = c_add(p1, jq1);
+    u[4] = c_sub(p1, jq1);
+    u[2] = c_add(p2, jq2);
+    u[3] = c_sub(p2, jq2);
+}
+
+static inline void dft7(cf *u)
+{
+    cf a1 = c_add(u[1], u[6]), a2 = c_add(u[2], u[5]), a3 = c_add(u[3], u[4]);
+    cf b1 = c_sub(u[1], u[6]), b2 = c_sub(u[2], u[5]), b3 = c_sub(u[3], u[4]);
+    /* s = 1: cos(1,2,3) sin(1,2,3); s = 2: cos(2,3,1) sin(2,-3,-1); s = 3: cos(3,1,2) sin(3,-1,2) */
+    cf p1 = c_fma_s(K7_C3, a3, c_fma_s(K7_C2, a2, c_fma_s(K7_C1, a1, u[0])));
+    cf p2 = c_fma_s(K7_C1, a3, c_fma_s(K7_C3, a2, c_fma_s(K7_C2, a1, u[0])));
+    cf p3 = c_fma_s(K7_C2, a3, c_fma_s(K7_C1, a2, c_fma_s(K7_C3, a1, u[0])));
+    cf q1 = c_fma_s(K7_S3, b3, c_fma_s(K7_S2, b2, c_scale(K7_S1, b1)));
+    cf q2 = c_fma_s(-K7_S1, b3, c_fma_s(-K7_S3, b2, c_scale(K7_S2, b1)));
+    cf q3 = c_fma_s(K7_S2, b3, c_fma_s(-K7_S1, b2, c_scale(K7_S3, b1)));
+    cf jq1 = c_mulmi(q1), jq2 = c_mulmi(q2), jq3 = c_mulmi(q3);
+    u[0] = c_add(c_add(c_add(u[0], a1), a2), a3);
+    u[1] = c_add(p1, jq1);
+    u[6] = c_sub(p1, jq1);
+    u[2] = c_add(p2, jq2);
+    u[5] = c_sub(p2, jq2);
+    u[3] = c_add(p3, jq3);
+    u[4] = c_sub(p3, jq3);
+}
+
+static inline void dft_r(cf *u, int r)
+{
+    switch (r) {
+    case 2: dft2(u); break;
+    case 3: dft3(u); break;
+    case 4: dft4(u); break;
+    case 5: dft5(u); break;
+    default: dft7(u); break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* S4: in-place decimation-in-frequency FFT (natural in, digit-reversed out) and the inverse    */
+/*     decimation-in-time FFT (digit-reversed in, natural out, unnormalised, sign +).           */
+/* ------------------------------------------------------------------------------------------ */
+static void fft_dif(cf *a, int64_t n, const int32_t *radix, int nr, const cf *tw)
+{
+    int64_t len = n;
+    for (int p = 0; p < nr; ++p) {
+        int r = radix[p];
+        int64_t m = len / r, ts = n / len;
+        for (int64_t base = 0; base < n; base += len) {
+            for (int64_t j = 0; j < m; ++j) {
+                cf u[7];
+                for (int q = 0; q < r; ++q) u[q] = a[base + j + q * m];
+                dft_r(u, r);
+                a[base + j] = u[0];
+                for (int s = 1; s < r; ++s) a[base + j + s * m] = c_mul(u[s], tw[ts * j * s]);
+            }
+        }
+        len = m;
+    }
+}
+
+static void fft_idit(cf *a, int64_t n, const int32_t *radix, int nr, const cf *tw)
+{
+    int64_t m = 1;
+    for (int p = nr - 1; p >= 0; --p) {
+        int r = radix[p];
+        int64_t len = m * r, ts = n / len;
+        for (int64_t base = 0; base < n; base += len) {
+            for (int64_t j = 0; j < m; ++j) {
+                cf u[7];
+                u[0] = a[base + j];
+                for (int q = 1; q < r; ++q) u[q] = c_mulc(a[base + j + q * m], tw[ts * j * q]);
+                /* inverse codelet = swap(forward codelet(swap(.))) */
+                for (int q = 0; q < r; ++q) { float t = u[q].r; u[q].r = u[q].i; u[q].i = t; }
+                dft_r(u, r);
+                for (int s = 0; s < r; ++s) { cf o = {u[s].i, u[s].r}; a[base + j + s * m] = o; }
+            }
+        }
+        m = len;
+    }
+}
+
+int64_t hpfw_oracle_digit_pos(int64_t k, int64_t n, const int32_t *radix, int nr)
+{
+    int64_t pos = 0, len = n;
+    for (int p = 0; p < nr; ++p) {
+        int r = radix[p];
+        len /= r;
+        pos += (k % r) * len;
+        k /= r;
+    }
+    return pos;
+}
+
+void hpfw_oracle_fft_dif(float *a, int64_t n, const int32_t *radix, int nr)
+{
+    cf *tw = make_twiddle_table(n);
+    fft_dif((cf *)a, n, radix, nr, tw);
+    free(tw);
+}
+
+void hpfw_oracle_fft_idit(float *a, int64_t n, const int32_t *radix, int nr)
+{
+    cf *tw = make_twiddle_table(n);
+    fft_idit((cf *)a, n, radix, nr, tw);
+    free(tw);
+}
+
+/* radix list of a 7-smooth n: primes descending, pairs of 2 merged into 4 ([.. 4 .. 3 .. 2]).
+ * Returns the number of passes or -1. */
+static int make_radix_list(int64_t n, int32_t *radix)
+{
+    int c2 = 0, c3 = 0, c5 = 0, c7 = 0, nr = 0;
+    while (n % 7 == 0) { n /= 7; ++c7; }
+    while (n % 5 == 0) { n /= 5; ++c5; }
+    while (n % 3 == 0) { n /= 3; ++c3; }
+    while (n % 2 == 0) { n /= 2; ++c2; }
+    if (n != 1) return -1;
+    if (c7 + c5 + c2 / 2 + c3 + (c2 & 1) > HPFW_O_MAXRADIX) return -1;
+    for (int i = 0; i < c7; ++i) radix[nr++] = 7;
+    for (int i = 0; i < c5; ++i) radix[nr++] = 5;
+    for (int i = 0; i < c2 / 2; ++i) radix[nr++] = 4;
+    for (int i = 0; i < c3; ++i) radix[nr++] = 3;
+    if (c2 & 1) radix[nr++] = 2;
+    return nr;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* plan                                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+#define N2_MAX 15360 /* complex f32 elements one in-core FFT may hold (120 KiB) */
+#define SAMPLE_RATE 44100.0
+#define MIN_FREQ 130.81  /* cqt.h:60 */
+#define MAX_FREQ 4186.01 /* cqt.h:61 */
+#define BINS_PER_OCTAVE 24
+#define MIN_WINDOW 96 /* cqt.h:58: "minimumWindow", int(HopLength) */
+#define DOWNSAMPLE 3  /* cqt.h:22 */
+
+typedef struct {
+    int64_t p;        /* transform length (power of two)                         */
+    int32_t nr;
+    int32_t radix[HPFW_O_MAXRADIX];
+    cf *tw;           /* T_p                                                      */
+    cf *vrev;         /* DFT_p(chirp), stored at digit-reversed positions         */
+} bluestein_class;
+
+struct hpfw_oracle_plan {
+    hpfw_oracle_plan_info info;
+    int32_t start[HPFW_O_BINS], lg[HPFW_O_BINS], psize[HPFW_O_BINS], cls[HPFW_O_BINS];
+    cf *tw_n2;       /* T_{n2}                                    */
+    cf *tw_n1;       /* T_{n1}                                    */
+    cf *tw_big;      /* [n1][h] : T_N[n1 * k2]                    */
+    int32_t *pos_n2; /* digit-reversed position of output k2       */
+    cf *g[HPFW_O_BINS]; /* window * chirp / (M * P), length lg[j]  */
+    int n_cls;
+    bluestein_class bc[8];
+};
+
+/* essentia NSGConstantQ::designWindow as configured at cqt.h:54-61: band centres
+ * f_j = fmin 2^(j/24), bandwidth Q f_j (gamma = 0), positions floor(f_j / fftres), window
+ * lengths max(round(bw_j / fftres), minimumWindow); rasterize "full": M = max_j Lg_j over the
+ * constant-Q bands (DC / Nyquist bands are computed by essentia but discarded at cqt.h:64-69). */
+static int make_bands(hpfw_oracle_plan *p)
+{
+    int64_t n = p->info.n_samples;
+    double fftres = SAMPLE_RATE / (double)n;
+    double q = pow(2.0, 1.0 / BINS_PER_OCTAVE) - pow(2.0, -1.0 / BINS_PER_OCTAVE);
+    int nb = (int)floor(BINS_PER_OCTAVE * log2(MAX_FREQ / MIN_FREQ)) + 1;
+    if (nb != HPFW_O_BINS) return -1;
+    int64_t kmin = n, kmax = 0, m = 0;
+    for (int j = 0; j < HPFW_O_BINS; ++j) {
+        double f = MIN_FREQ * pow(2.0, (double)j / BINS_PER_OCTAVE);
+        int64_t posit = (int64_t)floor(f / fftres);
+        int64_t lg = (int64_t)round(q * f / fftres);
+        if (lg < MIN_WINDOW) lg = MIN_WINDOW;
+        int64_t st = posit - lg / 2;
+        p->start[j] = (int32_t)st;
+        p->lg[j] = (int32_t)lg;
+        if (st < kmin) kmin = st;
+        if (st + lg > kmax) kmax = st + lg;
+        if (lg > m) m = lg;
+    }
+    if (kmin < 0 || kmax > n / 2) return -1; /* bands must stay inside the positive half */
+    p->info.kmin = kmin;
+    p->info.kmax = kmax;
+    p->info.m = m;
+    p->info.c = (m + DOWNSAMPLE - 1) / DOWNSAMPLE; /* valid columns only */
+    p->info.n_frames = p->info.c - (HPFW_O_CTX - 1);
+    p->info.n_hp = p->info.n_frames - HPFW_O_LAG;
+    if (p->info.n_frames < 0) p->info.n_frames = 0;
+    if (p->info.n_hp < 0) p->info.n_hp = 0;
+    return 0;
+}
+
+/* S5: V_P = DFT_P(v) in double: iterative radix-2 decimation in time, twiddles from twiddle_d,
+ * butterfly t = w*b (4 mul, 1 sub, 1 add), a' = a + t, b' = a - t.  No fused operations. */
+static void fft_r2_double(double *re, double *im, int64_t n)
+{
+    for (int64_t i = 1, j = 0; i < n; ++i) {
+        int64_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (int64_t len = 2; len <= n; len <<= 1) {
+        int64_t half = len >> 1, ts = n / len;
+        for (int64_t j = 0; j < half; ++j) {
+            double wr, wi;
+            twiddle_d(ts * j, n, &wr, &wi);
+            for (int64_t base = 0; base < n; base += len) {
+                int64_t ia = base + j, ib = ia + half;
+                double tr = wr * re[ib] - wi * im[ib];
+                double ti = wr * im[ib] + wi * re[ib];
+                re[ib] = re[ia] - tr;
+                im[ib] = im[ia] - ti;
+                re[ia] = re[ia] + tr;
+                im[ia] = im[ia] + ti;
+            }
+        }
+    }
+}
+
+static void chirp_d(int64_t m, int64_t big_m, double *c, double *s)
+{
+    /* e^{+i pi 3 m^2 / M}; the phase is reduced exactly in integers first */
+    int64_t mm = m < 0 ? -m : m;
+    int64_t r = (int64_t)(((__int128)3 * mm * mm) % (2 * big_m));
+    double ang = M_PI * (double)r / (double)big_m;
+    *c = cos(ang);
+    *s = sin(ang);
+}
+
+static int make_bluestein(hpfw_oracle_plan *p)
+{
+    int64_t big_m = p->info.m, c = p->info.c;
+    p->n_cls = 0;
+    for (int j = 0; j < HPFW_O_BINS; ++j) {
+        int64_t need = p->lg[j] + c - 1, ps = 64;
+        while (ps < need) ps <<= 1;
+        p->psize[j] = (int32_t)ps;
+        int k;
+        for (k = 0; k < p->n_cls; ++k)
+            if (p->bc[k].p == ps) break;
+        if (k == p->n_cls) {
+            if (p->n_cls == 8) return -1;
+            bluestein_class *b = &p->bc[p->n_cls++];
+            b->p = ps;
+            b->nr = make_radix_list(ps, b->radix);
+            b->tw = make_twiddle_table(ps);
+            double *re = (double *)calloc((size_t)ps, sizeof(double));
+            double *im = (double *)calloc((size_t)ps, sizeof(double));
+            /* v[m mod P] = e^{-i pi 3 m^2 / M}, m in [-(P - C), C - 1] */
+            for (int64_t mm = -(ps - c); mm <= c - 1; ++mm) {
+                double cc, ss;
+                chirp_d(mm, big_m, &cc, &ss);
+                int64_t idx = mm < 0 ? mm + ps : mm;
+                re[idx] = cc;
+                im[idx] = -ss;
+            }
+            fft_r2_double(re, im, ps);
+            b->vrev = (cf *)malloc(sizeof(cf) * (size_t)ps);
+            for (int64_t kk = 0; kk < ps; ++kk) {
+                int64_t pos = hpfw_oracle_digit_pos(kk, ps, b->radix, b->nr);
+                b->vrev[pos].r = (float)re[kk];
+                b->vrev[pos].i = (float)im[kk];
+            }
+            free(re);
+            free(im);
+        }
+        p->cls[j] = k;
+        /* G_j[k] = hann_Lg[k] * e^{+i pi 3 k^2 / M} / (M * P); hann: essentia Windowing "hann",
+         * 0.5 - 0.5 cos(2 pi i / (size - 1)), un-normalised, no zero-phase */
+        int64_t lg = p->lg[j];
+        p->g[j] = (cf *)malloc(sizeof(cf) * (size_t)lg);
+        double scale = 1.0 / ((double)big_m * (double)ps);
+        for (int64_t i = 0; i < lg; ++i) {
+            double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)(lg - 1));
+            double cc, ss;
+            chirp_d(i, big_m, &cc, &ss);
+            p->g[j][i].r = (float)(w * cc * scale);
+            p->g[j][i].i = (float)(w * ss * scale);
+        }
+    }
+    return 0;
+}
+
+hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n)
+{
+    if (n < 2) return NULL;
+    hpfw_oracle_plan *p = (hpfw_oracle_plan *)calloc(1, sizeof(*p));
+    p->info.n_samples = n;
+    /* N = n1 * n2: n1 = smallest divisor with n / n1 <= N2_MAX */
+    int64_t n1 = 0;
+    for (int64_t d = 1; d <= n; ++d) {
+        if (n % d) continue;
+        if (n / d <= N2_MAX) { n1 = d; break; }
+    }
+    int64_t n2 = n / n1;
+    p->info.n1 = n1;
+    p->info.n2 = n2;
+    p->info.h = n2 / 2 + 1;
+    p->info.n_radix = make_radix_list(n2, p->info.radix);
+    if (p->info.n_radix < 0 || make_bands(p) != 0) {
+        free(p);
+        return NULL;
+    }
+    /* n1 itself must also be 7-smooth for N to be: check through the radix helper */
+    int32_t tmp[HPFW_O_MAXRADIX];
+    if (make_radix_list(n1, tmp) < 0) {
+        free(p);
+        return NULL;
+    }
+    p->tw_n2 = make_twiddle_table(n2);
+    p->tw_n1 = make_twiddle_table(n1);
+    p->tw_big = (cf *)malloc(sizeof(cf) * (size_t)(n1 * p->info.h));
+    for (int64_t a = 0; a < n1; ++a)
+        for (int64_t k2 = 0; k2 < p->info.h; ++k2)
+            hpfw_oracle_twiddle(a * k2, n, &p->tw_big[a * p->info.h + k2].r,
+                                &p->tw_big[a * p->info.h + k2].i);
+    p->pos_n2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)n2);
+    for (int64_t k = 0; k < n2; ++k)
+        p->pos_n2[k] = (int32_t)hpfw_oracle_digit_pos(k, n2, p->info.radix, p->info.n_radix);
+    if (make_bluestein(p) != 0) {
+        hpfw_oracle_plan_destroy(p);
+        return NULL;
+    }
+    return p;
+}
+
+void hpfw_oracle_plan_destroy(hpfw_oracle_plan *p)
+{
+    if (!p) return;
+    free(p->tw_n2);
+    free(p->tw_n1);
+    free(p->tw_big);
+    free(p->pos_n2);
+    for (int j = 0; j < HPFW_O_BINS; ++j) free(p->g[j]);
+    for (int k = 0; k < p->n_cls; ++k) {
+        free(p->bc[k].tw);
+        free(p->bc[k].vrev);
+    }
+    free(p);
+}
+
+void hpfw_oracle_plan_get_info(const hpfw_oracle_plan *p, hpfw_oracle_plan_info *out) { *out = p->info; }
+
+void hpfw_oracle_plan_bands(const hpfw_oracle_plan *p, int32_t *start, int32_t *lg, int32_t *psize)
+{
+    memcpy(start, p->start, sizeof(p->start));
+    memcpy(lg, p->lg, sizeof(p->lg));
+    memcpy(psize, p->psize, sizeof(p->psize));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a1 + forward DFT (S6).  x[n] = pcm[n] / 32768 (MonoLoader on PCM16 mono 44.1 kHz, cqt.h:45). */
+/* X[k] = sum_n x[n] e^{-2 pi i k n / N}, k in [kmin, kmax), through N = n1 * n2:               */
+/*   residues n = a + n1 * n2', pairs of residues packed into one complex length-n2 FFT,         */
+/*   Hermitian split, twiddle T_N[a k2], then a length-n1 DFT as an fma chain over a.           */
+/* ------------------------------------------------------------------------------------------ */
+void hpfw_oracle_spectrum(const hpfw_oracle_plan *p, const int16_t *pcm, float *x_ri)
+{
+    const int64_t n1 = p->info.n1, n2 = p->info.n2, h = p->info.h;
+    cf *yp = (cf *)malloc(sizeof(cf) * (size_t)(n1 * h));
+    cf *z = (cf *)malloc(sizeof(cf) * (size_t)n2);
+    for (int64_t a = 0; a < n1; a += 2) {
+        int has_b = (a + 1 < n1);
+        for (int64_t t = 0; t < n2; ++t) {
+            z[t].r = (float)pcm[a + n1 * t] / 32768.0f;
+            z[t].i = has_b ? (float)pcm[a + 1 + n1 * t] / 32768.0f : 0.0f;
+        }
+        fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
+        for (int64_t k2 = 0; k2 < h; ++k2) {
+            cf zk = z[p->pos_n2[k2]];
+            cf zm = z[p->pos_n2[(n2 - k2) % n2]];
+            cf ya = {0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
+            cf yb = {0.5f * (zk.i + zm.i), 0.5f * (zm.r - zk.r)};
+            yp[a * h + k2] = c_mul(ya, p->tw_big[a * h + k2]);
+            if (has_b) yp[(a + 1) * h + k2] = c_mul(yb, p->tw_big[(a + 1) * h + k2]);
+        }
+    }
+    for (int64_t k = p->info.kmin; k < p->info.kmax; ++k) {
+        int64_t k1 = k / n2, k2 = k % n2;
+        int conj = 0;
+        if (k2 >= h) { /* X[k] = conj(X[N - k]) */
+            k1 = n1 - 1 - k1;
+            k2 = n2 - k2;
+            conj = 1;
+        }
+        float ar = 0.0f, ai = 0.0f;
+        for (int64_t a = 0; a < n1; ++a) {
+            cf d = p->tw_n1[(a * k1) % n1];
+            cf y = yp[a * h + k2];
+            ar = fmaf(d.r, y.r, ar);
+            ar = fmaf(-d.i, y.i, ar);
+            ai = fmaf(d.r, y.i, ai);
+            ai = fmaf(d.i, y.r, ai);
+        }
+        x_ri[2 * (k - p->info.kmin)] = ar;
+        x_ri[2 * (k - p->info.kmin) + 1] = conj ? -ai : ai;
+    }
+    free(z);
+    free(yp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a2 (inverse half) + a3 (S7).  For band j essentia multiplies the slice                        */
+/* X[posit_j - floor(Lg/2) + i], i < Lg, by the Hann window, places it in a length-M buffer      */
+/* and takes IFFT_M (cqt.h:66-71); hpfw keeps |c_j[3c]| (cqt.h:73-81).  The placement rotation   */
+/* and the global phase only change the phase of c_j, so                                         */
+/*   |c_j[3c]| = | (1/M) sum_i X[s_j + i] hann[i] e^{2 pi i 3 c i / M} |                          */
+/* which is evaluated as a Bluestein chirp-z transform of length P_j >= Lg_j + C - 1.            */
+/* ------------------------------------------------------------------------------------------ */
+void hpfw_oracle_cqmag(const hpfw_oracle_plan *p, const float *x_ri, float *mag)
+{
+    const cf *x = (const cf *)x_ri;
+    const int64_t c = p->info.c;
+    int64_t pmax = 0;
+    for (int k = 0; k < p->n_cls; ++k)
+        if (p->bc[k].p > pmax) pmax = p->bc[k].p;
+    cf *a = (cf *)malloc(sizeof(cf) * (size_t)pmax);
+    for (int j = 0; j < HPFW_O_BINS; ++j) {
+        const bluestein_class *b = &p->bc[p->cls[j]];
+        const int64_t ps = b->p, lg = p->lg[j], off = p->start[j] - p->info.kmin;
+        for (int64_t i = 0; i < lg; ++i) a[i] = c_mul(x[off + i], p->g[j][i]);
+        memset(a + lg, 0, sizeof(cf) * (size_t)(ps - lg));
+        fft_dif(a, ps, b->radix, b->nr, b->tw);
+        for (int64_t i = 0; i < ps; ++i) a[i] = c_mul(a[i], b->vrev[i]);
+        fft_idit(a, ps, b->radix, b->nr, b->tw);
+        for (int64_t i = 0; i < c; ++i) mag[j * c + i] = sqrtf(fmaf(a[i].r, a[i].r, a[i].i * a[i].i));
+    }
+    free(a);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a4 (S8).  convert.h:18-25 squares, convert.h:7-16 takes 10 log10 relative to the maximum     */
+/* with a 1e-10 floor and clips 80 dB below the (new) maximum, which is 0 by construction.       */
+/* log10 is evaluated in double by a fixed sequence of IEEE operations.                          */
+/* ------------------------------------------------------------------------------------------ */
+double hpfw_oracle_log10(double x)
+{
+    union { double d; uint64_t u; } v;
+    v.d = x;
+    int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+    v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL; /* m in [1, 2) */
+    double m = v.d;
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    /* atanh series: log(m) = 2 s (1 + z/3 + z^2/5 + ... + z^11/23) */
+    double r = 1.0 / 23.0;
+    r = fma(r, z, 1.0 / 21.0);
+    r = fma(r, z, 1.0 / 19.0);
+    r = fma(r, z, 1.0 / 17.0);
+    r = fma(r, z, 1.0 / 15.0);
+    r = fma(r, z, 1.0 / 13.0);
+    r = fma(r, z, 1.0 / 11.0);
+    r = fma(r, z, 1.0 / 9.0);
+    r = fma(r, z, 1.0 / 7.0);
+    r = fma(r, z, 1.0 / 5.0);
+    r = fma(r, z, 1.0 / 3.0);
+    r = fma(r, z, 1.0);
+    double lm = 2.0 * s * r;
+    return fma((double)e, 0.30102999566398119521, lm * 0.43429448190325182765);
+}
+
+static inline float db_term(float pw)
+{
+    float x = pw < 1e-10f ? 1e-10f : pw;
+    return (float)(10.0 * hpfw_oracle_log10((double)x));
+}
+
+void hpfw_oracle_db(const float *mag, int64_t n, float *s_db)
+{
+    float pmax = 0.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        float pw = mag[i] * mag[i];
+        if (pw > pmax) pmax = pw;
+    }
+    float ref = db_term(pmax);
+    for (int64_t i = 0; i < n; ++i) {
+        float l = db_term(mag[i] * mag[i]) - ref;
+        s_db[i] = l < -80.0f ? -80.0f : l;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a5 + a6 (S9).  frames[b*20 + t, n] = S[b, n + t] (hashprint_handle.h:84-90, row-major        */
+/* flatten of the 121 x 20 block), P = filters * frames (parallel_collector.h:57) as one fma    */
+/* chain per output over k = b*20 + t ascending, starting from 0.                                */
+/* ------------------------------------------------------------------------------------------ */
+void hpfw_oracle_project(const float *f, const float *s_db, int64_t c, float *proj)
+{
+    const int64_t nf = c - (HPFW_O_CTX - 1);
+    for (int64_t n = 0; n < nf; ++n) {
+        float acc[HPFW_O_NFILT];
+        for (int r = 0; r < HPFW_O_NFILT; ++r) acc[r] = 0.0f;
+        for (int b = 0; b < HPFW_O_BINS; ++b) {
+            for (int t = 0; t < HPFW_O_CTX; ++t) {
+                const float sv = s_db[b * c + n + t];
+                const float *fk = f + (size_t)(b * HPFW_O_CTX + t) * HPFW_O_NFILT;
+                for (int r = 0; r < HPFW_O_NFILT; ++r) acc[r] = fmaf(fk[r], sv, acc[r]);
+            }
+        }
+        for (int r = 0; r < HPFW_O_NFILT; ++r) proj[r * nf + n] = acc[r];
+    }
+}
+
+/* a7 + a8.  bit (63 - r) of hp[i] = (P[r,i] - P[r,i+80] >= 0)  hashprint_handle.h:119-122,137-142 */
+void hpfw_oracle_pack(const float *proj, int64_t nf, uint64_t *hp)
+{
+    for (int64_t i = 0; i + HPFW_O_LAG < nf; ++i) {
+        uint64_t v = 0;
+        for (int r = 0; r < HPFW_O_NFILT; ++r) {
+            float d = proj[r * nf + i] - proj[r * nf + i + HPFW_O_LAG];
+            if (d >= 0.0f) v |= 1ULL << (63 - r);
+        }
+        hp[i] = v;
+    }
+}
+
+int64_t hpfw_oracle_extract(const hpfw_oracle_plan *p, const float *f, const int16_t *pcm, uint64_t *hp)
+{
+    const int64_t c = p->info.c, nk = p->info.kmax - p->info.kmin;
+    if (p->info.n_hp <= 0) return 0;
+    float *x = (float *)malloc(sizeof(float) * 2 * (size_t)nk);
+    float *mag = (float *)malloc(sizeof(float) * (size_t)(HPFW_O_BINS * c));
+    float *proj = (float *)malloc(sizeof(float) * (size_t)(HPFW_O_NFILT * p->info.n_frames));
+    hpfw_oracle_spectrum(p, pcm, x);
+    hpfw_oracle_cqmag(p, x, mag);
+    hpfw_oracle_db(mag, HPFW_O_BINS * c, mag);
+    hpfw_oracle_project(f, mag, c, proj);
+    hpfw_oracle_pack(proj, p->info.n_frames, hp);
+    free(proj);
+    free(mag);
+    free(x);
+    return p->info.n_hp;
+}
+
+typedef struct {
+    const hpfw_oracle_plan *p;
+    const float *f;
+    const int16_t *pcm;
+    uint64_t *hp;
+    int64_t lo, hi;
+} extract_job;
+
+static void *extract_worker(void *arg)
+{
+    extract_job *j = (extract_job *)arg;
+    for (int64_t i = j->lo; i < j->hi; ++i)
+        hpfw_oracle_extract(j->p, j->f, j->pcm + i * j->p->info.n_samples, j->hp + i * j->p->info.n_hp);
+    return NULL;
+}
+
+int64_t hpfw_oracle_extract_batch(const hpfw_oracle_plan *p, const float *f, const int16_t *pcm,
+                                  int64_t n_clips, uint64_t *hp, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_t th[256];
+    extract_job jobs[256];
+    int64_t chunk = (n_clips + n_threads - 1) / n_threads;
+    int used = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        int64_t lo = t * chunk, hi = lo + chunk > n_clips ? n_clips : lo + chunk;
+        if (lo >= hi) break;
+        extract_job jb = {p, f, pcm, hp, lo, hi};
+        jobs[used] = jb;
+        pthread_create(&th[used], NULL, extract_worker, &jobs[used]);
+        ++used;
+    }
+    for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+    return p->info.n_hp;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a9.  storage.h:33-54                                                                         */
+/* ------------------------------------------------------------------------------------------ */
+void hpfw_oracle_match_clip(const uint64_t *q, int64_t k, const uint64_t *r, int64_t n,
+                            uint64_t *best_dist, int64_t *best_off)
+{
+    uint64_t best = UINT64_MAX;
+    int64_t boff = 0;
+    if (n < k) k = n;
+    for (int64_t i = 0; i < n - k + 1; ++i) {
+        uint64_t cnt = 0;
+        for (int64_t j = 0; j < k; ++j) cnt += (uint64_t)__builtin_popcountll(q[j] ^ r[i + j]);
+        if (cnt < best) {
+            best = cnt;
+            boff = i;
+        }
+    }
+    *best_dist = best;
+    *best_off = boff;
+}
+
+typedef struct {
+    const uint64_t *db;
+    const int64_t *db_off;
+    int64_t n_clips;
+    const uint64_t *q;
+    const int64_t *q_off;
+    int topk;
+    hpfw_oracle_hit *out;
+    int64_t lo, hi;
+} search_job;
+
+static void *search_worker(void *arg)
+{
+    search_job *s = (search_job *)arg;
+    for (int64_t qi = s->lo; qi < s->hi; ++qi) {
+        hpfw_oracle_hit *top = s->out + qi * s->topk;
+        int have = 0;
+        for (int t = 0; t < s->topk; ++t) {
+            top[t].dist = 0xffffffffu;
+            top[t].clip = 0xffffffffu;
+            top[t].offset = 0;
+            top[t].pad = 0;
+        }
+        for (int64_t cidx = 0; cidx < s->n_clips; ++cidx) {
+            int64_t n = s->db_off[cidx + 1] - s->db_off[cidx];
+            int64_t k = s->q_off[qi + 1] - s->q_off[qi];
+            if (n <= 0 || k <= 0) continue;
+            uint64_t d;
+            int64_t off;
+            hpfw_oracle_match_clip(s->q + s->q_off[qi], k, s->db + s->db_off[cidx], n, &d, &off);
+            /* insertion by ascending (dist, clip): clips arrive in ascending id, so a strict
+             * comparison on dist keeps the earlier clip first (storage.h:56) */
+            int pos = have;
+            while (pos > 0 && top[pos - 1].dist > d) --pos;
+            if (pos >= s->topk) continue;
+            int last = have < s->topk ? have : s->topk - 1;
+            for (int t = last; t > pos; --t) top[t] = top[t - 1];
+            top[pos].dist = (uint32_t)d;
+            top[pos].clip = (uint32_t)cidx;
+            top[pos].offset = (int32_t)off;
+            top[pos].pad = 0;
+            if (have < s->topk) ++have;
+        }
+    }
+    return NULL;
+}
+
+void hpfw_oracle_search_topk(const uint64_t *db, const int64_t *db_off, int64_t n_clips,
+                             const uint64_t *q, const int64_t *q_off, int64_t n_q, int topk,
+                             hpfw_oracle_hit *out, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_t th[256];
+    search_job jobs[256];
+    int64_t chunk = (n_q + n_threads - 1) / n_threads;
+    int used = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        int64_t lo = t * chunk, hi = lo + chunk > n_q ? n_q : lo + chunk;
+        if (lo >= hi) break;
+        search_job jb = {db, db_off, n_clips, q, q_off, topk, out, lo, hi};
+        jobs[used] = jb;
+        pthread_create(&th[used], NULL, search_worker, &jobs[used]);
+        ++used;
+    }
+    for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+}

@@ -1,0 +1,110 @@
+/*
+ * hpfw_oracle.h -- CPU restatement (plain C) of the hpfw index()/search() hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker / the reported CPU baseline.  The product path (hpfw_amd/csrc, include/) never
+ * includes, links or calls anything from here.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
+ *  and it cannot be compiled in this image (essentia, cereal, spdlog,
+ * boost and the Eigen/Core umbrella header are absent; DESIGN.md "Oracle").  The restatement is
+ * pinned instead to (1) the reference sources read as text, cited per function below, and
+ * (2) an independent float64 numpy statement of the same mathematics (oracle/nsgt_f64.py).
+ *
+ * Every function states the reference file:line it follows.  Where the reference leaves the
+ * floating-point evaluation order to a third party (essentia/FFTW, Eigen/MKL, -ffast-math), the
+ * order is fixed by DESIGN.md "Arithmetic specification"; the HIP kernels implement the same
+ * specification so that their results can be compared bit for bit.
+ */
+#ifndef HPFW_ORACLE_H
+#define HPFW_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPFW_O_BINS 121      /* CQT<..., NumberBins = 121, ...>  cqt.h:21                  */
+#define HPFW_O_CTX 20        /* HashprintHandle<uint64_t, CQT<>, 20, 80>  live_song_id.h:16 */
+#define HPFW_O_LAG 80
+#define HPFW_O_NFILT 64      /* sizeof(uint64_t) * 8  hashprint_handle.h:64                 */
+#define HPFW_O_FRAME (HPFW_O_BINS * HPFW_O_CTX) /* 2420  hashprint_handle.h:60              */
+#define HPFW_O_MAXRADIX 24
+
+typedef struct hpfw_oracle_plan hpfw_oracle_plan;
+
+typedef struct {
+    int64_t n_samples; /* N                                                        */
+    int64_t n1;        /* number of residue classes (short DFT length)             */
+    int64_t n2;        /* long in-core FFT length, N = n1 * n2                      */
+    int64_t h;         /* n2 / 2 + 1 : stored half spectrum of each residue FFT     */
+    int64_t kmin;      /* first forward-DFT bin consumed by any CQ band            */
+    int64_t kmax;      /* one past the last                                        */
+    int64_t m;         /* M = max_j Lg_j : length of every band's inverse DFT      */
+    int64_t c;         /* C = ceil(M / 3) spectrogram columns                      */
+    int64_t n_frames;  /* C - 19                                                   */
+    int64_t n_hp;      /* C - 99 (0 when the clip is too short)                    */
+    int32_t n_radix;   /* passes of the length-n2 FFT                              */
+    int32_t radix[HPFW_O_MAXRADIX];
+} hpfw_oracle_plan_info;
+
+/* ---- geometry: essentia NSGConstantQ as configured at cqt.h:54-61 ---- */
+hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n_samples); /* NULL when N is not 7-smooth */
+void hpfw_oracle_plan_destroy(hpfw_oracle_plan *p);
+void hpfw_oracle_plan_get_info(const hpfw_oracle_plan *p, hpfw_oracle_plan_info *out);
+/* per band j = 0..120: slice start in the forward DFT, window length Lg_j, Bluestein size P_j */
+void hpfw_oracle_plan_bands(const hpfw_oracle_plan *p, int32_t *start, int32_t *lg, int32_t *psize);
+
+/* ---- a1 + a2 (forward half): PCM16 -> forward DFT bins [kmin, kmax)   cqt.h:45-52, 66-71 ---- */
+void hpfw_oracle_spectrum(const hpfw_oracle_plan *p, const int16_t *pcm, float *x_ri /* [kmax-kmin][2] */);
+/* ---- a2 (band inverse DFT) + a3: |c_j[3c]|, bin-major [121][C]         cqt.h:66-81 ---- */
+void hpfw_oracle_cqmag(const hpfw_oracle_plan *p, const float *x_ri, float *mag);
+/* ---- a4: amplitude_to_db -> power_to_db                                convert.h:7-25 ---- */
+void hpfw_oracle_db(const float *mag, int64_t n, float *s_db);
+/* ---- a5 + a6: implicit calc_frames and filters * frames
+ *      hashprint_handle.h:79-93, parallel_collector.h:57,127.
+ *      f_colmajor: Filters = Matrix<float,64,Dynamic> column-major (hashprint_handle.h:68):
+ *      element (r,k) at r + 64*k.  s_db bin-major [121][c].  out P row-major [64][c-19]. ---- */
+void hpfw_oracle_project(const float *f_colmajor, const float *s_db, int64_t c, float *proj);
+/* ---- a7 + a8: calc_fingerprint + fingerprint_to_hashprint   hashprint_handle.h:115-142 ---- */
+void hpfw_oracle_pack(const float *proj, int64_t n_frames, uint64_t *hp /* [n_frames-80] */);
+/* ---- a1..a8 for one clip (calc_hashprint, parallel_collector.h:54-59); returns n_hp ---- */
+int64_t hpfw_oracle_extract(const hpfw_oracle_plan *p, const float *f_colmajor, const int16_t *pcm,
+                            uint64_t *hp);
+/* ---- a10: static chunks of ceil(n/T) clips per thread (flow_builder.hpp:321-325) ---- */
+int64_t hpfw_oracle_extract_batch(const hpfw_oracle_plan *p, const float *f_colmajor,
+                                  const int16_t *pcm, int64_t n_clips, uint64_t *hp, int n_threads);
+
+/* ---- a9: MemoryStorage::find inner loops, storage.h:33-54: per reference clip the first
+ *      strict minimum over offsets of sum_j popcount(q[j] ^ r[off + j]), k = min(k, n). ---- */
+void hpfw_oracle_match_clip(const uint64_t *q, int64_t k, const uint64_t *r, int64_t n,
+                            uint64_t *best_dist, int64_t *best_off);
+
+typedef struct {
+    uint32_t dist;
+    uint32_t clip;
+    int32_t offset;
+    uint32_t pad;
+} hpfw_oracle_hit;
+
+/* top-k over the whole database, ascending (dist, clip id): storage.h:56-60 keeps the first
+ * strict minimum in database order; the notebook keeps the 10 smallest (liveid.ipynb cell 9).
+ * db: concatenated hashprints, db_off[n_clips+1].  Unused slots: dist = clip = 0xffffffff. */
+void hpfw_oracle_search_topk(const uint64_t *db, const int64_t *db_off, int64_t n_clips,
+                             const uint64_t *q, const int64_t *q_off, int64_t n_q, int topk,
+                             hpfw_oracle_hit *out /* [n_q][topk] */, int n_threads);
+
+/* ---- pieces exposed so tests can pin them one by one ---- */
+double hpfw_oracle_log10(double x);                                       /* DESIGN.md "dB" */
+void hpfw_oracle_twiddle(int64_t m, int64_t n, float *re, float *im);     /* e^{-2 pi i m/n} */
+/* in-place forward DIF FFT (digit-reversed output) and its inverse DIT twin */
+void hpfw_oracle_fft_dif(float *a_ri, int64_t n, const int32_t *radix, int n_radix);
+void hpfw_oracle_fft_idit(float *a_ri, int64_t n, const int32_t *radix, int n_radix);
+int64_t hpfw_oracle_digit_pos(int64_t k, int64_t n, const int32_t *radix, int n_radix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+"""Float64 numpy statement of the mathematics behind the hot path -- the independent pin of the
+C oracle (TEST INFRASTRUCTURE ONLY; PARITY UNPINNED against the reference, see hpfw_oracle.h).
+
+It follows the published algorithm directly, with none of the C oracle's decomposition:
+one full-length FFT, one length-M inverse FFT per band, every third sample.
+
+  essentia NSGConstantQ as configured at /root/reference/include/hpfw/spectrum/cqt.h:54-61
+  (Holighaus/Doerfler/Velasco/Grill NSGT; essentia nsgconstantq.cpp designWindow/compute):
+    f_j = fmin 2^(j/24), bw_j = (2^(1/24) - 2^(-1/24)) f_j, fftres = sr / N
+    posit_j = floor(f_j / fftres), Lg_j = max(round(bw_j / fftres), minimumWindow = 96)
+    window = hann(Lg_j) = 0.5 - 0.5 cos(2 pi i / (Lg_j - 1)), rasterize "full": M = max_j Lg_j
+    c_j = IFFT_M( circular placement of X[posit_j - floor(Lg_j/2) + i] * hann[i] )
+  hpfw keeps |c_j[3 c]| (cqt.h:73-81) and converts to dB (convert.h:7-25).
+"""
+import numpy as np
+
+SR = 44100.0
+FMIN, FMAX = 130.81, 4186.01
+BPO = 24
+MIN_WINDOW = 96
+BINS = 121
+
+
+def bands(n):
+    fftres = SR / n
+    q = 2.0 ** (1.0 / BPO) - 2.0 ** (-1.0 / BPO)
+    nb = int(np.floor(BPO * np.log2(FMAX / FMIN))) + 1
+    assert nb == BINS
+    f = FMIN * 2.0 ** (np.arange(nb) / BPO)
+    posit = np.floor(f / fftres).astype(np.int64)
+    lg = np.maximum(np.floor(q * f / fftres + 0.5).astype(np.int64), MIN_WINDOW)
+    return posit, lg
+
+
+def cq_magnitudes(pcm):
+    """|c_j[3c]| in float64, bin-major [121][ceil(M/3)], for int16 PCM."""
+    x = np.asarray(pcm, np.float64) / 32768.0
+    n = x.size
+    spec = np.fft.fft(x)
+    posit, lg = bands(n)
+    m = int(lg.max())
+    cols = (m + 2) // 3
+    out = np.zeros((BINS, cols))
+    for j in range(BINS):
+        L = int(lg[j])
+        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(L) / (L - 1))
+        idx = (posit[j] - L // 2 + np.arange(L)) % n
+        prod = spec[idx] * win
+        buf = np.zeros(m, np.complex128)
+        # essentia places the upper half of the slice at the start and the lower half at the end
+        # of the length-M buffer (band centre at index 0); only the phase depends on this.
+        half = L // 2
+        buf[: L - half] = prod[half:]
+        buf[m - half:] = prod[:half]
+        cj = np.fft.ifft(buf)  # 1/M normalised
+        out[j] = np.abs(cj[::3])[:cols]
+    return out
+
+
+def amplitude_to_db(mag):
+    """convert.h:18-25 -> 7-16 in float64."""
+    p = np.asarray(mag, np.float64) ** 2
+    mx = max(1e-10, float(p.max()))
+    log_spec = 10.0 * np.log10(np.where(p < 1e-10, 1e-10, p)) - 10.0 * np.log10(mx)
+    mx2 = log_spec.max()
+    return np.where(log_spec < mx2 - 80.0, mx2 - 80.0, log_spec)
+
+
+def project(filters_rk, s_db):
+    """hashprint_handle.h:79-93 + parallel_collector.h:57: filters [64][2420] (row r, col k),
+    s_db [121][C] -> [64][C-19] in float64."""
+    s = np.asarray(s_db, np.float64)
+    c = s.shape[1]
+    nf = c - 19
+    frames = np.zeros((BINS * 20, nf))
+    for b in range(BINS):
+        for t in range(20):
+            frames[b * 20 + t] = s[b, t:t + nf]
+    return np.asarray(filters_rk, np.float64) @ frames
+
+
+def pack(proj):
+    """hashprint_handle.h:115-142: delta over 80 frames, >= 0, MSB-first packing."""
+    d = proj[:, :-80] - proj[:, 80:]
+    bits = (d >= 0)
+    w = (np.uint64(1) << np.arange(63, -1, -1, dtype=np.uint64))
+    return (bits.astype(np.uint64) * w[:, None]).sum(axis=0, dtype=np.uint64)
