@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X.
+
+Metric (BASELINE.json): "hashprints/sec (index) + Hamming matches/sec (search), 30 s@44.1 kHz clips".
+One step = one pass of the extraction hot path (int16 PCM -> CQT -> dB -> projection -> 64-bit
+hashprints) over the batch of configs[1]: 1 000 x 30 s synthetic 44.1 kHz clips per GPU, inputs
+already resident in HBM.  `value` = hashprints/s over all ranks (weak scaling: every rank extracts
+its own 1 000 clips, no collective on this path).  The search half of the metric (configs[2]:
+10 000-clip index per GPU, 1 000 x 5 s queries, top-10, one RCCL all-gather of the per-shard
+top-k) is timed in the same run and reported under "search".
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through
+python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PROJECT_FLOP_PER_CLIP = 2.0 * 64 * 2420 * 2400       # filters [64x2420] . frames [2420x2400]
+MFMA_F32_PEAK_TFLOPS = 157.3                         # MI355X_MICROARCH.md: dense f32 MFMA peak
+VALU_PAIR_PEAK = 256 * 4 * 32 * 2.4e9 / 4            # 4 VALU lane-ops per 64-bit pair
+
+
+def synth_clips_gpu(torch, n_clips, n_samples, seed, device, chunk=25):
+    """synthetic 'songs' generated on the device: 0.25 s notes of 6 partials in the CQ range with
+    10 ms fades plus -30 dBFS noise, int16.  (Same recipe as hpfw_amd.synth.gen_clip, torch RNG.)"""
+    sr, note = 44100, 11025
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((n_clips, n_samples), dtype=torch.int16, device=device)
+    n_notes = (n_samples + note - 1) // note
+    t = torch.arange(note, device=device, dtype=torch.float32) / sr
+    ramp = torch.arange(note, device=device, dtype=torch.float32)
+    fade = torch.clamp(torch.minimum(ramp, note - 1 - ramp) / (0.010 * sr), max=1.0)
+    for c0 in range(0, n_clips, chunk):
+        nc = min(chunk, n_clips - c0)
+        f = 130.81 * (4186.01 / 130.81) ** torch.rand((nc, n_notes, 6, 1), generator=g, device=device)
+        a = 0.05 + 0.15 * torch.rand((nc, n_notes, 6, 1), generator=g, device=device)
+        ph = 6.2831853 * torch.rand((nc, n_notes, 6, 1), generator=g, device=device)
+        x = (a * torch.sin(6.2831853 * f * t + ph)).sum(2) * fade          # [nc][notes][note]
+        x = x.reshape(nc, n_notes * note)[:, :n_samples]
+        x = x + 0.0316 * torch.randn((nc, n_samples), generator=g, device=device)
+        x = x / torch.clamp(x.abs().amax(dim=1, keepdim=True), min=1.0)
+        out[c0:c0 + nc] = torch.round(x * 32767).to(torch.int16)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clips", type=int, default=1000, help="30 s clips per GPU (configs[1]: 1000)")
+    ap.add_argument("--seconds", type=float, default=30.0)
+    ap.add_argument("--batch", type=int, default=0, help="clips per internal pass (0 = library default)")
+    ap.add_argument("--index-clips", type=int, default=10000, help="search: indexed clips per GPU")
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips-per-core", type=int, default=64)
+    args = ap.parse_args()
+
+    import torch
+    import hpfw_amd
+    from hpfw_amd import dist as hdist, synth
+
+    rank, local_rank, world = hdist.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        return float(t.item())
+
+    gpu = hpfw_amd.Gpu(local_rank)
+    filt = synth.make_filters()
+    gpu.set_filters(filt)
+    if args.batch:
+        gpu.set_batch(args.batch)
+    n_samples = int(round(args.seconds * 44100))
+    geo = gpu.geometry(n_samples)
+    n_clips = args.clips
+    stream = torch.cuda.current_stream().cuda_stream
+
+    pcm = synth_clips_gpu(torch, n_clips, n_samples, 0x68706677 + rank, device)
+    hp = torch.empty((n_clips, geo.n_hp), dtype=torch.int64, device=device)
+    torch.cuda.synchronize()
+
+    def step():
+        gpu.extract_dev(pcm.data_ptr(), n_samples, n_clips, hp.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # dominant kernel (f32 MFMA projection): one HIP event pair per launch, on the launch stream
+    gpu.set_kernel_timing(1 << hpfw_amd.KERNEL_KINDS.index("project_mfma"))
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gpu.timer_start(stream)
+    for _ in range(args.steps):
+        step()
+    ev_ms = gpu.timer_stop(stream)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    dt = max_over_ranks(dt)
+    kt = gpu.kernel_timing()
+    gpu.set_kernel_timing(0)
+    ms_per_step = dt * 1e3 / args.steps
+    hashprints = float(n_clips) * geo.n_hp * world * args.steps
+    value = hashprints / dt
+
+    pj_ms, pj_launches = kt["project_mfma"]
+    clips_per_launch = n_clips * args.steps / max(pj_launches, 1)
+    achieved = PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0) * clips_per_launch / (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12 \
+        if pj_launches else 0.0
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr_path):
+        try:
+            traffic = json.load(open(tr_path)).get("project_mfma_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "project_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "avg_launch_ms": round(pj_ms / max(pj_launches, 1), 4), "launches": pj_launches,
+                "flop_per_clip": PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0),
+                "clips_per_launch": clips_per_launch}
+
+    # per-kernel split of one extra (untimed) pass, for the record
+    gpu.set_kernel_timing(-1)
+    step()
+    torch.cuda.synchronize()
+    split = {k: round(v[0], 3) for k, v in gpu.kernel_timing().items() if v[1]}
+    gpu.set_kernel_timing(0)
+
+    # parity sample: a few clips of the batch against the oracle (checker only, outside any timing)
+    parity = None
+    cpu_baseline = None
+    if rank == 0:
+        from oracle import oracle
+        plan = oracle.Plan(n_samples)
+        idx = sorted(set([0, n_clips // 2, n_clips - 1]))
+        host = pcm[idx].cpu().numpy()
+        want = np.stack([plan.extract(filt, c) for c in host])
+        got = hp[idx].cpu().numpy().view(np.uint64)
+        parity = {"clips_checked": len(idx), "bit_identical": bool(np.array_equal(got, want))}
+        if world == 1 and not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            n_cpu = min(n_clips, max(cores, args.cpu_clips_per_core * cores))
+            sample = pcm[:n_cpu].cpu().numpy()
+            t1 = time.perf_counter()
+            plan.extract_batch(filt, sample, n_threads=cores)
+            cdt = time.perf_counter() - t1
+            cpu_baseline = {"value": round(n_cpu * geo.n_hp / cdt, 1), "unit": "hashprints/s", "cores": cores,
+                            "kind": "port",
+                            "sample": f"{n_cpu} of the same {args.seconds:g} s clips, oracle/hpfw_oracle.c "
+                                      f"(own C restatement, -O3 -mfma, no FFTW/Eigen/TBB on this box), "
+                                      f"{cores} threads in static chunks as flow_builder.hpp:321-325, {cdt:.1f} s",
+                            "clips_per_s": round(n_cpu / cdt, 2)}
+
+    search = None
+    if not args.no_search:
+        search = bench_search(torch, tdist if world > 1 else None, gpu, hdist, synth, args, rank, world, device,
+                              stream, barrier, max_over_ranks)
+
+    if rank == 0:
+        line = {
+            "metric": "hashprints/sec (index) + Hamming matches/sec (search), 30 s@44.1 kHz clips",
+            "value": round(value, 1), "unit": "hashprints/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {n_clips} x {args.seconds:g} s synthetic 44.1 kHz PCM16 clips per GPU, "
+                                   "hashprint extraction only (CQT + dB + projection + bit pack), inputs resident in HBM",
+                       "clips_per_gpu": n_clips, "clip_seconds": args.seconds, "hashprints_per_clip": geo.n_hp,
+                       "parallelism": f"clips sharded over {world} GPU(s), no collective on this path"},
+            "clips_per_s": round(value / geo.n_hp, 1),
+            "event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
+            "kernel_ms_one_pass": split,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "search": search,
+        }
+        print(json.dumps(line), flush=True)
+    gpu.close()
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, stream, barrier, max_over_ranks):
+    """configs[2] per GPU (configs[3] layout when world > 1): index shard resident in HBM, replicated
+    queries, scan + per-shard top-k on every rank, one all-gather of Q x k x 16 B, identical merge."""
+    import hpfw_amd
+    n_hp, kq = 2320, 305
+    n_local = args.index_clips
+    g = torch.Generator(device=device)
+    g.manual_seed(0x1D8 + rank)
+    db = torch.randint(-2 ** 63, 2 ** 63 - 1, (n_local, n_hp), dtype=torch.int64, generator=g, device=device)
+    # queries are planted in shard 0's clips (every rank regenerates shard 0's first rows the same way)
+    g0 = torch.Generator(device=device)
+    g0.manual_seed(0x1D8)
+    db0 = db if rank == 0 else torch.randint(-2 ** 63, 2 ** 63 - 1, (n_local, n_hp), dtype=torch.int64,
+                                              generator=g0, device=device)
+    nq = args.queries
+    src = torch.arange(nq, device=device) % n_local
+    offs = (torch.arange(nq, device=device) * 37) % (n_hp - kq + 1)
+    cols = offs[:, None] + torch.arange(kq, device=device)[None, :]
+    q = db0[src[:, None], cols].clone()
+    gq = torch.Generator(device=device)
+    gq.manual_seed(0x51)
+    for _ in range(6):   # six random bit flips per hashprint
+        q ^= torch.ones_like(q) << torch.randint(0, 63, q.shape, generator=gq, device=device)
+    del db0
+    lo = rank * n_local
+    gpu.index_clear()
+    gpu.index_set_clip_base(lo)
+    gpu.index_add_dev(db.data_ptr(), np.arange(0, (n_local + 1) * n_hp, n_hp, dtype=np.int64), stream)
+    q_off = np.arange(0, (nq + 1) * kq, kq, dtype=np.int64)
+    hits = torch.empty((nq, args.topk, 4), dtype=torch.int32, device=device)
+    gathered = torch.empty((world, nq, args.topk, 4), dtype=torch.int32, device=device) if world > 1 else None
+
+    def one():
+        gpu.search_topk_dev(q.data_ptr(), q_off, args.topk, hits.data_ptr(), stream)
+        if world > 1:
+            tdist.all_gather_into_tensor(gathered, hits)
+
+    one()
+    torch.cuda.synchronize()
+    gpu.set_kernel_timing(1 << hpfw_amd.KERNEL_KINDS.index("hamming_scan"))
+    reps = 2
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    torch.cuda.synchronize()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    kt = gpu.kernel_timing()
+    gpu.set_kernel_timing(0)
+    pairs = float(nq) * n_local * world * kq * (n_hp - kq + 1) * reps
+    res = hits.cpu().numpy().reshape(nq, args.topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(nq, args.topk)
+    if world > 1:
+        per = gathered.cpu().numpy().reshape(world, nq, args.topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(
+            world, nq, args.topk)
+        res = hpfw_amd.merge_topk(per, args.topk)
+    ok = bool((res[:, 0]["clip"] == (np.arange(nq) % n_local)).all()
+              and (res[:, 0]["offset"] == ((np.arange(nq) * 37) % (n_hp - kq + 1))).all())
+    scan_ms, scan_l = kt["hamming_scan"]
+    pairs_rank_launch = float(nq) * n_local * kq * (n_hp - kq + 1) * reps / max(scan_l, 1)
+    scan_rate = pairs_rank_launch / (scan_ms / max(scan_l, 1) * 1e-3) if scan_l else 0.0
+    return {"value": round(pairs / dt, 1), "unit": "hashprint-pair Hamming matches/s",
+            "workload": f"configs[2] per GPU: {n_local}-clip index ({n_hp} hashprints each) resident in HBM, "
+                        f"{nq} x {kq}-hashprint queries, exhaustive sliding scan, top-{args.topk}"
+                        + (f", all-gather of per-shard top-k over {world} ranks (RCCL)" if world > 1 else ""),
+            "ms_per_search": round(dt * 1e3 / reps, 3), "queries_per_s": round(nq * reps / dt, 1),
+            "planted_queries_found": ok,
+            "scan_kernel": {"pairs_per_s": round(scan_rate, 1), "valu_peak_pairs_per_s": VALU_PAIR_PEAK,
+                            "frac_of_valu_peak": round(scan_rate / VALU_PAIR_PEAK, 4),
+                            "note": "integer VALU-issue bound (2 v_xor + 2 v_bcnt per pair); HBM is not binding"}}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,246 @@
+"""ctypes binding of libhpfw_gpu.so (include/hpfw_gpu.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing the symbols
+raises.  The library is built in-tree by hpfw_amd.build.build() (hipcc --offload-arch=gfx950).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhpfw_gpu.so")
+
+HIT_DTYPE = np.dtype([("dist", "<u4"), ("clip", "<u4"), ("offset", "<i4"), ("pad", "<u4")])
+
+KERNEL_KINDS = ("fwd_rows", "fwd_cols", "cq_chirpz", "db", "project_mfma", "delta_pack",
+                "hamming_scan", "topk")
+
+# every symbol include/hpfw_gpu.h declares (tests check that the library exports all of them)
+EXPORTS = (
+    "hpfw_gpu_last_error", "hpfw_gpu_version", "hpfw_gpu_create", "hpfw_gpu_destroy",
+    "hpfw_gpu_set_filters", "hpfw_gpu_geometry", "hpfw_gpu_extract_pcm16",
+    "hpfw_gpu_extract_pcm16_host", "hpfw_gpu_set_batch", "hpfw_gpu_stage_spectrum",
+    "hpfw_gpu_stage_cqmag", "hpfw_gpu_stage_db", "hpfw_gpu_stage_project", "hpfw_gpu_stage_pack",
+    "hpfw_gpu_index_clear", "hpfw_gpu_index_add", "hpfw_gpu_index_add_device",
+    "hpfw_gpu_index_size", "hpfw_gpu_index_set_clip_base", "hpfw_gpu_search_topk_device",
+    "hpfw_gpu_search_topk", "hpfw_gpu_merge_topk", "hpfw_gpu_timer_start", "hpfw_gpu_timer_stop",
+    "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
+    "par_collector_new", "par_collector_del", "par_collector_prepare",
+    "par_collector_calc_hashprint", "par_collector_save", "par_collector_load",
+    "prepare_result_free", "calc_hashprint_result_free",
+)
+
+
+class Geometry(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int64) for n in
+                ("n_samples", "n1", "n2", "kmin", "kmax", "m", "c", "n_frames", "n_hp")]
+
+
+class FilenameHashprintPair(ctypes.Structure):
+    """modules/python/pyhpfw/pyhpfw.py:7-10 of the reference."""
+    _fields_ = [("filename", ctypes.c_char_p),
+                ("hashprint", ctypes.POINTER(ctypes.c_uint64)),
+                ("hp_size", ctypes.c_int)]
+
+
+class HpfwError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library, or raise: the product has no other path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HpfwError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32, u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32
+    L.hpfw_gpu_last_error.restype = ctypes.c_char_p
+    L.hpfw_gpu_version.restype = ctypes.c_char_p
+    L.hpfw_gpu_create.argtypes = [i32, ctypes.POINTER(vp)]
+    L.hpfw_gpu_destroy.argtypes = [vp]
+    L.hpfw_gpu_destroy.restype = None
+    L.hpfw_gpu_set_filters.argtypes = [vp, vp]
+    L.hpfw_gpu_geometry.argtypes = [vp, i64, ctypes.POINTER(Geometry)]
+    L.hpfw_gpu_extract_pcm16.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_extract_pcm16_host.argtypes = [vp, vp, i64, i64, vp]
+    L.hpfw_gpu_set_batch.argtypes = [vp, i32]
+    L.hpfw_gpu_stage_spectrum.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_stage_cqmag.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_stage_db.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_stage_project.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_stage_pack.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_index_clear.argtypes = [vp]
+    L.hpfw_gpu_index_add.argtypes = [vp, vp, vp, i64]
+    L.hpfw_gpu_index_add_device.argtypes = [vp, vp, vp, i64, vp]
+    L.hpfw_gpu_index_size.argtypes = [vp]
+    L.hpfw_gpu_index_size.restype = i64
+    L.hpfw_gpu_index_set_clip_base.argtypes = [vp, u32]
+    L.hpfw_gpu_search_topk_device.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.hpfw_gpu_search_topk.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.hpfw_gpu_merge_topk.argtypes = [vp, i32, i64, i32, vp]
+    L.hpfw_gpu_timer_start.argtypes = [vp, vp]
+    L.hpfw_gpu_timer_stop.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.hpfw_gpu_set_kernel_timing.argtypes = [vp, i32]
+    L.hpfw_gpu_get_kernel_timing.argtypes = [vp, vp, vp, vp, ctypes.POINTER(i32)]
+    L.hpfw_gpu_plan_checksum.argtypes = [i64, vp]
+    L.par_collector_new.restype = vp
+    L.par_collector_del.argtypes = [vp]
+    L.par_collector_del.restype = None
+    L.par_collector_prepare.restype = ctypes.POINTER(FilenameHashprintPair)
+    L.par_collector_prepare.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32, ctypes.POINTER(i32)]
+    L.par_collector_calc_hashprint.restype = ctypes.POINTER(ctypes.c_uint64)
+    L.par_collector_calc_hashprint.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32)]
+    L.par_collector_load.argtypes = [vp, ctypes.c_char_p]
+    L.par_collector_load.restype = None
+    L.par_collector_save.argtypes = [vp, ctypes.c_char_p]
+    L.par_collector_save.restype = None
+    L.prepare_result_free.argtypes = [vp, i32]
+    L.prepare_result_free.restype = None
+    L.calc_hashprint_result_free.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    L.calc_hashprint_result_free.restype = None
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise HpfwError(f"hpfw_gpu error {rc}: {lib().hpfw_gpu_last_error().decode()}")
+
+
+def _hp(a):
+    """host pointer of a contiguous numpy array"""
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Gpu:
+    """One handle = one MI355X device.  Device-pointer methods take integers (tensor.data_ptr())."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        check(lib().hpfw_gpu_create(int(device), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hpfw_gpu_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- configuration -------------------------------------------------------------------
+    def set_filters(self, filters_colmajor):
+        f = np.ascontiguousarray(filters_colmajor, np.float32).ravel()
+        if f.size != 64 * 2420:
+            raise ValueError("filters must hold 64 x 2420 floats (column-major)")
+        check(lib().hpfw_gpu_set_filters(self._h, _hp(f)))
+
+    def geometry(self, n_samples):
+        g = Geometry()
+        check(lib().hpfw_gpu_geometry(self._h, int(n_samples), ctypes.byref(g)))
+        return g
+
+    def set_batch(self, clips_per_pass):
+        check(lib().hpfw_gpu_set_batch(self._h, int(clips_per_pass)))
+
+    # ---- extraction ----------------------------------------------------------------------
+    def extract_dev(self, d_pcm, n_samples, n_clips, d_hp, stream=0):
+        check(lib().hpfw_gpu_extract_pcm16(self._h, d_pcm, n_samples, n_clips, d_hp, stream))
+
+    def extract(self, pcm):
+        """pcm: int16 [n_clips][n_samples] (host) -> uint64 [n_clips][n_hp]"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        g = self.geometry(pcm.shape[1])
+        hp = np.zeros((pcm.shape[0], g.n_hp), np.uint64)
+        check(lib().hpfw_gpu_extract_pcm16_host(self._h, _hp(pcm), pcm.shape[1], pcm.shape[0], _hp(hp)))
+        return hp
+
+    def stage_spectrum_dev(self, d_pcm, n_samples, n_clips, d_x, stream=0):
+        check(lib().hpfw_gpu_stage_spectrum(self._h, d_pcm, n_samples, n_clips, d_x, stream))
+
+    def stage_cqmag_dev(self, d_x, n_samples, n_clips, d_mag, stream=0):
+        check(lib().hpfw_gpu_stage_cqmag(self._h, d_x, n_samples, n_clips, d_mag, stream))
+
+    def stage_db_dev(self, d_mag, n_clips, c, d_db, stream=0):
+        check(lib().hpfw_gpu_stage_db(self._h, d_mag, n_clips, c, d_db, stream))
+
+    def stage_project_dev(self, d_db, n_clips, c, d_proj, stream=0):
+        check(lib().hpfw_gpu_stage_project(self._h, d_db, n_clips, c, d_proj, stream))
+
+    def stage_pack_dev(self, d_proj, n_clips, n_frames, d_hp, stream=0):
+        check(lib().hpfw_gpu_stage_pack(self._h, d_proj, n_clips, n_frames, d_hp, stream))
+
+    # ---- index + search ------------------------------------------------------------------
+    def index_clear(self):
+        check(lib().hpfw_gpu_index_clear(self._h))
+
+    def index_add(self, hp, offsets):
+        hp = np.ascontiguousarray(hp, np.uint64).ravel()
+        off = np.ascontiguousarray(offsets, np.int64)
+        check(lib().hpfw_gpu_index_add(self._h, _hp(hp), _hp(off), off.size - 1))
+
+    def index_add_dev(self, d_hp, offsets, stream=0):
+        off = np.ascontiguousarray(offsets, np.int64)
+        check(lib().hpfw_gpu_index_add_device(self._h, d_hp, _hp(off), off.size - 1, stream))
+
+    def index_size(self):
+        return int(lib().hpfw_gpu_index_size(self._h))
+
+    def index_set_clip_base(self, base):
+        check(lib().hpfw_gpu_index_set_clip_base(self._h, int(base)))
+
+    def search_topk(self, q_hp, q_off, k):
+        q = np.ascontiguousarray(q_hp, np.uint64).ravel()
+        off = np.ascontiguousarray(q_off, np.int64)
+        out = np.zeros((off.size - 1, k), HIT_DTYPE)
+        check(lib().hpfw_gpu_search_topk(self._h, _hp(q), _hp(off), off.size - 1, int(k), _hp(out)))
+        return out
+
+    def search_topk_dev(self, d_q, q_off, k, d_out, stream=0):
+        off = np.ascontiguousarray(q_off, np.int64)
+        check(lib().hpfw_gpu_search_topk_device(self._h, d_q, _hp(off), off.size - 1, int(k), d_out, stream))
+
+    # ---- timing --------------------------------------------------------------------------
+    def timer_start(self, stream=0):
+        check(lib().hpfw_gpu_timer_start(self._h, stream))
+
+    def timer_stop(self, stream=0):
+        ms = ctypes.c_float(0)
+        check(lib().hpfw_gpu_timer_stop(self._h, stream, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def set_kernel_timing(self, mask):
+        check(lib().hpfw_gpu_set_kernel_timing(self._h, int(mask)))
+
+    def kernel_timing(self):
+        n = ctypes.c_int(16)
+        names = (ctypes.c_char_p * 16)()
+        ms = (ctypes.c_float * 16)()
+        launches = (ctypes.c_int * 16)()
+        check(lib().hpfw_gpu_get_kernel_timing(self._h, names, ms, launches, ctypes.byref(n)))
+        return {names[i].decode(): (float(ms[i]), int(launches[i])) for i in range(n.value)}
+
+
+def merge_topk(per_shard_hits, k):
+    """per_shard_hits: [n_shards][n_q][k] HIT_DTYPE -> [n_q][k], ascending (dist, clip)."""
+    a = np.ascontiguousarray(per_shard_hits, HIT_DTYPE)
+    n_shards, n_q, kk = a.shape
+    assert kk == k
+    out = np.zeros((n_q, k), HIT_DTYPE)
+    check(lib().hpfw_gpu_merge_topk(_hp(a), n_shards, n_q, k, _hp(out)))
+    return out
+
+
+def plan_checksum(n_samples):
+    out = np.zeros(8, np.uint64)
+    rc = lib().hpfw_gpu_plan_checksum(int(n_samples), _hp(out))
+    if rc != 0:
+        raise HpfwError(f"unsupported clip length {n_samples}")
+    return out

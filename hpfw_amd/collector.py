@@ -1,0 +1,54 @@
+"""Python twin of the reference's ctypes class (modules/python/pyhpfw/pyhpfw.py:13-81), bound to
+the same eight C symbols (modules/python/parallel_collector_wrapper.hpp:21-38) that
+libhpfw_gpu.so re-exports on top of the GPU path."""
+import ctypes
+from typing import List, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+class ParallelCollector:
+    def __init__(self):
+        self.__lib = _lib.lib()
+        self.__collector = self.__lib.par_collector_new()
+        if not self.__collector:
+            raise _lib.HpfwError("par_collector_new failed: " + self.__lib.hpfw_gpu_last_error().decode())
+
+    def prepare(self, filenames) -> List[Tuple[np.ndarray, str]]:
+        """pyhpfw.py:46-61: list of (uint64 array, stem) -- array first, as the reference returns."""
+        pyarr = [f.encode("utf-8") for f in filenames]
+        arr = (ctypes.c_char_p * len(pyarr))(*pyarr)
+        got = ctypes.c_int(0)
+        hps = self.__lib.par_collector_prepare(self.__collector, arr, len(pyarr), ctypes.byref(got))
+        out = []
+        for h in range(got.value):
+            n = hps[h].hp_size
+            a = np.ctypeslib.as_array(hps[h].hashprint, shape=(n,)).astype(np.uint64).copy()
+            out.append((a, hps[h].filename.decode("utf-8")))
+        self.__lib.prepare_result_free(hps, got)
+        return out
+
+    def calc_hashprint(self, filename: str) -> np.ndarray:
+        """pyhpfw.py:63-72"""
+        size = ctypes.c_int(0)
+        hp = self.__lib.par_collector_calc_hashprint(self.__collector, filename.encode("utf-8"),
+                                                     ctypes.byref(size))
+        if not hp:
+            raise _lib.HpfwError(f"calc_hashprint({filename!r}) failed: "
+                                 + self.__lib.hpfw_gpu_last_error().decode())
+        a = np.ctypeslib.as_array(hp, shape=(size.value,)).astype(np.uint64).copy()
+        self.__lib.calc_hashprint_result_free(hp)
+        return a
+
+    def load(self, cache: str = ""):
+        self.__lib.par_collector_load(self.__collector, cache.encode("utf-8"))
+
+    def save(self, cache: str = ""):
+        self.__lib.par_collector_save(self.__collector, cache.encode("utf-8"))
+
+    def __del__(self):
+        if getattr(self, "_ParallelCollector__collector", None):
+            self.__lib.par_collector_del(self.__collector)
+            self.__collector = None

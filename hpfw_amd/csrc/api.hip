@@ -1,0 +1,709 @@
+// api.hip -- implementation of the C-ABI declared in include/hpfw_gpu.h.
+// Host orchestration only: plans, workspaces, batching over clips (the role of
+// ParallelCollector::collect_fingerprints' parallel_for, reference
+// include/hpfw/core/parallel_collector.h:115-137) and MemoryStorage::build/find
+// (include/hpfw/audioproblems/live-song-id/storage.h:21-64).  All arithmetic is in the kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/hpfw_gpu.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(HPFW_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+template <class T>
+int upload(const std::vector<T> &v, const T **out, std::vector<void *> &owned)
+{
+    void *d = nullptr;
+    if (v.empty()) {
+        *out = nullptr;
+        return 0;
+    }
+    HIP_TRY(hipMalloc(&d, v.size() * sizeof(T)));
+    owned.push_back(d);
+    HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T *>(d);
+    return 0;
+}
+
+hpfw::RadixList to_radix(const std::vector<int> &r)
+{
+    hpfw::RadixList rl;
+    std::memset(&rl, 0, sizeof(rl));
+    rl.n = (int)r.size();
+    for (size_t i = 0; i < r.size(); ++i) rl.r[i] = r[i];
+    return rl;
+}
+
+struct DevPlan {
+    hpfw::HostPlan hp;
+    hpfw::FwdPlanDev fwd;
+    hpfw::CqPlanDev cq;
+    std::vector<hpfw::CqClassDev> cls;
+    std::vector<void *> owned;
+    ~DevPlan()
+    {
+        for (void *p : owned) (void)hipFree(p);
+    }
+};
+
+enum KernelKind { K_ROWS = 0, K_COLS, K_CQ, K_DB, K_PROJECT, K_PACK, K_SCAN, K_TOPK, K_COUNT };
+const char *const kKernelNames[K_COUNT] = {"fwd_rows", "fwd_cols", "cq_chirpz", "db",
+                                           "project_mfma", "delta_pack", "hamming_scan", "topk"};
+
+struct TimedLaunch {
+    int kind;
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct hpfw_gpu {
+    int device = 0;
+    bool has_filters = false;
+    float *d_fpack = nullptr;
+    std::map<int64_t, std::unique_ptr<DevPlan>> plans;
+    int batch = 32;
+    // extraction workspace
+    size_t ws_bytes[5] = {0, 0, 0, 0, 0};
+    void *ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // yp, x, mag, proj, magmax
+    // index
+    uint64_t *d_db = nullptr;
+    size_t db_cap = 0;
+    std::vector<int64_t> db_off{0};
+    int64_t *d_db_off = nullptr;
+    size_t db_off_cap = 0;
+    bool db_off_dirty = true;
+    uint32_t clip_base = 0;
+    // search scratch
+    uint64_t *d_best = nullptr;
+    size_t best_cap = 0;
+    int64_t *d_q_off = nullptr;
+    size_t q_off_cap = 0;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned timing_mask = 0;
+    std::vector<TimedLaunch> timed;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    float k_ms[K_COUNT] = {0};
+    int k_launches[K_COUNT] = {0};
+};
+
+namespace {
+
+int ensure(void **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return 0;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(p, need));
+    *cap = need;
+    return 0;
+}
+
+struct Timed {
+    hpfw_gpu *h;
+    int kind;
+    hipStream_t s;
+    bool on;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(hpfw_gpu *h_, int kind_, hipStream_t s_) : h(h_), kind(kind_), s(s_), on((h_->timing_mask >> kind_) & 1u)
+    {
+        if (!on) return;
+        if (h->ev_pool.empty()) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+        } else {
+            a = h->ev_pool.back().first;
+            b = h->ev_pool.back().second;
+            h->ev_pool.pop_back();
+        }
+        (void)hipEventRecord(a, s);
+    }
+    ~Timed()
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        h->timed.push_back({kind, a, b});
+    }
+};
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(HPFW_E_HIP, std::string("launch of ") + what + ": " + hipGetErrorString(e));
+    return 0;
+}
+
+int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
+{
+    auto it = h->plans.find(n);
+    if (it != h->plans.end()) {
+        *out = it->second.get();
+        return 0;
+    }
+    auto dp = std::make_unique<DevPlan>();
+    std::string why;
+    if (!hpfw::build_plan(n, dp->hp, why))
+        return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n) + ": " + why);
+    const hpfw::HostPlan &p = dp->hp;
+    using hpfw::cf;
+    hpfw::FwdPlanDev &f = dp->fwd;
+    f.n = p.n;
+    f.n1 = p.n1;
+    f.n2 = p.n2;
+    f.h = p.h;
+    f.kmin = p.kmin;
+    f.kmax = p.kmax;
+    f.k1lo = p.k1lo;
+    f.k1hi = p.k1hi;
+    f.radix = to_radix(p.radix);
+    int rc;
+    static_assert(sizeof(hpfw::HostCf) == sizeof(cf), "complex layout");
+    if ((rc = upload(p.tw_n2, reinterpret_cast<const hpfw::HostCf **>(&f.tw_n2), dp->owned))) return rc;
+    if ((rc = upload(p.tw_n1, reinterpret_cast<const hpfw::HostCf **>(&f.tw_n1), dp->owned))) return rc;
+    if ((rc = upload(p.tw_big, reinterpret_cast<const hpfw::HostCf **>(&f.tw_big), dp->owned))) return rc;
+    if ((rc = upload(p.pos_n2, &f.pos_n2, dp->owned))) return rc;
+    hpfw::CqPlanDev &c = dp->cq;
+    c.kmin = p.kmin;
+    c.nk = p.kmax - p.kmin;
+    c.c = p.c;
+    std::vector<int> start(p.start, p.start + 121), lg(p.lg, p.lg + 121);
+    if ((rc = upload(start, &c.start, dp->owned))) return rc;
+    if ((rc = upload(lg, &c.lg, dp->owned))) return rc;
+    if ((rc = upload(p.g_off, &c.g_off, dp->owned))) return rc;
+    if ((rc = upload(p.g, reinterpret_cast<const hpfw::HostCf **>(&c.g), dp->owned))) return rc;
+    for (const hpfw::BluesteinClass &bc : p.classes) {
+        hpfw::CqClassDev cd;
+        cd.p = bc.p;
+        cd.n_bands = (int)bc.bands.size();
+        cd.radix = to_radix(bc.radix);
+        if ((rc = upload(bc.tw, reinterpret_cast<const hpfw::HostCf **>(&cd.tw), dp->owned))) return rc;
+        if ((rc = upload(bc.vrev, reinterpret_cast<const hpfw::HostCf **>(&cd.vrev), dp->owned))) return rc;
+        if ((rc = upload(bc.bands, &cd.band, dp->owned))) return rc;
+        dp->cls.push_back(cd);
+    }
+    if ((size_t)p.n2 * sizeof(cf) > 150 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
+    *out = dp.get();
+    h->plans[n] = std::move(dp);
+    return 0;
+}
+
+int ensure_ws(hpfw_gpu *h, const hpfw::HostPlan &p, int nb)
+{
+    const size_t need[5] = {(size_t)nb * p.n1 * p.h * 8, (size_t)nb * (p.kmax - p.kmin) * 8,
+                            (size_t)nb * 121 * p.c * 4, (size_t)nb * 64 * (size_t)std::max(p.n_frames, 1) * 4,
+                            (size_t)nb * 4};
+    for (int i = 0; i < 5; ++i) {
+        int rc = ensure(&h->ws[i], &h->ws_bytes[i], need[i]);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// the chain for nb clips already sized into the workspace
+int run_chain(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, uint64_t *d_hp, hipStream_t s)
+{
+    using hpfw::cf;
+    const hpfw::HostPlan &p = dp->hp;
+    cf *yp = (cf *)h->ws[0];
+    cf *x = (cf *)h->ws[1];
+    float *mag = (float *)h->ws[2];
+    float *proj = (float *)h->ws[3];
+    unsigned *mm = (unsigned *)h->ws[4];
+    int rc;
+    HIP_TRY(hipMemsetAsync(mm, 0, (size_t)nb * 4, s));
+    {
+        Timed t(h, K_ROWS, s);
+        hpfw::launch_fwd_rows(dp->fwd, d_pcm, nb, yp, s);
+    }
+    if ((rc = check_launch("fwd_rows"))) return rc;
+    {
+        Timed t(h, K_COLS, s);
+        hpfw::launch_fwd_cols(dp->fwd, yp, nb, x, s);
+    }
+    if ((rc = check_launch("fwd_cols"))) return rc;
+    for (const hpfw::CqClassDev &cd : dp->cls) {
+        Timed t(h, K_CQ, s);
+        hpfw::launch_cq_class(dp->cq, cd, x, nb, mag, mm, s);
+    }
+    if ((rc = check_launch("cq_chirpz"))) return rc;
+    {
+        Timed t(h, K_DB, s);
+        hpfw::launch_db(mag, mm, nb, (int64_t)121 * p.c, mag, s);
+    }
+    if ((rc = check_launch("db"))) return rc;
+    {
+        Timed t(h, K_PROJECT, s);
+        hpfw::launch_project(h->d_fpack, mag, nb, p.c, proj, s);
+    }
+    if ((rc = check_launch("project"))) return rc;
+    {
+        Timed t(h, K_PACK, s);
+        hpfw::launch_pack(proj, nb, p.n_frames, d_hp, s);
+    }
+    return check_launch("delta_pack");
+}
+
+} // namespace
+
+extern "C" {
+
+const char *hpfw_gpu_last_error(void) { return g_err.c_str(); }
+const char *hpfw_gpu_version(void) { return "hpfw-gpu 0.1 (gfx950)"; }
+
+int hpfw_gpu_create(int device, hpfw_gpu **out)
+{
+    if (!out) return fail(HPFW_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(HPFW_E_INVALID, "no such device");
+    HIP_TRY(hipSetDevice(device));
+    auto *h = new hpfw_gpu();
+    h->device = device;
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        delete h;
+        return fail(HPFW_E_HIP, "hipEventCreate failed");
+    }
+    *out = h;
+    return 0;
+}
+
+void hpfw_gpu_destroy(hpfw_gpu *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    h->plans.clear();
+    for (void *p : h->ws)
+        if (p) (void)hipFree(p);
+    if (h->d_fpack) (void)hipFree(h->d_fpack);
+    if (h->d_db) (void)hipFree(h->d_db);
+    if (h->d_db_off) (void)hipFree(h->d_db_off);
+    if (h->d_best) (void)hipFree(h->d_best);
+    if (h->d_q_off) (void)hipFree(h->d_q_off);
+    for (auto &t : h->timed) {
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    for (auto &e : h->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+int hpfw_gpu_set_filters(hpfw_gpu *h, const float *f)
+{
+    if (!h || !f) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<float> packed((size_t)hpfw::kFilters * hpfw::kFrame);
+    hpfw::pack_filters_for_mfma(f, packed.data());
+    if (!h->d_fpack) HIP_TRY(hipMalloc((void **)&h->d_fpack, packed.size() * 4));
+    HIP_TRY(hipMemcpy(h->d_fpack, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+    h->has_filters = true;
+    return 0;
+}
+
+int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out)
+{
+    if (!h || !out) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    DevPlan *dp;
+    int rc = get_plan(h, n_samples, &dp);
+    if (rc) return rc;
+    const hpfw::HostPlan &p = dp->hp;
+    *out = {p.n, p.n1, p.n2, p.kmin, p.kmax, p.m, p.c, p.n_frames, p.n_hp};
+    return 0;
+}
+
+int hpfw_gpu_set_batch(hpfw_gpu *h, int clips)
+{
+    if (!h || clips < 0 || clips > 4096) return fail(HPFW_E_INVALID, "batch out of range");
+    h->batch = clips == 0 ? 32 : clips;
+    return 0;
+}
+
+int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,
+                           uint64_t *d_hp, void *stream)
+{
+    if (!h || !d_pcm || !d_hp || n_clips < 0) return fail(HPFW_E_INVALID, "bad argument");
+    if (!h->has_filters) return fail(HPFW_E_NOFILTERS, "no filters loaded: call hpfw_gpu_set_filters first");
+    HIP_TRY(hipSetDevice(h->device));
+    DevPlan *dp;
+    int rc = get_plan(h, n_samples, &dp);
+    if (rc) return rc;
+    if (dp->hp.n_hp <= 0) return fail(HPFW_E_UNSUPPORTED, "clip too short to yield a hashprint");
+    hipStream_t s = (hipStream_t)stream;
+    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
+    if ((rc = ensure_ws(h, dp->hp, nbmax))) return rc;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
+        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
+        rc = run_chain(h, dp, d_pcm + c0 * n_samples, nb, d_hp + c0 * dp->hp.n_hp, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples, int64_t n_clips,
+                                uint64_t *hp)
+{
+    if (!h || !pcm || !hp || n_clips < 0) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hpfw_geometry g;
+    int rc = hpfw_gpu_geometry(h, n_samples, &g);
+    if (rc) return rc;
+    if (n_clips == 0) return 0;
+    int16_t *d_pcm = nullptr;
+    uint64_t *d_hp = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_pcm, (size_t)n_clips * n_samples * 2));
+    if (hipMalloc((void **)&d_hp, (size_t)n_clips * std::max<int64_t>(g.n_hp, 1) * 8) != hipSuccess) {
+        (void)hipFree(d_pcm);
+        return fail(HPFW_E_NOMEM, "hipMalloc failed");
+    }
+    rc = 0;
+    if (hipMemcpy(d_pcm, pcm, (size_t)n_clips * n_samples * 2, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (!rc) rc = hpfw_gpu_extract_pcm16(h, d_pcm, n_samples, n_clips, d_hp, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(HPFW_E_HIP, "kernel execution failed");
+    if (!rc && hipMemcpy(hp, d_hp, (size_t)n_clips * g.n_hp * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(HPFW_E_HIP, "D2H copy failed");
+    (void)hipFree(d_pcm);
+    (void)hipFree(d_hp);
+    return rc;
+}
+
+// ---- stages ----------------------------------------------------------------------------------
+int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,
+                            float *d_x, void *stream)
+{
+    if (!h || !d_pcm || !d_x) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    DevPlan *dp;
+    int rc = get_plan(h, n_samples, &dp);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
+    if ((rc = ensure_ws(h, dp->hp, nbmax))) return rc;
+    const int64_t nk = dp->hp.kmax - dp->hp.kmin;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
+        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
+        hpfw::launch_fwd_rows(dp->fwd, d_pcm + c0 * n_samples, nb, (hpfw::cf *)h->ws[0], s);
+        if ((rc = check_launch("fwd_rows"))) return rc;
+        hpfw::launch_fwd_cols(dp->fwd, (hpfw::cf *)h->ws[0], nb, (hpfw::cf *)d_x + c0 * nk, s);
+        if ((rc = check_launch("fwd_cols"))) return rc;
+    }
+    return 0;
+}
+
+int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64_t n_clips, float *d_mag,
+                         void *stream)
+{
+    if (!h || !d_x || !d_mag) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    DevPlan *dp;
+    int rc = get_plan(h, n_samples, &dp);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
+    if ((rc = ensure_ws(h, dp->hp, nbmax))) return rc;
+    const int64_t nk = dp->hp.kmax - dp->hp.kmin;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
+        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
+        HIP_TRY(hipMemsetAsync(h->ws[4], 0, (size_t)nb * 4, s));
+        for (const hpfw::CqClassDev &cd : dp->cls)
+            hpfw::launch_cq_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb,
+                                  d_mag + c0 * 121 * dp->hp.c, (unsigned *)h->ws[4], s);
+        if ((rc = check_launch("cq_chirpz"))) return rc;
+    }
+    return 0;
+}
+
+int hpfw_gpu_stage_db(hpfw_gpu *h, const float *d_mag, int64_t n_clips, int64_t c, float *d_db, void *stream)
+{
+    if (!h || !d_mag || !d_db || c <= 0) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    const int64_t per = 121 * c;
+    const int nbmax = 1024;
+    if ((rc = ensure(&h->ws[4], &h->ws_bytes[4], (size_t)nbmax * 4))) return rc;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
+        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
+        HIP_TRY(hipMemsetAsync(h->ws[4], 0, (size_t)nb * 4, s));
+        hpfw::launch_magmax(d_mag + c0 * per, nb, per, (unsigned *)h->ws[4], s);
+        hpfw::launch_db(d_mag + c0 * per, (unsigned *)h->ws[4], nb, per, d_db + c0 * per, s);
+        if ((rc = check_launch("db"))) return rc;
+    }
+    return 0;
+}
+
+int hpfw_gpu_stage_project(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c, float *d_proj,
+                           void *stream)
+{
+    if (!h || !d_db || !d_proj || c < hpfw::kCtx) return fail(HPFW_E_INVALID, "bad argument");
+    if (!h->has_filters) return fail(HPFW_E_NOFILTERS, "no filters loaded: call hpfw_gpu_set_filters first");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nf = c - (hpfw::kCtx - 1);
+    for (int64_t c0 = 0; c0 < n_clips; c0 += 16384) {
+        const int nb = (int)std::min<int64_t>(16384, n_clips - c0);
+        Timed t(h, K_PROJECT, s);
+        hpfw::launch_project(h->d_fpack, d_db + c0 * 121 * c, nb, (int)c, d_proj + c0 * 64 * nf, s);
+    }
+    return check_launch("project");
+}
+
+int hpfw_gpu_stage_pack(hpfw_gpu *h, const float *d_proj, int64_t n_clips, int64_t n_frames, uint64_t *d_hp,
+                        void *stream)
+{
+    if (!h || !d_proj || !d_hp || n_frames <= hpfw::kLag) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += 16384) {
+        const int nb = (int)std::min<int64_t>(16384, n_clips - c0);
+        hpfw::launch_pack(d_proj + c0 * 64 * n_frames, nb, (int)n_frames, d_hp + c0 * (n_frames - hpfw::kLag), s);
+    }
+    return check_launch("delta_pack");
+}
+
+// ---- index + search ----------------------------------------------------------------------------
+int hpfw_gpu_index_clear(hpfw_gpu *h)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    h->db_off.assign(1, 0);
+    h->db_off_dirty = true;
+    return 0;
+}
+
+static int index_add_impl(hpfw_gpu *h, const uint64_t *hp, const int64_t *offsets, int64_t n_clips, bool dev,
+                          hipStream_t s)
+{
+    if (!h || !hp || !offsets || n_clips < 0) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int64_t i = 0; i < n_clips; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(HPFW_E_INVALID, "offsets must be non-decreasing");
+    const int64_t add = offsets[n_clips] - offsets[0];
+    const int64_t have = h->db_off.back();
+    if ((size_t)(have + add) > h->db_cap) {
+        size_t ncap = std::max<size_t>((size_t)(have + add), h->db_cap * 2);
+        ncap = std::max<size_t>(ncap, 1 << 16);
+        uint64_t *nd = nullptr;
+        HIP_TRY(hipMalloc((void **)&nd, ncap * 8));
+        if (have) HIP_TRY(hipMemcpy(nd, h->d_db, (size_t)have * 8, hipMemcpyDeviceToDevice));
+        if (h->d_db) HIP_TRY(hipFree(h->d_db));
+        h->d_db = nd;
+        h->db_cap = ncap;
+    }
+    if (add) {
+        if (dev)
+            HIP_TRY(hipMemcpyAsync(h->d_db + have, hp + offsets[0], (size_t)add * 8, hipMemcpyDeviceToDevice, s));
+        else
+            HIP_TRY(hipMemcpy(h->d_db + have, hp + offsets[0], (size_t)add * 8, hipMemcpyHostToDevice));
+    }
+    for (int64_t i = 0; i < n_clips; ++i) h->db_off.push_back(have + (offsets[i + 1] - offsets[0]));
+    h->db_off_dirty = true;
+    return 0;
+}
+
+int hpfw_gpu_index_add(hpfw_gpu *h, const uint64_t *hp, const int64_t *offsets, int64_t n_clips)
+{
+    return index_add_impl(h, hp, offsets, n_clips, false, nullptr);
+}
+
+int hpfw_gpu_index_add_device(hpfw_gpu *h, const uint64_t *d_hp, const int64_t *offsets, int64_t n_clips,
+                              void *stream)
+{
+    return index_add_impl(h, d_hp, offsets, n_clips, true, (hipStream_t)stream);
+}
+
+int64_t hpfw_gpu_index_size(hpfw_gpu *h) { return h ? (int64_t)h->db_off.size() - 1 : 0; }
+
+int hpfw_gpu_index_set_clip_base(hpfw_gpu *h, uint32_t base)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    h->clip_base = base;
+    return 0;
+}
+
+int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64_t *q_off, int64_t n_q, int k,
+                                hpfw_hit *d_out, void *stream)
+{
+    if (!h || !q_off || !d_out || n_q < 0 || k < 1 || k > 64) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n_q == 0) return 0;
+    if (!d_q_hp) return fail(HPFW_E_INVALID, "null queries");
+    const int64_t n_clips = (int64_t)h->db_off.size() - 1;
+    int rc;
+    if (n_clips == 0) { // nothing indexed: every slot is "none"
+        hpfw::launch_topk(nullptr, (int)n_q, 0, k, h->clip_base, d_out, s);
+        return check_launch("topk");
+    }
+    if (h->db_off_dirty) {
+        if ((rc = ensure((void **)&h->d_db_off, &h->db_off_cap, h->db_off.size() * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->d_db_off, h->db_off.data(), h->db_off.size() * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h->db_off_dirty = false;
+    }
+    int64_t k_max = 0;
+    for (int64_t i = 0; i < n_q; ++i) {
+        if (q_off[i + 1] < q_off[i]) return fail(HPFW_E_INVALID, "q_off must be non-decreasing");
+        k_max = std::max(k_max, q_off[i + 1] - q_off[i]);
+    }
+    if (k_max > 16000) return fail(HPFW_E_UNSUPPORTED, "query longer than 16000 hashprints");
+    if ((rc = ensure((void **)&h->d_q_off, &h->q_off_cap, (size_t)(n_q + 1) * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_q_off, q_off, (size_t)(n_q + 1) * 8, hipMemcpyHostToDevice, s));
+    // queries are processed in groups so the (query, clip) table stays below 1 GiB
+    int64_t qgroup = std::max<int64_t>(8, ((int64_t)1 << 27) / n_clips / 8 * 8);
+    qgroup = std::min<int64_t>(qgroup, (n_q + 7) / 8 * 8);
+    if ((rc = ensure((void **)&h->d_best, &h->best_cap, (size_t)qgroup * n_clips * 8))) return rc;
+    for (int64_t g0 = 0; g0 < n_q; g0 += qgroup) {
+        const int ng = (int)std::min<int64_t>(qgroup, n_q - g0);
+        HIP_TRY(hipMemsetAsync(h->d_best, 0xff, (size_t)ng * n_clips * 8, s));
+        hpfw::SearchArgs a;
+        a.db = h->d_db;
+        a.db_off = h->d_db_off;
+        a.n_clips = (int)n_clips;
+        a.q = d_q_hp;
+        a.q_off = h->d_q_off + g0;
+        a.n_q = ng;
+        a.k_max = (int)k_max;
+        a.best = h->d_best;
+        {
+            Timed t(h, K_SCAN, s);
+            hpfw::launch_hamming_scan(a, s);
+        }
+        if ((rc = check_launch("hamming_scan"))) return rc;
+        {
+            Timed t(h, K_TOPK, s);
+            hpfw::launch_topk(h->d_best, ng, (int)n_clips, k, h->clip_base, d_out + g0 * k, s);
+        }
+        if ((rc = check_launch("topk"))) return rc;
+    }
+    return 0;
+}
+
+int hpfw_gpu_search_topk(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, int64_t n_q, int k,
+                         hpfw_hit *out)
+{
+    if (!h || !q_off || !out || n_q < 0) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_q == 0) return 0;
+    const int64_t total = q_off[n_q] - q_off[0];
+    uint64_t *d_q = nullptr;
+    hpfw_hit *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_q, (size_t)std::max<int64_t>(total, 1) * 8));
+    if (hipMalloc((void **)&d_out, (size_t)n_q * k * sizeof(hpfw_hit)) != hipSuccess) {
+        (void)hipFree(d_q);
+        return fail(HPFW_E_NOMEM, "hipMalloc failed");
+    }
+    int rc = 0;
+    std::vector<int64_t> rel((size_t)n_q + 1);
+    for (int64_t i = 0; i <= n_q; ++i) rel[(size_t)i] = q_off[i] - q_off[0];
+    if (total && hipMemcpy(d_q, q_hp + q_off[0], (size_t)total * 8, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (!rc) rc = hpfw_gpu_search_topk_device(h, d_q, rel.data(), n_q, k, d_out, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(HPFW_E_HIP, "kernel execution failed");
+    if (!rc && hipMemcpy(out, d_out, (size_t)n_q * k * sizeof(hpfw_hit), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(HPFW_E_HIP, "D2H copy failed");
+    (void)hipFree(d_q);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int hpfw_gpu_merge_topk(const hpfw_hit *in, int n_shards, int64_t n_q, int k, hpfw_hit *out)
+{
+    if (!in || !out || n_shards < 1 || n_q < 0 || k < 1) return fail(HPFW_E_INVALID, "bad argument");
+    std::vector<hpfw_hit> all((size_t)n_shards * k);
+    for (int64_t q = 0; q < n_q; ++q) {
+        for (int s = 0; s < n_shards; ++s)
+            for (int t = 0; t < k; ++t) all[(size_t)s * k + t] = in[((size_t)s * n_q + q) * k + t];
+        std::stable_sort(all.begin(), all.end(), [](const hpfw_hit &a, const hpfw_hit &b) {
+            if (a.dist != b.dist) return a.dist < b.dist;
+            return a.clip < b.clip;
+        });
+        for (int t = 0; t < k; ++t) out[(size_t)q * k + t] = all[(size_t)t];
+    }
+    return 0;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+int hpfw_gpu_timer_start(hpfw_gpu *h, void *stream)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    HIP_TRY(hipEventRecord(h->ev0, (hipStream_t)stream));
+    return 0;
+}
+
+int hpfw_gpu_timer_stop(hpfw_gpu *h, void *stream, float *ms)
+{
+    if (!h || !ms) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipEventRecord(h->ev1, (hipStream_t)stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+int hpfw_gpu_set_kernel_timing(hpfw_gpu *h, int mask)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    h->timing_mask = (unsigned)mask;
+    for (auto &t : h->timed) h->ev_pool.push_back({t.a, t.b});
+    h->timed.clear();
+    std::memset(h->k_ms, 0, sizeof(h->k_ms));
+    std::memset(h->k_launches, 0, sizeof(h->k_launches));
+    return 0;
+}
+
+int hpfw_gpu_get_kernel_timing(hpfw_gpu *h, const char **names, float *ms, int *launches, int *n)
+{
+    if (!h || !names || !ms || !launches || !n) return fail(HPFW_E_INVALID, "null argument");
+    for (auto &t : h->timed) {
+        HIP_TRY(hipEventSynchronize(t.b));
+        float e = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&e, t.a, t.b));
+        h->k_ms[t.kind] += e;
+        h->k_launches[t.kind] += 1;
+        h->ev_pool.push_back({t.a, t.b});
+    }
+    h->timed.clear();
+    const int cap = *n;
+    int w = 0;
+    for (int i = 0; i < K_COUNT && w < cap; ++i, ++w) {
+        names[w] = kKernelNames[i];
+        ms[w] = h->k_ms[i];
+        launches[w] = h->k_launches[i];
+    }
+    *n = w;
+    return 0;
+}
+
+} // extern "C"

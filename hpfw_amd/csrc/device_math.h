@@ -1,0 +1,230 @@
+// device_math.h -- complex f32 helpers, radix-2/3/4/5/7 butterflies and the in-LDS FFT passes.
+//
+// Every rounding is explicit (the library is built with -ffp-contract=off): the sequence of IEEE
+// operations is the one fixed in DESIGN.md "Arithmetic specification" (S1, S3, S4), so results
+// can be compared bit for bit with a host evaluation of the same specification.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hpfw {
+
+struct cf {
+    float r, i;
+};
+
+__device__ __forceinline__ cf c_add(cf a, cf b) { return {a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ cf c_sub(cf a, cf b) { return {a.r - b.r, a.i - b.i}; }
+// a * w
+__device__ __forceinline__ cf c_mul(cf a, cf w)
+{
+    float p = a.i * w.i;
+    float q = a.i * w.r;
+    return {__builtin_fmaf(a.r, w.r, -p), __builtin_fmaf(a.r, w.i, q)};
+}
+// a * conj(w)
+__device__ __forceinline__ cf c_mulc(cf a, cf w)
+{
+    float p = a.i * w.i;
+    float q = a.r * w.i;
+    return {__builtin_fmaf(a.r, w.r, p), __builtin_fmaf(a.i, w.r, -q)};
+}
+// -i * a
+__device__ __forceinline__ cf c_mulmi(cf a) { return {a.i, -a.r}; }
+__device__ __forceinline__ cf c_fma_s(float s, cf a, cf b)
+{
+    return {__builtin_fmaf(s, a.r, b.r), __builtin_fmaf(s, a.i, b.i)};
+}
+__device__ __forceinline__ cf c_scale(float s, cf a) { return {s * a.r, s * a.i}; }
+
+// ---- forward DFT butterflies (sign -), in place on u[0..R) -------------------------------
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<2> {
+    static __device__ __forceinline__ void run(cf *u)
+    {
+        cf a = u[0], b = u[1];
+        u[0] = c_add(a, b);
+        u[1] = c_sub(a, b);
+    }
+};
+
+template <>
+struct Dft<3> {
+    static __device__ __forceinline__ void run(cf *u)
+    {
+        const float s = 0.86602540378443864676f;
+        cf t1 = c_add(u[1], u[2]);
+        cf d = c_sub(u[1], u[2]);
+        cf m1 = c_fma_s(-0.5f, t1, u[0]);
+        cf jd = {s * d.i, -(s * d.r)};
+        u[0] = c_add(u[0], t1);
+        u[1] = c_add(m1, jd);
+        u[2] = c_sub(m1, jd);
+    }
+};
+
+template <>
+struct Dft<4> {
+    static __device__ __forceinline__ void run(cf *u)
+    {
+        cf t0 = c_add(u[0], u[2]);
+        cf t1 = c_sub(u[0], u[2]);
+        cf t2 = c_add(u[1], u[3]);
+        cf t3 = c_mulmi(c_sub(u[1], u[3]));
+        u[0] = c_add(t0, t2);
+        u[2] = c_sub(t0, t2);
+        u[1] = c_add(t1, t3);
+        u[3] = c_sub(t1, t3);
+    }
+};
+
+template <>
+struct Dft<5> {
+    static __device__ __forceinline__ void run(cf *u)
+    {
+        const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+        const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+        cf a1 = c_add(u[1], u[4]), a2 = c_add(u[2], u[3]);
+        cf b1 = c_sub(u[1], u[4]), b2 = c_sub(u[2], u[3]);
+        cf p1 = c_fma_s(c2, a2, c_fma_s(c1, a1, u[0]));
+        cf p2 = c_fma_s(c1, a2, c_fma_s(c2, a1, u[0]));
+        cf q1 = c_fma_s(s2, b2, c_scale(s1, b1));
+        cf q2 = c_fma_s(-s1, b2, c_scale(s2, b1));
+        cf jq1 = c_mulmi(q1), jq2 = c_mulmi(q2);
+        u[0] = c_add(c_add(u[0], a1), a2);
+        u[1] = c_add(p1, jq1);
+        u[4] = c_sub(p1, jq1);
+        u[2] = c_add(p2, jq2);
+        u[3] = c_sub(p2, jq2);
+    }
+};
+
+template <>
+struct Dft<7> {
+    static __device__ __forceinline__ void run(cf *u)
+    {
+        const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f,
+                    c3 = -0.90096886790241912624f;
+        const float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f,
+                    s3 = 0.43388373911755812048f;
+        cf a1 = c_add(u[1], u[6]), a2 = c_add(u[2], u[5]), a3 = c_add(u[3], u[4]);
+        cf b1 = c_sub(u[1], u[6]), b2 = c_sub(u[2], u[5]), b3 = c_sub(u[3], u[4]);
+        cf p1 = c_fma_s(c3, a3, c_fma_s(c2, a2, c_fma_s(c1, a1, u[0])));
+        cf p2 = c_fma_s(c1, a3, c_fma_s(c3, a2, c_fma_s(c2, a1, u[0])));
+        cf p3 = c_fma_s(c2, a3, c_fma_s(c1, a2, c_fma_s(c3, a1, u[0])));
+        cf q1 = c_fma_s(s3, b3, c_fma_s(s2, b2, c_scale(s1, b1)));
+        cf q2 = c_fma_s(-s1, b3, c_fma_s(-s3, b2, c_scale(s2, b1)));
+        cf q3 = c_fma_s(s2, b3, c_fma_s(-s1, b2, c_scale(s3, b1)));
+        cf jq1 = c_mulmi(q1), jq2 = c_mulmi(q2), jq3 = c_mulmi(q3);
+        u[0] = c_add(c_add(c_add(u[0], a1), a2), a3);
+        u[1] = c_add(p1, jq1);
+        u[6] = c_sub(p1, jq1);
+        u[2] = c_add(p2, jq2);
+        u[5] = c_sub(p2, jq2);
+        u[3] = c_add(p3, jq3);
+        u[4] = c_sub(p3, jq3);
+    }
+};
+
+// ---- one in-place pass over an array of n complex values held in LDS ---------------------
+// Forward decimation in frequency: sub-transform length `len`, radix R, m = len / R.
+// Butterfly (base, j): gather a[base + j + q m], DFT_R, multiply output s >= 1 by T_n[ts j s],
+// ts = n / len; scatter to the same places.  `tw` is the table T_n (global memory).
+template <int R>
+__device__ __forceinline__ void dif_pass(cf *a, int n, int len, const cf *__restrict__ tw, int tid,
+                                         int nthreads)
+{
+    const int m = len / R;
+    const int ts = n / len;
+    const int nb = n / R;
+    for (int b = tid; b < nb; b += nthreads) {
+        const int blk = b / m;
+        const int j = b - blk * m;
+        cf *p = a + blk * len + j;
+        cf u[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) u[q] = p[q * m];
+        Dft<R>::run(u);
+        p[0] = u[0];
+        const int tj = ts * j;
+#pragma unroll
+        for (int s = 1; s < R; ++s) p[s * m] = c_mul(u[s], tw[tj * s]);
+    }
+}
+
+// Inverse decimation in time (sign +, unnormalised): sub-transform length len = m R.
+// Butterfly (base, j): gather a[base + j + q m] * conj(T_n[ts j q]) (q >= 1), inverse DFT_R
+// evaluated as swap(DFT_R(swap(.))), scatter.
+template <int R>
+__device__ __forceinline__ void idit_pass(cf *a, int n, int m, const cf *__restrict__ tw, int tid,
+                                          int nthreads)
+{
+    const int len = m * R;
+    const int ts = n / len;
+    const int nb = n / R;
+    for (int b = tid; b < nb; b += nthreads) {
+        const int blk = b / m;
+        const int j = b - blk * m;
+        cf *p = a + blk * len + j;
+        cf u[R];
+        const int tj = ts * j;
+        {
+            cf v = p[0];
+            u[0] = {v.i, v.r};
+        }
+#pragma unroll
+        for (int q = 1; q < R; ++q) {
+            cf v = c_mulc(p[q * m], tw[tj * q]);
+            u[q] = {v.i, v.r};
+        }
+        Dft<R>::run(u);
+#pragma unroll
+        for (int s = 0; s < R; ++s) p[s * m] = {u[s].i, u[s].r};
+    }
+}
+
+struct RadixList {
+    int n;        // number of passes
+    int r[24];
+};
+
+// Full in-LDS transforms; every thread of the block must call them (they contain barriers).
+__device__ __forceinline__ void lds_fft_dif(cf *a, int n, const RadixList &rl,
+                                            const cf *__restrict__ tw, int tid, int nthreads)
+{
+    int len = n;
+    for (int p = 0; p < rl.n; ++p) {
+        const int r = rl.r[p];
+        switch (r) {
+        case 2: dif_pass<2>(a, n, len, tw, tid, nthreads); break;
+        case 3: dif_pass<3>(a, n, len, tw, tid, nthreads); break;
+        case 4: dif_pass<4>(a, n, len, tw, tid, nthreads); break;
+        case 5: dif_pass<5>(a, n, len, tw, tid, nthreads); break;
+        default: dif_pass<7>(a, n, len, tw, tid, nthreads); break;
+        }
+        len /= r;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void lds_fft_idit(cf *a, int n, const RadixList &rl,
+                                             const cf *__restrict__ tw, int tid, int nthreads)
+{
+    int m = 1;
+    for (int p = rl.n - 1; p >= 0; --p) {
+        const int r = rl.r[p];
+        switch (r) {
+        case 2: idit_pass<2>(a, n, m, tw, tid, nthreads); break;
+        case 3: idit_pass<3>(a, n, m, tw, tid, nthreads); break;
+        case 4: idit_pass<4>(a, n, m, tw, tid, nthreads); break;
+        case 5: idit_pass<5>(a, n, m, tw, tid, nthreads); break;
+        default: idit_pass<7>(a, n, m, tw, tid, nthreads); break;
+        }
+        m *= r;
+        __syncthreads();
+    }
+}
+
+} // namespace hpfw

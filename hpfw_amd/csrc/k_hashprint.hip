@@ -1,0 +1,140 @@
+// k_hashprint.hip -- a5..a8: dB spectrogram -> projection -> delta -> 64-bit hashprints.
+//
+// Replaces HashprintHandle::calc_frames + `filters * frames` (reference
+// include/hpfw/core/hashprint_handle.h:79-93, include/hpfw/core/parallel_collector.h:57,127: an
+// Eigen/MKL sgemm [64 x 2420] . [2420 x n_frames]) and calc_fingerprint / fingerprint_to_hashprint
+// (hashprint_handle.h:115-142).
+//
+// project_kernel: implicit im2col.  frames[b*20 + t, n] = S[b, n + t] is never materialised; the
+// workgroup keeps an [11 bins][256 + 19 columns] slab of S and the matching 220-deep slab of the
+// filters in LDS and feeds v_mfma_f32_32x32x2_f32.  The accumulation over k = b*20 + t is one
+// chain per output in ascending k (the MFMA adds k, k+1 in order and chains across instructions),
+// which is bit for bit the fmaf chain of DESIGN.md S9.
+#include "kernels.h"
+
+namespace hpfw {
+
+extern __shared__ __align__(16) unsigned char smem_raw[];
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kPjThreads = 256;            // 4 waves; each wave owns 64 filters x 64 frames
+constexpr int kPjTileN = 256;              // frames per workgroup
+constexpr int kPjBinsPerChunk = 11;        // 121 = 11 * 11
+constexpr int kPjCols = kPjTileN + kCtx - 1;   // 275 spectrogram columns per slab row
+constexpr int kPjRow = 276;                // LDS row stride in floats
+constexpr int kPjKp = kPjBinsPerChunk * kCtx / 2; // 110 k-pairs per chunk
+constexpr size_t kPjLds = (size_t)kPjBinsPerChunk * kPjRow * 4 + (size_t)kPjKp * 64 * 8;
+
+__global__ __launch_bounds__(kPjThreads) void project_kernel(const float *__restrict__ fpack,
+                                                             const float *__restrict__ sdb, int c, int nf,
+                                                             float *__restrict__ proj)
+{
+    float *s_tile = reinterpret_cast<float *>(smem_raw);
+    float2 *f_tile = reinterpret_cast<float2 *>(smem_raw + (size_t)kPjBinsPerChunk * kPjRow * 4);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5;
+    const int clip = blockIdx.y;
+    const int n0 = blockIdx.x * kPjTileN;
+    const float *S = sdb + (int64_t)clip * kBins * c;
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0}; // [filter tile][frame tile]
+    const int nl = wave * 64 + (lane & 31);
+
+    for (int chunk = 0; chunk < kBins / kPjBinsPerChunk; ++chunk) {
+        __syncthreads();
+        for (int i = tid; i < kPjBinsPerChunk * kPjCols; i += kPjThreads) {
+            const int b = i / kPjCols;
+            const int col = i - b * kPjCols;
+            const int gc = n0 + col;
+            s_tile[b * kPjRow + col] = gc < c ? S[(int64_t)(chunk * kPjBinsPerChunk + b) * c + gc] : 0.0f;
+        }
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(fpack + (size_t)chunk * kPjKp * 128);
+            float4 *dst = reinterpret_cast<float4 *>(f_tile);
+            for (int i = tid; i < kPjKp * 32; i += kPjThreads) dst[i] = src[i];
+        }
+        __syncthreads();
+        for (int b = 0; b < kPjBinsPerChunk; ++b) {
+            const float *srow = s_tile + b * kPjRow + nl + kh;
+            const float2 *frow = f_tile + (b * (kCtx / 2)) * 64 + lane;
+#pragma unroll
+            for (int tp = 0; tp < kCtx / 2; ++tp) {
+                const float2 av = frow[tp * 64];
+                const float b0 = srow[2 * tp];
+                const float b1 = srow[2 * tp + 32];
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc11, 0, 0, 0);
+            }
+        }
+    }
+    // D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float *P = proj + (int64_t)clip * kFilters * nf;
+    const int n = n0 + nl;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+        if (n < nf) {
+            P[(int64_t)row * nf + n] = acc00[reg];
+            P[(int64_t)(row + 32) * nf + n] = acc10[reg];
+        }
+        if (n + 32 < nf) {
+            P[(int64_t)row * nf + n + 32] = acc01[reg];
+            P[(int64_t)(row + 32) * nf + n + 32] = acc11[reg];
+        }
+    }
+}
+
+// bit (63 - r) of hp[i] = (P[r,i] - P[r,i+80] >= 0)
+__global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ proj, int nf, int nhp,
+                                                   uint64_t *__restrict__ hp)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int clip = blockIdx.y;
+    if (i >= nhp) return;
+    const float *P = proj + (int64_t)clip * kFilters * nf + i;
+    uint64_t v = 0;
+#pragma unroll 16
+    for (int r = 0; r < kFilters; ++r) {
+        const float d = P[(int64_t)r * nf] - P[(int64_t)r * nf + kLag];
+        v |= (uint64_t)(d >= 0.0f) << (63 - r);
+    }
+    hp[(int64_t)clip * nhp + i] = v;
+}
+
+void pack_filters_for_mfma(const float *f, float *fpack)
+{
+    // operand image of v_mfma_f32_32x32x2_f32: lane l supplies A[row = l & 31][k = l >> 5]
+    for (int kp = 0; kp < kFrame / 2; ++kp)
+        for (int l = 0; l < 64; ++l)
+            for (int tile = 0; tile < 2; ++tile) {
+                const int r = tile * 32 + (l & 31);
+                const int k = 2 * kp + (l >> 5);
+                fpack[((size_t)kp * 64 + l) * 2 + tile] = f[(size_t)r + 64 * (size_t)k];
+            }
+}
+
+static int g_pj_lds_set = 0;
+
+void launch_project(const float *d_fpack, const float *d_db, int n_clips, int c, float *d_proj, hipStream_t s)
+{
+    if (!g_pj_lds_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(project_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        g_pj_lds_set = 1;
+    }
+    const int nf = c - (kCtx - 1);
+    dim3 grid((nf + kPjTileN - 1) / kPjTileN, n_clips);
+    hipLaunchKernelGGL(project_kernel, grid, dim3(kPjThreads), kPjLds, s, d_fpack, d_db, c, nf, d_proj);
+}
+
+void launch_pack(const float *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s)
+{
+    const int nhp = nf - kLag;
+    dim3 grid((nhp + 255) / 256, n_clips);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, s, d_proj, nf, nhp, d_hp);
+}
+
+} // namespace hpfw

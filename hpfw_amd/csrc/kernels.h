@@ -1,0 +1,89 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (one per hot loop of the reference,
+// SURVEY.md section 2.1).  Each launcher only enqueues on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+
+namespace hpfw {
+
+constexpr int kBins = 121;
+constexpr int kCtx = 20;
+constexpr int kLag = 80;
+constexpr int kFilters = 64;
+constexpr int kFrame = kBins * kCtx;
+
+// Device-side description of the forward transform N = n1 * n2 (tables live in HBM).
+struct FwdPlanDev {
+    int64_t n;          // samples per clip
+    int n1, n2, h;      // h = n2 / 2 + 1
+    int kmin, kmax;     // forward bins consumed
+    int k1lo, k1hi;     // rows k1 of the length-n1 DFT that hold bins in [kmin, kmax)
+    RadixList radix;    // passes of the length-n2 FFT
+    const cf *tw_n2;    // T_{n2}            [n2]
+    const cf *tw_n1;    // T_{n1}            [n1]
+    const cf *tw_big;   // T_N[a * k2]       [n1][h]
+    const int *pos_n2;  // digit-reversed position of output k2   [n2]
+};
+
+// One Bluestein size class (all bands whose chirp-z length is p).
+struct CqClassDev {
+    int p;              // transform length (power of two)
+    int n_bands;        // bands in this class
+    RadixList radix;
+    const cf *tw;       // T_p   [p]
+    const cf *vrev;     // DFT_p(chirp) at digit-reversed positions [p]
+    const int *band;    // band index j                 [n_bands]
+};
+
+struct CqPlanDev {
+    int kmin, nk;       // first forward bin, number of bins per clip
+    int c;              // spectrogram columns
+    const int *start;   // slice start (absolute bin)   [121]
+    const int *lg;      // window length                [121]
+    const int64_t *g_off; // offset of band j in g     [121]
+    const cf *g;        // window * chirp / (M P)       [sum lg]
+};
+
+// a1 + forward FFT of residue pairs: pcm [n_clips][n] -> yp [n_clips][n1][h] (twiddled half spectra)
+void launch_fwd_rows(const FwdPlanDev &fp, const int16_t *d_pcm, int n_clips, cf *d_yp, hipStream_t s);
+// length-n1 DFT across residues as fma chains: yp -> x [n_clips][kmax-kmin]
+void launch_fwd_cols(const FwdPlanDev &fp, const cf *d_yp, int n_clips, cf *d_x, hipStream_t s);
+// band chirp-z transforms: x -> mag [n_clips][121][c]; also atomically maxes d_magmax[clip] (bits)
+void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips,
+                     float *d_mag, unsigned *d_magmax, hipStream_t s);
+// per-clip maximum of mag when the chirp-z stage did not run (stage entry point): d_magmax[clip]
+void launch_magmax(const float *d_mag, int n_clips, int64_t per_clip, unsigned *d_magmax, hipStream_t s);
+// amplitude_to_db given the per-clip maximum
+void launch_db(const float *d_mag, const unsigned *d_magmax, int n_clips, int64_t per_clip, float *d_db,
+               hipStream_t s);
+// filters * frames on f32 MFMA: s_db [n_clips][121][c] -> proj [n_clips][64][c-19]
+// d_fpack: filters repacked by pack_filters_for_mfma()
+void launch_project(const float *d_fpack, const float *d_db, int n_clips, int c, float *d_proj,
+                    hipStream_t s);
+// delta over 80 frames, sign, bit pack: proj [n_clips][64][nf] -> hp [n_clips][nf-80]
+void launch_pack(const float *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s);
+
+// host helper: [kp][lane][2] operand image of the filters for v_mfma_f32_32x32x2_f32
+void pack_filters_for_mfma(const float *filters_colmajor, float *fpack /* 64*2420 */);
+
+// ---- search ------------------------------------------------------------------------------
+struct SearchArgs {
+    const uint64_t *db;      // concatenated hashprints
+    const int64_t *db_off;   // [n_clips + 1] (device)
+    int n_clips;
+    const uint64_t *q;       // concatenated queries (device)
+    const int64_t *q_off;    // [n_q + 1] (device)
+    int n_q;
+    int k_max;               // longest query
+    uint64_t *best;          // [n_q][n_clips]: (dist << 32) | offset
+};
+void launch_hamming_scan(const SearchArgs &a, hipStream_t s);
+void launch_topk(const uint64_t *d_best, int n_q, int n_clips, int k, uint32_t clip_base, void *d_out,
+                 hipStream_t s);
+
+// fail-loud launch check
+const char *last_launch_error();
+
+} // namespace hpfw

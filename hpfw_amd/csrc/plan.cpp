@@ -1,0 +1,300 @@
+// plan.cpp -- geometry of essentia's NSGConstantQ as hpfw configures it, and the constant tables
+// of the forward / chirp-z transforms.
+//
+// Geometry follows the reference call site include/hpfw/spectrum/cqt.h:54-61
+// (NSGConstantQ: inputSize = clip length, gamma 0, binsPerOctave 24, minimumWindow 96, window
+// "hann", minFrequency 130.81, maxFrequency 4186.01; essentia defaults otherwise: rasterize "full")
+// and essentia's designWindow(): f_j = fmin 2^(j/24), bw_j = (2^(1/24) - 2^(-1/24)) f_j,
+// posit_j = floor(f_j / fftres), Lg_j = max(round(bw_j / fftres), 96), M = max_j Lg_j.
+// hpfw keeps ceil(M / 3) columns (cqt.h:73-81).
+#include "plan.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace hpfw {
+
+namespace {
+constexpr double kSampleRate = 44100.0;
+constexpr double kMinFreq = 130.81;
+constexpr double kMaxFreq = 4186.01;
+constexpr int kBpo = 24;
+constexpr int kMinWindow = 96;
+constexpr int kDown = 3;
+constexpr int kBins = 121;
+constexpr int kCtx = 20;
+constexpr int kLag = 80;
+constexpr int64_t kN2Max = 15360; // complex f32 elements of one in-LDS transform (120 KiB)
+
+HostCf twiddle_f(int64_t m, int64_t n)
+{
+    double c, s;
+    twiddle_d(m, n, c, s);
+    return {(float)c, (float)s};
+}
+
+std::vector<HostCf> twiddle_table(int64_t n)
+{
+    std::vector<HostCf> t((size_t)n);
+    for (int64_t m = 0; m < n; ++m) t[(size_t)m] = twiddle_f(m, n);
+    return t;
+}
+
+// e^{+i pi 3 m^2 / M}: phase reduced exactly in integers before the double evaluation
+void chirp_d(int64_t m, int64_t big_m, double &c, double &s)
+{
+    const int64_t mm = m < 0 ? -m : m;
+    const int64_t r = (int64_t)(((__int128)3 * mm * mm) % (2 * big_m));
+    const double ang = M_PI * (double)r / (double)big_m;
+    c = std::cos(ang);
+    s = std::sin(ang);
+}
+
+// S5: iterative radix-2 decimation-in-time FFT in double, twiddles from twiddle_d, butterfly
+// t = w b (4 mul, 1 sub, 1 add), a' = a + t, b' = a - t; nothing fused.
+void fft_r2_double(std::vector<double> &re, std::vector<double> &im)
+{
+    const int64_t n = (int64_t)re.size();
+    for (int64_t i = 1, j = 0; i < n; ++i) {
+        int64_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[i], re[j]);
+            std::swap(im[i], im[j]);
+        }
+    }
+    for (int64_t len = 2; len <= n; len <<= 1) {
+        const int64_t half = len >> 1, ts = n / len;
+        for (int64_t j = 0; j < half; ++j) {
+            double wr, wi;
+            twiddle_d(ts * j, n, wr, wi);
+            for (int64_t base = 0; base < n; base += len) {
+                const int64_t ia = base + j, ib = ia + half;
+                const double tr = wr * re[ib] - wi * im[ib];
+                const double ti = wr * im[ib] + wi * re[ib];
+                re[ib] = re[ia] - tr;
+                im[ib] = im[ia] - ti;
+                re[ia] = re[ia] + tr;
+                im[ia] = im[ia] + ti;
+            }
+        }
+    }
+}
+} // namespace
+
+void twiddle_d(int64_t m, int64_t n, double &re, double &im)
+{
+    m %= n;
+    if (m < 0) m += n;
+    const int64_t a = 8 * m;
+    const int oct = (int)(a / n);
+    const int64_t r = a - (int64_t)oct * n;
+    const int64_t t = (oct & 1) ? (n - r) : r;
+    const double alpha = M_PI * (double)t / (double)(4 * n);
+    const double ca = std::cos(alpha), sa = std::sin(alpha);
+    double c, s;
+    switch (oct) {
+    case 0: c = ca; s = sa; break;
+    case 1: c = sa; s = ca; break;
+    case 2: c = -sa; s = ca; break;
+    case 3: c = -ca; s = sa; break;
+    case 4: c = -ca; s = -sa; break;
+    case 5: c = -sa; s = -ca; break;
+    case 6: c = sa; s = -ca; break;
+    default: c = ca; s = -sa; break;
+    }
+    re = c;
+    im = -s;
+}
+
+int64_t digit_pos(int64_t k, int64_t n, const std::vector<int> &radix)
+{
+    int64_t pos = 0, len = n;
+    for (int r : radix) {
+        len /= r;
+        pos += (k % r) * len;
+        k /= r;
+    }
+    return pos;
+}
+
+// primes descending, pairs of 2 merged into 4: [7.. 5.. 4.. 3.. 2]
+bool make_radix_list(int64_t n, std::vector<int> &radix)
+{
+    int c2 = 0, c3 = 0, c5 = 0, c7 = 0;
+    while (n % 7 == 0) { n /= 7; ++c7; }
+    while (n % 5 == 0) { n /= 5; ++c5; }
+    while (n % 3 == 0) { n /= 3; ++c3; }
+    while (n % 2 == 0) { n /= 2; ++c2; }
+    if (n != 1) return false;
+    radix.clear();
+    radix.insert(radix.end(), c7, 7);
+    radix.insert(radix.end(), c5, 5);
+    radix.insert(radix.end(), c2 / 2, 4);
+    radix.insert(radix.end(), c3, 3);
+    if (c2 & 1) radix.push_back(2);
+    return radix.size() <= 24;
+}
+
+bool build_plan(int64_t n, HostPlan &p, std::string &why)
+{
+    if (n < 2) {
+        why = "clip too short";
+        return false;
+    }
+    p = HostPlan();
+    p.n = n;
+    // ---- bands ----
+    const double fftres = kSampleRate / (double)n;
+    const double q = std::pow(2.0, 1.0 / kBpo) - std::pow(2.0, -1.0 / kBpo);
+    const int nb = (int)std::floor(kBpo * std::log2(kMaxFreq / kMinFreq)) + 1;
+    if (nb != kBins) {
+        why = "band count mismatch";
+        return false;
+    }
+    int64_t kmin = n, kmax = 0, big_m = 0;
+    for (int j = 0; j < kBins; ++j) {
+        const double f = kMinFreq * std::pow(2.0, (double)j / kBpo);
+        const int64_t posit = (int64_t)std::floor(f / fftres);
+        int64_t lg = (int64_t)std::round(q * f / fftres);
+        if (lg < kMinWindow) lg = kMinWindow;
+        const int64_t st = posit - lg / 2;
+        p.start[j] = (int)st;
+        p.lg[j] = (int)lg;
+        if (st < kmin) kmin = st;
+        if (st + lg > kmax) kmax = st + lg;
+        if (lg > big_m) big_m = lg;
+    }
+    if (kmin < 0 || kmax > n / 2) {
+        why = "clip too short: constant-Q bands leave the positive half spectrum";
+        return false;
+    }
+    p.kmin = (int)kmin;
+    p.kmax = (int)kmax;
+    p.m = (int)big_m;
+    p.c = (int)((big_m + kDown - 1) / kDown);
+    p.n_frames = p.c - (kCtx - 1);
+    p.n_hp = p.n_frames - kLag;
+    if (p.n_frames < 0) p.n_frames = 0;
+    if (p.n_hp < 0) p.n_hp = 0;
+    // ---- forward split N = n1 * n2 ----
+    int64_t n1 = 0;
+    for (int64_t d = 1; d <= n; ++d) {
+        if (n % d) continue;
+        if (n / d <= kN2Max) {
+            n1 = d;
+            break;
+        }
+    }
+    const int64_t n2 = n / n1;
+    std::vector<int> tmp;
+    if (!make_radix_list(n2, p.radix) || !make_radix_list(n1, tmp)) {
+        why = "clip length has a prime factor other than 2, 3, 5, 7";
+        return false;
+    }
+    if (n1 > 8192) {
+        why = "clip too long";
+        return false;
+    }
+    p.n1 = (int)n1;
+    p.n2 = (int)n2;
+    p.h = (int)(n2 / 2 + 1);
+    p.k1lo = (int)(kmin / n2);
+    p.k1hi = (int)((kmax - 1) / n2);
+    p.tw_n2 = twiddle_table(n2);
+    p.tw_n1 = twiddle_table(n1);
+    p.tw_big.resize((size_t)n1 * p.h);
+    for (int64_t a = 0; a < n1; ++a)
+        for (int64_t k2 = 0; k2 < p.h; ++k2) p.tw_big[(size_t)(a * p.h + k2)] = twiddle_f(a * k2, n);
+    p.pos_n2.resize((size_t)n2);
+    for (int64_t k = 0; k < n2; ++k) p.pos_n2[(size_t)k] = (int)digit_pos(k, n2, p.radix);
+    // ---- chirp-z classes ----
+    p.g_off.assign(kBins, 0);
+    int64_t goff = 0;
+    for (int j = 0; j < kBins; ++j) {
+        const int64_t need = p.lg[j] + p.c - 1;
+        int64_t ps = 64;
+        while (ps < need) ps <<= 1;
+        if (ps > 16384) {
+            why = "clip too long: chirp-z length exceeds the LDS";
+            return false;
+        }
+        p.psize[j] = (int)ps;
+        size_t k = 0;
+        for (; k < p.classes.size(); ++k)
+            if (p.classes[k].p == ps) break;
+        if (k == p.classes.size()) {
+            BluesteinClass bc;
+            bc.p = (int)ps;
+            make_radix_list(ps, bc.radix);
+            bc.tw = twiddle_table(ps);
+            std::vector<double> re((size_t)ps, 0.0), im((size_t)ps, 0.0);
+            for (int64_t mm = -(ps - p.c); mm <= p.c - 1; ++mm) { // v[m mod P] = e^{-i pi 3 m^2 / M}
+                double cc, ss;
+                chirp_d(mm, big_m, cc, ss);
+                const int64_t idx = mm < 0 ? mm + ps : mm;
+                re[(size_t)idx] = cc;
+                im[(size_t)idx] = -ss;
+            }
+            fft_r2_double(re, im);
+            bc.vrev.resize((size_t)ps);
+            for (int64_t kk = 0; kk < ps; ++kk) {
+                const int64_t pos = digit_pos(kk, ps, bc.radix);
+                bc.vrev[(size_t)pos] = {(float)re[(size_t)kk], (float)im[(size_t)kk]};
+            }
+            p.classes.push_back(std::move(bc));
+        }
+        p.classes[k].bands.push_back(j);
+        // G_j[i] = hann_Lg[i] e^{+i pi 3 i^2 / M} / (M P)
+        const int64_t lg = p.lg[j];
+        p.g_off[j] = goff;
+        const double scale = 1.0 / ((double)big_m * (double)ps);
+        for (int64_t i = 0; i < lg; ++i) {
+            const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / (double)(lg - 1));
+            double cc, ss;
+            chirp_d(i, big_m, cc, ss);
+            p.g.push_back({(float)(w * cc * scale), (float)(w * ss * scale)});
+        }
+        goff += lg;
+    }
+    return true;
+}
+
+} // namespace hpfw
+
+// ---- host-only diagnostic: FNV-1a checksums of the plan tables (no device involved) ----------
+namespace {
+uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < bytes; ++i) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+} // namespace
+
+extern "C" int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8)
+{
+    hpfw::HostPlan p;
+    std::string why;
+    if (!out8 || !hpfw::build_plan(n_samples, p, why)) return -2;
+    out8[0] = fnv1a(p.tw_n2.data(), p.tw_n2.size() * 8);
+    out8[1] = fnv1a(p.tw_n1.data(), p.tw_n1.size() * 8);
+    out8[2] = fnv1a(p.tw_big.data(), p.tw_big.size() * 8);
+    out8[3] = fnv1a(p.pos_n2.data(), p.pos_n2.size() * 4);
+    uint64_t h = fnv1a(p.start, sizeof(p.start));
+    h = fnv1a(p.lg, sizeof(p.lg), h);
+    out8[4] = fnv1a(p.psize, sizeof(p.psize), h);
+    out8[5] = fnv1a(p.g.data(), p.g.size() * 8);
+    uint64_t ht = 1469598103934665603ull, hv = ht;
+    for (const hpfw::BluesteinClass &bc : p.classes) {
+        ht = fnv1a(bc.tw.data(), bc.tw.size() * 8, ht);
+        hv = fnv1a(bc.vrev.data(), bc.vrev.size() * 8, hv);
+    }
+    out8[6] = ht;
+    out8[7] = hv;
+    return 0;
+}

@@ -1,0 +1,45 @@
+// plan.h -- host-side geometry and tables of the extraction path (DESIGN.md "Arithmetic
+// specification" S2, S5-S7).  Everything here runs once per distinct clip length.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace hpfw {
+
+struct HostCf {
+    float r, i;
+};
+
+struct BluesteinClass {
+    int p = 0;
+    std::vector<int> radix;
+    std::vector<HostCf> tw;    // T_p
+    std::vector<HostCf> vrev;  // DFT_p(chirp) at digit-reversed positions
+    std::vector<int> bands;    // bands using this size
+};
+
+struct HostPlan {
+    int64_t n = 0;
+    int n1 = 0, n2 = 0, h = 0;
+    int kmin = 0, kmax = 0, k1lo = 0, k1hi = 0;
+    int m = 0, c = 0, n_frames = 0, n_hp = 0;
+    std::vector<int> radix;                 // passes of the length-n2 FFT
+    std::vector<HostCf> tw_n2, tw_n1, tw_big;
+    std::vector<int> pos_n2;
+    int start[121], lg[121], psize[121];
+    std::vector<int64_t> g_off;             // [121]
+    std::vector<HostCf> g;                  // window * chirp / (M P), concatenated
+    std::vector<BluesteinClass> classes;
+};
+
+// Returns false (and a reason) when the clip length is unsupported.
+bool build_plan(int64_t n_samples, HostPlan &out, std::string &why);
+
+// e^{-2 pi i m / n} with exact octant symmetry, evaluated in double (S2)
+void twiddle_d(int64_t m, int64_t n, double &re, double &im);
+// mixed-radix digit reversal of the DIF pass list
+int64_t digit_pos(int64_t k, int64_t n, const std::vector<int> &radix);
+bool make_radix_list(int64_t n, std::vector<int> &radix);
+
+} // namespace hpfw

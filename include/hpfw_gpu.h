@@ -1,0 +1,175 @@
+/*
+ * hpfw_gpu.h -- C-ABI of the MI355X (gfx950) hashprint hot path: the drop-in boundary.
+ *
+ * What it replaces (paths relative to the hpfw reference tree):
+ *   extraction  ParallelCollector::calc_hashprint / collect_fingerprints
+ *               include/hpfw/core/parallel_collector.h:54-59, 115-137, i.e.
+ *               CQT<>::spectrogram            include/hpfw/spectrum/cqt.h:36-84
+ *               amplitude_to_db/power_to_db   include/hpfw/spectrum/convert.h:7-25
+ *               calc_frames, filters*frames, calc_fingerprint, fingerprint_to_hashprint
+ *                                             include/hpfw/core/hashprint_handle.h:79-142
+ *   search      MemoryStorage::build / find   include/hpfw/audioproblems/live-song-id/storage.h:21-64
+ *               and the notebook's top-10 rule examples/python/liveid.ipynb cell 9
+ *   legacy FFI  the eight extern "C" symbols of modules/python/parallel_collector_wrapper.hpp:21-38
+ *               (declared at the end of this file with the same shapes)
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; every function returns 0 on success and a negative
+ *     hpfw_status otherwise and never throws; hpfw_gpu_last_error() returns a thread-local
+ *     message for the last failure on the calling thread.
+ *   - pointers named d_* are DEVICE pointers (HBM) on the handle's device; all others are host
+ *     pointers.  `stream` is a hipStream_t passed as void* (NULL = the default stream); device
+ *     entry points only enqueue work on it and return without synchronising.
+ *   - a handle may be used by one host thread at a time.
+ *   - layouts: PCM is int16 mono 44.1 kHz, clips of equal length back to back;
+ *     spectrograms are bin-major [121][C] (the reference's Eigen matrix is column-major 121 x C:
+ *     element (b, c) at b + 121 c; ours is at b * C + c); filters are the reference's
+ *     Matrix<float,64,Dynamic> column-major: element (r, k) at r + 64 k, k = bin * 20 + t;
+ *     hashprints are uint64, bit (63 - r) <-> filter row r (hashprint_handle.h:137-142).
+ */
+#ifndef HPFW_GPU_H
+#define HPFW_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPFW_BINS 121     /* cqt.h:21 NumberBins                      */
+#define HPFW_CONTEXT 20   /* live_song_id.h:16 FramesContext          */
+#define HPFW_LAG 80       /* live_song_id.h:16 T                      */
+#define HPFW_FILTERS 64   /* hashprint_handle.h:64 sizeof(uint64_t)*8 */
+#define HPFW_FRAME_SIZE (HPFW_BINS * HPFW_CONTEXT)
+
+typedef enum {
+    HPFW_OK = 0,
+    HPFW_E_INVALID = -1,     /* bad argument                                       */
+    HPFW_E_UNSUPPORTED = -2, /* clip length not 7-smooth / too short / too long    */
+    HPFW_E_NOFILTERS = -3,   /* extraction before hpfw_gpu_set_filters             */
+    HPFW_E_HIP = -4,         /* a HIP runtime call failed (message has the detail) */
+    HPFW_E_NOMEM = -5,
+    HPFW_E_IO = -6           /* legacy file entry points: unreadable / unsupported WAV */
+} hpfw_status;
+
+typedef struct hpfw_gpu hpfw_gpu; /* opaque */
+
+/* geometry of clips of n_samples samples: essentia NSGConstantQ as configured at cqt.h:54-61 */
+typedef struct {
+    int64_t n_samples;
+    int64_t n1, n2;   /* forward transform split N = n1 * n2                       */
+    int64_t kmin, kmax; /* forward DFT bins [kmin, kmax) consumed by the 121 bands  */
+    int64_t m;        /* M: inverse transform length of every band                 */
+    int64_t c;        /* spectrogram columns ceil(M / 3)                           */
+    int64_t n_frames; /* c - 19    hashprint_handle.h:84                           */
+    int64_t n_hp;     /* c - 99    hashprint_handle.h:118                          */
+} hpfw_geometry;
+
+/* one search result; SearchResult{filename, cnt, offset} of storage.h:11-15 with the filename
+ * replaced by the clip's index in hpfw_gpu_index_add order */
+typedef struct {
+    uint32_t dist;   /* sum of popcounts over the query                  */
+    uint32_t clip;   /* clip_base + index in add order; 0xffffffff = none */
+    int32_t offset;  /* first offset reaching dist (storage.h:50-53)      */
+    uint32_t pad;
+} hpfw_hit;
+
+const char *hpfw_gpu_last_error(void);
+const char *hpfw_gpu_version(void);
+
+int hpfw_gpu_create(int device, hpfw_gpu **out);
+void hpfw_gpu_destroy(hpfw_gpu *h);
+
+/* filters = ParallelCollector::filters (parallel_collector.h:77), host pointer, 64 x 2420 floats */
+int hpfw_gpu_set_filters(hpfw_gpu *h, const float *filters_colmajor);
+int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out);
+
+/* ---- extraction: calc_hashprint for n_clips clips of n_samples samples each ------------- */
+/* d_hp receives [n_clips][n_hp] */
+int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,
+                           uint64_t *d_hp, void *stream);
+/* host buffers; copies in, runs, copies out, synchronises */
+int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples, int64_t n_clips,
+                                uint64_t *hp);
+/* clips processed per internal pass (workspace = ~9.5 MB per clip at 30 s); 0 = default */
+int hpfw_gpu_set_batch(hpfw_gpu *h, int clips_per_pass);
+
+/* ---- per-stage entry points (parity checkpoints; same kernels the full chain runs) ------- */
+/* PCM -> forward DFT bins [kmin,kmax): d_x [n_clips][kmax-kmin][2]           cqt.h:45-52,66 */
+int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,
+                            float *d_x, void *stream);
+/* bins -> |c_j[3c]|: d_mag [n_clips][121][C]                                  cqt.h:66-81 */
+int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64_t n_clips,
+                         float *d_mag, void *stream);
+/* amplitude_to_db, per clip: d_mag, d_db [n_clips][121][C] (may alias)        convert.h:7-25 */
+int hpfw_gpu_stage_db(hpfw_gpu *h, const float *d_mag, int64_t n_clips, int64_t c, float *d_db,
+                      void *stream);
+/* filters * calc_frames(S): d_proj [n_clips][64][C-19]       hashprint_handle.h:79-93 + :57 */
+int hpfw_gpu_stage_project(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c,
+                           float *d_proj, void *stream);
+/* calc_fingerprint + fingerprint_to_hashprint: d_hp [n_clips][n_frames-80]   :115-142 */
+int hpfw_gpu_stage_pack(hpfw_gpu *h, const float *d_proj, int64_t n_clips, int64_t n_frames,
+                        uint64_t *d_hp, void *stream);
+
+/* ---- index + search: MemoryStorage::build / find ----------------------------------------- */
+int hpfw_gpu_index_clear(hpfw_gpu *h);
+/* appends n_clips hashprints; clip i is hp[offsets[i] .. offsets[i+1]); host or device source */
+int hpfw_gpu_index_add(hpfw_gpu *h, const uint64_t *hp, const int64_t *offsets, int64_t n_clips);
+int hpfw_gpu_index_add_device(hpfw_gpu *h, const uint64_t *d_hp, const int64_t *offsets,
+                              int64_t n_clips, void *stream);
+int64_t hpfw_gpu_index_size(hpfw_gpu *h); /* number of clips */
+/* added to every reported clip id (rank's first global clip id when the index is sharded) */
+int hpfw_gpu_index_set_clip_base(hpfw_gpu *h, uint32_t clip_base);
+
+/* top-k clips per query, ascending (dist, clip): query q is q_hp[q_off[q] .. q_off[q+1]).
+ * d_q_hp device; q_off host; d_out device [n_q][k].  k <= 64. */
+int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64_t *q_off,
+                                int64_t n_q, int k, hpfw_hit *d_out, void *stream);
+/* host convenience: copies queries in and hits out, synchronises */
+int hpfw_gpu_search_topk(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, int64_t n_q,
+                         int k, hpfw_hit *out);
+/* deterministic merge of per-shard top-k lists (e.g. after an all-gather): in [n_shards][n_q][k]
+ * -> out [n_q][k], ascending (dist, clip).  Host arrays. */
+int hpfw_gpu_merge_topk(const hpfw_hit *in, int n_shards, int64_t n_q, int k, hpfw_hit *out);
+
+/* ---- events: time a region on `stream` with HIP events (bench.py uses these so that the
+ * timing is taken on the stream the kernels run on) ---------------------------------------- */
+int hpfw_gpu_timer_start(hpfw_gpu *h, void *stream);
+int hpfw_gpu_timer_stop(hpfw_gpu *h, void *stream, float *ms); /* synchronises on the stop event */
+/* per-kernel device time, measured with one HIP event pair per launch on the launch stream.
+ * mask bit i enables kernel kind i in the order reported by hpfw_gpu_get_kernel_timing
+ * (fwd_rows, fwd_cols, cq_chirpz, db, project_mfma, delta_pack, hamming_scan, topk); -1 = all,
+ * 0 = off.  Setting the mask resets the accumulated times. */
+int hpfw_gpu_set_kernel_timing(hpfw_gpu *h, int mask);
+/* names[i] (static strings) and ms[i], launches[i] for i < *n; pass capacity in *n */
+int hpfw_gpu_get_kernel_timing(hpfw_gpu *h, const char **names, float *ms, int *launches, int *n);
+
+/* ---- host-only diagnostic: FNV-1a checksums of the eight groups of constant tables built for
+ * clips of n_samples samples (twiddles, digit reversal, bands, window*chirp, chirp spectra).
+ * No device is touched. */
+int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8);
+
+/* ---- legacy FFI: modules/python/parallel_collector_wrapper.hpp:12-38, same shapes --------- */
+typedef struct {
+    char *filename;
+    uint64_t *hashprint;
+    int hp_size;
+} FilenameHashprintPair; /* wrapper.hpp:12-16 */
+
+typedef struct hpfw_legacy_collector hpfw_legacy_collector; /* stands in for LiveIdCollector */
+
+hpfw_legacy_collector *par_collector_new(void);                         /* wrapper.hpp:21 */
+void par_collector_del(hpfw_legacy_collector *collector);               /* wrapper.hpp:23 */
+FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *collector,
+                                             const char **filenames, int n, int *got); /* :25-28 */
+uint64_t *par_collector_calc_hashprint(hpfw_legacy_collector *collector, const char *filename,
+                                       int *size);                      /* wrapper.hpp:30 */
+void par_collector_save(hpfw_legacy_collector *collector, const char *cache); /* wrapper.hpp:32 */
+void par_collector_load(hpfw_legacy_collector *collector, const char *cache); /* wrapper.hpp:34 */
+void prepare_result_free(FilenameHashprintPair *res, int got);          /* wrapper.hpp:36 */
+void calc_hashprint_result_free(uint64_t *hp);                          /* wrapper.hpp:38 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

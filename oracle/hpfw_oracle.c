@@ -818,3 +818,37 @@ void hpfw_oracle_search_topk(const uint64_t *db, const int64_t *db_off, int64_t 
     }
     for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
 }
+
+/* FNV-1a checksums of the plan tables, so a test can compare them with the product's tables
+ * without either side exposing the tables themselves. */
+static uint64_t fnv1a(const void *data, size_t bytes, uint64_t h)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < bytes; ++i) {
+        h ^= p[i];
+        h *= 1099511628211ULL;
+    }
+    return h;
+}
+
+void hpfw_oracle_plan_checksum(const hpfw_oracle_plan *p, uint64_t *out8)
+{
+    const uint64_t seed = 1469598103934665603ULL;
+    out8[0] = fnv1a(p->tw_n2, (size_t)p->info.n2 * 8, seed);
+    out8[1] = fnv1a(p->tw_n1, (size_t)p->info.n1 * 8, seed);
+    out8[2] = fnv1a(p->tw_big, (size_t)(p->info.n1 * p->info.h) * 8, seed);
+    out8[3] = fnv1a(p->pos_n2, (size_t)p->info.n2 * 4, seed);
+    uint64_t h = fnv1a(p->start, sizeof(p->start), seed);
+    h = fnv1a(p->lg, sizeof(p->lg), h);
+    out8[4] = fnv1a(p->psize, sizeof(p->psize), h);
+    h = seed;
+    for (int j = 0; j < HPFW_O_BINS; ++j) h = fnv1a(p->g[j], (size_t)p->lg[j] * 8, h);
+    out8[5] = h;
+    uint64_t ht = seed, hv = seed;
+    for (int k = 0; k < p->n_cls; ++k) {
+        ht = fnv1a(p->bc[k].tw, (size_t)p->bc[k].p * 8, ht);
+        hv = fnv1a(p->bc[k].vrev, (size_t)p->bc[k].p * 8, hv);
+    }
+    out8[6] = ht;
+    out8[7] = hv;
+}

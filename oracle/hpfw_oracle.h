@@ -96,6 +96,9 @@ void hpfw_oracle_search_topk(const uint64_t *db, const int64_t *db_off, int64_t 
                              const uint64_t *q, const int64_t *q_off, int64_t n_q, int topk,
                              hpfw_oracle_hit *out /* [n_q][topk] */, int n_threads);
 
+/* FNV-1a checksums of the eight table groups (compared with the product's own tables) */
+void hpfw_oracle_plan_checksum(const hpfw_oracle_plan *p, uint64_t *out8);
+
 /* ---- pieces exposed so tests can pin them one by one ---- */
 double hpfw_oracle_log10(double x);                                       /* DESIGN.md "dB" */
 void hpfw_oracle_twiddle(int64_t m, int64_t n, float *re, float *im);     /* e^{-2 pi i m/n} */

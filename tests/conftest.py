@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (checker only)."""
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def filters():
+    from hpfw_amd import synth
+    return synth.make_filters()
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU in this environment")
+    return torch
+
+
+@pytest.fixture(scope="session")
+def gpu(torch_cuda, filters):
+    """hpfw_amd.Gpu handle with the filter fixture loaded.  Fails loudly when the HIP library is
+    missing -- there is no fallback."""
+    import hpfw_amd
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filters)
+    yield g
+    g.close()
+
+
+def bits_equal(a, b):
+    """bitwise equality of two float32 arrays, +0 == -0 excluded on purpose"""
+    a = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    b = np.ascontiguousarray(b, np.float32).view(np.uint32)
+    return a.shape == b.shape and bool((a == b).all())
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)

@@ -1,0 +1,224 @@
+"""GPU parity: every stage of the HIP path against the CPU oracle on the same seeded inputs,
+called through the C-ABI (include/hpfw_gpu.h).  Bars: bit-exact for hashprints, Hamming distances,
+offsets and top-k order; the float stages are also required to be bit-exact against the oracle
+(both implement DESIGN.md's arithmetic specification) and within 1e-4 of the maximum against the
+float64 definition (oracle/nsgt_f64.py) -- the tolerance BASELINE.json's north_star states for the
+CQT magnitudes."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+from hpfw_amd import synth  # noqa: E402
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _report(name, got, want):
+    d = ulp_diff(got, want)
+    return (f"{name}: {int((d > 0).sum())} of {d.size} values differ, max {int(d.max())} ulp, "
+            f"max abs {float(np.abs(got.astype(np.float64) - want).max()):.3e}")
+
+
+@pytest.mark.parametrize("seconds", [3.0, 5.0, 30.0])
+def test_stages_bit_exact(gpu, torch_cuda, oracle, filters, seconds):
+    torch = torch_cuda
+    n_clips = 3 if seconds < 30 else 2
+    clips = np.stack([synth.gen_clip(100 + i, seconds) for i in range(n_clips)])
+    n = clips.shape[1]
+    plan = oracle.Plan(n)
+    g = gpu.geometry(n)
+    assert (g.n1, g.n2, g.kmin, g.kmax, g.m, g.c, g.n_frames, g.n_hp) == (
+        plan.n1, plan.n2, plan.kmin, plan.kmax, plan.m, plan.c, plan.n_frames, plan.n_hp)
+    nk = plan.kmax - plan.kmin
+    d_pcm = _dev(torch, clips)
+    # a1 + forward DFT
+    d_x = torch.empty((n_clips, nk, 2), dtype=torch.float32, device="cuda")
+    gpu.stage_spectrum_dev(d_pcm.data_ptr(), n, n_clips, d_x.data_ptr())
+    torch.cuda.synchronize()
+    x_gpu = d_x.cpu().numpy()
+    x_ref = np.stack([plan.spectrum(c) for c in clips])
+    assert np.array_equal(x_gpu, x_ref), _report("spectrum", x_gpu, x_ref)
+    # chirp-z bands -> |c_j[3c]|
+    d_mag = torch.empty((n_clips, 121, plan.c), dtype=torch.float32, device="cuda")
+    gpu.stage_cqmag_dev(d_x.data_ptr(), n, n_clips, d_mag.data_ptr())
+    torch.cuda.synchronize()
+    mag_gpu = d_mag.cpu().numpy()
+    mag_ref = np.stack([plan.cqmag(x) for x in x_ref])
+    assert np.array_equal(mag_gpu, mag_ref), _report("cqmag", mag_gpu, mag_ref)
+    # north_star tolerance against the float64 definition: 1e-4 relative (to each band's maximum)
+    from oracle import nsgt_f64
+    m64 = nsgt_f64.cq_magnitudes(clips[0])
+    rel = np.abs(mag_gpu[0] - m64).max(axis=1) / m64.max(axis=1)
+    assert rel.max() < 1e-4, f"CQ magnitudes vs float64 definition: {rel.max():.3e}"
+    # dB
+    d_db = torch.empty_like(d_mag)
+    gpu.stage_db_dev(d_mag.data_ptr(), n_clips, plan.c, d_db.data_ptr())
+    torch.cuda.synchronize()
+    db_gpu = d_db.cpu().numpy()
+    db_ref = np.stack([oracle.db(m) for m in mag_ref])
+    assert bits_equal(db_gpu, db_ref), _report("db", db_gpu, db_ref)
+    # projection (f32 MFMA) against the fmaf chain
+    d_proj = torch.empty((n_clips, 64, plan.n_frames), dtype=torch.float32, device="cuda")
+    gpu.stage_project_dev(d_db.data_ptr(), n_clips, plan.c, d_proj.data_ptr())
+    torch.cuda.synchronize()
+    pr_gpu = d_proj.cpu().numpy()
+    pr_ref = np.stack([oracle.project(filters, s) for s in db_ref])
+    assert bits_equal(pr_gpu, pr_ref), _report("project", pr_gpu, pr_ref)
+    # delta + pack
+    d_hp = torch.empty((n_clips, plan.n_hp), dtype=torch.int64, device="cuda")
+    gpu.stage_pack_dev(d_proj.data_ptr(), n_clips, plan.n_frames, d_hp.data_ptr())
+    torch.cuda.synchronize()
+    hp_gpu = d_hp.cpu().numpy().view(np.uint64)
+    hp_ref = np.stack([oracle.pack(p) for p in pr_ref])
+    assert np.array_equal(hp_gpu, hp_ref)
+    # whole chain, host entry point
+    hp_all = gpu.extract(clips)
+    assert np.array_equal(hp_all, hp_ref)
+    assert np.array_equal(hp_all, np.stack([plan.extract(filters, c) for c in clips]))
+
+
+def test_extract_batches_and_order(gpu, oracle, filters):
+    """more clips than one internal pass, odd batch size: per-clip results do not depend on batching"""
+    clips = np.stack([synth.gen_clip(200 + i, 3.0) for i in range(11)])
+    plan = oracle.Plan(clips.shape[1])
+    want = plan.extract_batch(filters, clips, n_threads=4)
+    gpu.set_batch(4)
+    got4 = gpu.extract(clips)
+    gpu.set_batch(0)
+    got = gpu.extract(clips)
+    assert np.array_equal(got4, want) and np.array_equal(got, want)
+
+
+def test_projection_edge_values(gpu, torch_cuda, oracle, filters):
+    """exact zeros (>= 0 -> bit 1), the -80 dB floor everywhere, and a tile that is not a multiple of 256"""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    for c in (100, 275, 276, 531):
+        s = rng.uniform(-80, 0, (2, 121, c)).astype(np.float32)
+        s[1] = -80.0
+        s[0, :, : c // 3] = 0.0
+        d_s = _dev(torch, s)
+        nf = c - 19
+        d_proj = torch.empty((2, 64, nf), dtype=torch.float32, device="cuda")
+        gpu.stage_project_dev(d_s.data_ptr(), 2, c, d_proj.data_ptr())
+        d_hp = torch.empty((2, nf - 80), dtype=torch.int64, device="cuda")
+        gpu.stage_pack_dev(d_proj.data_ptr(), 2, nf, d_hp.data_ptr())
+        torch.cuda.synchronize()
+        pr_ref = np.stack([oracle.project(filters, x) for x in s])
+        assert bits_equal(d_proj.cpu().numpy(), pr_ref), _report("project", d_proj.cpu().numpy(), pr_ref)
+        hp_ref = np.stack([oracle.pack(p) for p in pr_ref])
+        assert np.array_equal(d_hp.cpu().numpy().view(np.uint64), hp_ref)
+    # a constant spectrogram gives delta == 0 everywhere -> all 64 bits set (hashprint_handle.h:121)
+    assert (hp_ref[1] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+
+
+def _ragged(rng, lens):
+    hp = [rng.integers(0, 2 ** 64, size=n, dtype=np.uint64) for n in lens]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return (np.concatenate(hp) if hp else np.zeros(0, np.uint64)), off
+
+
+def test_search_matches_oracle(gpu, oracle):
+    rng = np.random.default_rng(11)
+    db_lens = [2320, 305, 40, 1000, 2320, 1, 700, 305, 2320, 64, 333, 2000, 5]
+    db, db_off = _ragged(rng, db_lens)
+    qs = []
+    # planted (noisy) slices, an exact slice, a query longer than some clips, a 1-long query, random
+    for c, o, k, flips in [(0, 100, 305, 5), (4, 2015, 305, 0), (3, 0, 1000, 9), (6, 10, 64, 3), (11, 7, 1, 0)]:
+        seg = db[db_off[c] + o: db_off[c] + o + k].copy()
+        for _ in range(flips):
+            seg ^= np.uint64(1) << rng.integers(0, 64, size=k, dtype=np.uint64)
+        qs.append(seg)
+    qs.append(rng.integers(0, 2 ** 64, size=305, dtype=np.uint64))
+    qs += [rng.integers(0, 2 ** 64, size=int(n), dtype=np.uint64) for n in rng.integers(1, 400, 9)]
+    q_off = np.concatenate([[0], np.cumsum([q.size for q in qs])]).astype(np.int64)
+    q = np.concatenate(qs)
+    gpu.index_clear()
+    gpu.index_add(db, db_off)
+    assert gpu.index_size() == len(db_lens)
+    for k in (1, 10, 13, 20):
+        got = gpu.search_topk(q, q_off, k)
+        want = oracle.search_topk(db, db_off, q, q_off, k, n_threads=4)
+        assert np.array_equal(got, want), f"top-{k} differs"
+    # storage.h:37-39 clamps k to the clip length, so the 1- and 5-word clips score at most 64 / 320
+    # and outrank a noisy true match; the planted slices are still found at their offsets
+    hit0 = got[0][got[0]["clip"] == 0][0]
+    assert hit0["offset"] == 100 and hit0["dist"] <= 5 * 305
+    assert got[1, 0]["clip"] == 4 and got[1, 0]["offset"] == 2015 and got[1, 0]["dist"] == 0
+
+
+def test_search_ties_and_duplicates(gpu, oracle):
+    """identical clips and repeated content: first strict minimum in database order and the
+    smallest offset win (storage.h:50,56)"""
+    rng = np.random.default_rng(12)
+    base = rng.integers(0, 2 ** 64, size=400, dtype=np.uint64)
+    rep = np.concatenate([base[:100], base[:100], base[:100]])   # the same 100 words three times
+    clips = [base, rep, base.copy(), np.zeros(300, np.uint64), np.zeros(300, np.uint64)]
+    db = np.concatenate(clips)
+    db_off = np.concatenate([[0], np.cumsum([c.size for c in clips])]).astype(np.int64)
+    qs = [base[:100], np.zeros(50, np.uint64), base[50:150]]
+    q = np.concatenate(qs)
+    q_off = np.concatenate([[0], np.cumsum([x.size for x in qs])]).astype(np.int64)
+    gpu.index_clear()
+    gpu.index_add(db, db_off)
+    got = gpu.search_topk(q, q_off, 5)
+    want = oracle.search_topk(db, db_off, q, q_off, 5)
+    assert np.array_equal(got, want)
+    assert [int(x) for x in got[0]["clip"][:3]] == [0, 1, 2] and (got[0]["dist"][:3] == 0).all()
+    assert (got[0]["offset"][:3] == 0).all()            # first offset of the repeated block
+    assert [int(x) for x in got[1]["clip"][:2]] == [3, 4]
+
+
+def test_search_empty_and_small_index(gpu, oracle):
+    rng = np.random.default_rng(13)
+    q = rng.integers(0, 2 ** 64, size=30, dtype=np.uint64)
+    q_off = np.array([0, 30], np.int64)
+    gpu.index_clear()
+    got = gpu.search_topk(q, q_off, 4)
+    assert (got["clip"] == 0xFFFFFFFF).all() and (got["dist"] == 0xFFFFFFFF).all()
+    db, db_off = _ragged(rng, [50, 60])
+    gpu.index_add(db, db_off)
+    got = gpu.search_topk(q, q_off, 4)                   # k larger than the index
+    want = oracle.search_topk(db, db_off, q, q_off, 4)
+    assert np.array_equal(got, want)
+    assert (got[0]["clip"][2:] == 0xFFFFFFFF).all()
+    # incremental add keeps clip ids in insertion order
+    db2, db_off2 = _ragged(rng, [70])
+    gpu.index_add(db2, db_off2)
+    got = gpu.search_topk(db2[5:35], q_off, 1)
+    assert got[0, 0]["clip"] == 2 and got[0, 0]["offset"] == 5 and got[0, 0]["dist"] == 0
+
+
+def test_full_size_properties(gpu, torch_cuda, oracle, filters):
+    """BASELINE-size clips (30 s) and queries (5 s): sampled clips bit-identical to the oracle, and
+    the round trip index -> noisy 5 s query -> search finds the right clip at the expected offset."""
+    n_clips = 12
+    clips = [synth.gen_clip(300 + i, 30.0) for i in range(n_clips)]
+    pcm = np.stack(clips)
+    hp = gpu.extract(pcm)
+    assert hp.shape == (n_clips, 2320)
+    plan = oracle.Plan(pcm.shape[1])
+    for i in (0, 7, 11):
+        assert np.array_equal(hp[i], plan.extract(filters, clips[i]))
+    off = np.arange(0, (n_clips + 1) * 2320, 2320, dtype=np.int64)
+    gpu.index_clear()
+    gpu.index_add(hp, off)
+    queries = [synth.gen_query(clips, q) for q in range(8)]
+    qpcm = np.stack([x[0] for x in queries])
+    qhp = gpu.extract(qpcm)
+    assert qhp.shape[1] == 304
+    qplan = oracle.Plan(qpcm.shape[1])
+    assert np.array_equal(qhp[3], qplan.extract(filters, qpcm[3]))
+    q_off = np.arange(0, 9 * 304, 304, dtype=np.int64)
+    hits = gpu.search_topk(qhp, q_off, 3)
+    want = oracle.search_topk(hp.ravel(), off, qhp.ravel(), q_off, 3, n_threads=8)
+    assert np.array_equal(hits, want)
+    hop = 1323000 / 7255 * 3                             # samples per spectrogram column
+    for qi, (_, ci, start) in enumerate(queries):
+        assert hits[qi, 0]["clip"] == ci
+        assert abs(hits[qi, 0]["offset"] - start / hop) <= 2
