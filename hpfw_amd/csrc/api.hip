@@ -86,7 +86,7 @@ struct hpfw_gpu {
     bool has_filters = false;
     float *d_fpack = nullptr;
     std::map<int64_t, std::unique_ptr<DevPlan>> plans;
-    int batch = 32;
+    int batch = 256; // clips per pass: ~2.4 GB of workspace at 30 s; fills the 256 CUs several times over
     // extraction workspace
     size_t ws_bytes[5] = {0, 0, 0, 0, 0};
     void *ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // yp, x, mag, proj, magmax
@@ -203,6 +203,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         cd.n_bands = (int)bc.bands.size();
         cd.radix = to_radix(bc.radix);
         if ((rc = upload(bc.tw, reinterpret_cast<const hpfw::HostCf **>(&cd.tw), dp->owned))) return rc;
+        if ((rc = upload(bc.oct, reinterpret_cast<const hpfw::HostCf **>(&cd.oct), dp->owned))) return rc;
         if ((rc = upload(bc.vrev, reinterpret_cast<const hpfw::HostCf **>(&cd.vrev), dp->owned))) return rc;
         if ((rc = upload(bc.bands, &cd.band, dp->owned))) return rc;
         dp->cls.push_back(cd);
@@ -347,7 +348,7 @@ int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out)
 int hpfw_gpu_set_batch(hpfw_gpu *h, int clips)
 {
     if (!h || clips < 0 || clips > 4096) return fail(HPFW_E_INVALID, "batch out of range");
-    h->batch = clips == 0 ? 32 : clips;
+    h->batch = clips == 0 ? 256 : clips;
     return 0;
 }
 

@@ -4,7 +4,7 @@
 // operations is the one fixed in DESIGN.md "Arithmetic specification" (S1, S3, S4), so results
 // can be compared bit for bit with a host evaluation of the same specification.
 #pragma once
-#include <hip/hip_runtime.h>
+#include "simt.h"
 
 namespace hpfw {
 
@@ -12,29 +12,29 @@ struct cf {
     float r, i;
 };
 
-__device__ __forceinline__ cf c_add(cf a, cf b) { return {a.r + b.r, a.i + b.i}; }
-__device__ __forceinline__ cf c_sub(cf a, cf b) { return {a.r - b.r, a.i - b.i}; }
+HPFW_DEVICE cf c_add(cf a, cf b) { return {a.r + b.r, a.i + b.i}; }
+HPFW_DEVICE cf c_sub(cf a, cf b) { return {a.r - b.r, a.i - b.i}; }
 // a * w
-__device__ __forceinline__ cf c_mul(cf a, cf w)
+HPFW_DEVICE cf c_mul(cf a, cf w)
 {
     float p = a.i * w.i;
     float q = a.i * w.r;
-    return {__builtin_fmaf(a.r, w.r, -p), __builtin_fmaf(a.r, w.i, q)};
+    return {HPFW_FMAF(a.r, w.r, -p), HPFW_FMAF(a.r, w.i, q)};
 }
 // a * conj(w)
-__device__ __forceinline__ cf c_mulc(cf a, cf w)
+HPFW_DEVICE cf c_mulc(cf a, cf w)
 {
     float p = a.i * w.i;
     float q = a.r * w.i;
-    return {__builtin_fmaf(a.r, w.r, p), __builtin_fmaf(a.i, w.r, -q)};
+    return {HPFW_FMAF(a.r, w.r, p), HPFW_FMAF(a.i, w.r, -q)};
 }
 // -i * a
-__device__ __forceinline__ cf c_mulmi(cf a) { return {a.i, -a.r}; }
-__device__ __forceinline__ cf c_fma_s(float s, cf a, cf b)
+HPFW_DEVICE cf c_mulmi(cf a) { return {a.i, -a.r}; }
+HPFW_DEVICE cf c_fma_s(float s, cf a, cf b)
 {
-    return {__builtin_fmaf(s, a.r, b.r), __builtin_fmaf(s, a.i, b.i)};
+    return {HPFW_FMAF(s, a.r, b.r), HPFW_FMAF(s, a.i, b.i)};
 }
-__device__ __forceinline__ cf c_scale(float s, cf a) { return {s * a.r, s * a.i}; }
+HPFW_DEVICE cf c_scale(float s, cf a) { return {s * a.r, s * a.i}; }
 
 // ---- forward DFT butterflies (sign -), in place on u[0..R) -------------------------------
 template <int R>
@@ -42,7 +42,7 @@ struct Dft;
 
 template <>
 struct Dft<2> {
-    static __device__ __forceinline__ void run(cf *u)
+    HPFW_DEVICE_STATIC void run(cf *u)
     {
         cf a = u[0], b = u[1];
         u[0] = c_add(a, b);
@@ -52,7 +52,7 @@ struct Dft<2> {
 
 template <>
 struct Dft<3> {
-    static __device__ __forceinline__ void run(cf *u)
+    HPFW_DEVICE_STATIC void run(cf *u)
     {
         const float s = 0.86602540378443864676f;
         cf t1 = c_add(u[1], u[2]);
@@ -67,7 +67,7 @@ struct Dft<3> {
 
 template <>
 struct Dft<4> {
-    static __device__ __forceinline__ void run(cf *u)
+    HPFW_DEVICE_STATIC void run(cf *u)
     {
         cf t0 = c_add(u[0], u[2]);
         cf t1 = c_sub(u[0], u[2]);
@@ -82,7 +82,7 @@ struct Dft<4> {
 
 template <>
 struct Dft<5> {
-    static __device__ __forceinline__ void run(cf *u)
+    HPFW_DEVICE_STATIC void run(cf *u)
     {
         const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
         const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
@@ -103,7 +103,7 @@ struct Dft<5> {
 
 template <>
 struct Dft<7> {
-    static __device__ __forceinline__ void run(cf *u)
+    HPFW_DEVICE_STATIC void run(cf *u)
     {
         const float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f,
                     c3 = -0.90096886790241912624f;
@@ -128,12 +128,18 @@ struct Dft<7> {
     }
 };
 
+struct RadixList {
+    int n;        // number of passes
+    int r[24];
+};
+
+#if !defined(HPFW_SIMT_EMU)
 // ---- one in-place pass over an array of n complex values held in LDS ---------------------
 // Forward decimation in frequency: sub-transform length `len`, radix R, m = len / R.
 // Butterfly (base, j): gather a[base + j + q m], DFT_R, multiply output s >= 1 by T_n[ts j s],
 // ts = n / len; scatter to the same places.  `tw` is the table T_n (global memory).
 template <int R>
-__device__ __forceinline__ void dif_pass(cf *a, int n, int len, const cf *__restrict__ tw, int tid,
+HPFW_DEVICE void dif_pass(cf *a, int n, int len, const cf *__restrict__ tw, int tid,
                                          int nthreads)
 {
     const int m = len / R;
@@ -158,7 +164,7 @@ __device__ __forceinline__ void dif_pass(cf *a, int n, int len, const cf *__rest
 // Butterfly (base, j): gather a[base + j + q m] * conj(T_n[ts j q]) (q >= 1), inverse DFT_R
 // evaluated as swap(DFT_R(swap(.))), scatter.
 template <int R>
-__device__ __forceinline__ void idit_pass(cf *a, int n, int m, const cf *__restrict__ tw, int tid,
+HPFW_DEVICE void idit_pass(cf *a, int n, int m, const cf *__restrict__ tw, int tid,
                                           int nthreads)
 {
     const int len = m * R;
@@ -185,13 +191,8 @@ __device__ __forceinline__ void idit_pass(cf *a, int n, int m, const cf *__restr
     }
 }
 
-struct RadixList {
-    int n;        // number of passes
-    int r[24];
-};
-
 // Full in-LDS transforms; every thread of the block must call them (they contain barriers).
-__device__ __forceinline__ void lds_fft_dif(cf *a, int n, const RadixList &rl,
+HPFW_DEVICE void lds_fft_dif(cf *a, int n, const RadixList &rl,
                                             const cf *__restrict__ tw, int tid, int nthreads)
 {
     int len = n;
@@ -209,7 +210,7 @@ __device__ __forceinline__ void lds_fft_dif(cf *a, int n, const RadixList &rl,
     }
 }
 
-__device__ __forceinline__ void lds_fft_idit(cf *a, int n, const RadixList &rl,
+HPFW_DEVICE void lds_fft_idit(cf *a, int n, const RadixList &rl,
                                              const cf *__restrict__ tw, int tid, int nthreads)
 {
     int m = 1;
@@ -226,5 +227,7 @@ __device__ __forceinline__ void lds_fft_idit(cf *a, int n, const RadixList &rl,
         __syncthreads();
     }
 }
+
+#endif // !HPFW_SIMT_EMU
 
 } // namespace hpfw

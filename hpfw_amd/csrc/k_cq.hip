@@ -7,12 +7,11 @@
 // (Bluestein) transform of power-of-two length P_j >= Lg_j + C - 1 held entirely in LDS
 // (DESIGN.md S7): a = X[s_j + i] G_j[i]; A = FFT_P(a); B = A . V_P; b = IFFT_P(B); |b[c]|.
 #include "kernels.h"
+#include "fft_lds.h"
 
 namespace hpfw {
 
 extern __shared__ __align__(16) unsigned char smem_raw[];
-
-constexpr int kCqThreads = 256;
 
 __device__ __forceinline__ float wave_max(float v)
 {
@@ -21,36 +20,29 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-__global__ __launch_bounds__(kCqThreads) void cq_kernel(CqPlanDev cp, CqClassDev cc, const cf *__restrict__ x,
-                                                        float *__restrict__ mag, unsigned *__restrict__ magmax)
+constexpr int cq_threads(int logp)
 {
-    cf *a = reinterpret_cast<cf *>(smem_raw);
-    const int tid = threadIdx.x;
+    const int t = (1 << logp) / 16; // one fused 16-point butterfly per thread and pass
+    return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+}
+
+// One workgroup = one band of one clip.  The body (fft_lds.h) is shared with the host-side SIMT
+// emulation of tests/emu; here HPFW_FOR_THREADS is the thread itself and HPFW_BARRIER a barrier.
+template <int LOGP>
+__global__ __launch_bounds__(cq_threads(LOGP)) void cq_kernel(CqPlanDev cp, CqClassDev cc,
+                                                              const cf *__restrict__ x, float *__restrict__ mag,
+                                                              unsigned *__restrict__ magmax)
+{
+    using P = Pow2<LOGP>;
+    cf *lds = reinterpret_cast<cf *>(smem_raw);
+    float *red = reinterpret_cast<float *>(lds + P::DATA); // reuses the twiddle slots after the last pass
     const int j = cc.band[blockIdx.x];
     const int clip = blockIdx.y;
-    const int lg = cp.lg[j];
     const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[j] - cp.kmin);
-    const cf *g = cp.g + cp.g_off[j];
-    for (int i = tid; i < cc.p; i += kCqThreads) {
-        cf v = {0.0f, 0.0f};
-        if (i < lg) v = c_mul(xs[i], g[i]);
-        a[i] = v;
-    }
-    __syncthreads();
-    lds_fft_dif(a, cc.p, cc.radix, cc.tw, tid, kCqThreads);
-    for (int i = tid; i < cc.p; i += kCqThreads) a[i] = c_mul(a[i], cc.vrev[i]);
-    __syncthreads();
-    lds_fft_idit(a, cc.p, cc.radix, cc.tw, tid, kCqThreads);
     float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
-    float mx = 0.0f;
-    for (int i = tid; i < cp.c; i += kCqThreads) {
-        const cf v = a[i];
-        const float m = sqrtf(__builtin_fmaf(v.r, v.r, v.i * v.i));
-        out[i] = m;
-        mx = fmaxf(mx, m);
-    }
-    mx = wave_max(mx);
-    if ((tid & 63) == 0) atomicMax(&magmax[clip], __float_as_uint(mx)); // mag >= 0: bit order = value order
+    cq_band_body<LOGP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.oct, cc.vrev, cp.c, out);
+    const float mx = wave_max(red[threadIdx.x]);
+    if ((threadIdx.x & 63) == 0) atomicMax(&magmax[clip], __float_as_uint(mx)); // mag >= 0: bit order = value order
 }
 
 // per-clip maximum for the stage entry point that starts from given magnitudes
@@ -123,19 +115,35 @@ __global__ __launch_bounds__(256) void db_kernel(const float *mag, const unsigne
     }
 }
 
-static int g_cq_lds_set = 0;
+template <int LOGP>
+static void launch_cq_t(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
+                        unsigned *d_magmax, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<LOGP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid(cc.n_bands, n_clips);
+    hipLaunchKernelGGL(cq_kernel<LOGP>, grid, dim3(cq_threads(LOGP)), (size_t)Pow2<LOGP>::LDS_CF * sizeof(cf), s, cp,
+                       cc, d_x, d_mag, d_magmax);
+}
 
 void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
                      unsigned *d_magmax, hipStream_t s)
 {
-    if (!g_cq_lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        g_cq_lds_set = 1;
+    switch (cc.p) {
+    case 64: launch_cq_t<6>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
+    case 128: launch_cq_t<7>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
+    case 256: launch_cq_t<8>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
+    case 512: launch_cq_t<9>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
+    case 1024: launch_cq_t<10>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
+    case 2048: launch_cq_t<11>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
+    case 4096: launch_cq_t<12>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
+    case 8192: launch_cq_t<13>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
+    default: launch_cq_t<14>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break; // 16384: the plan admits nothing larger
     }
-    dim3 grid(cc.n_bands, n_clips);
-    hipLaunchKernelGGL(cq_kernel, grid, dim3(kCqThreads), (size_t)cc.p * sizeof(cf), s, cp, cc, d_x, d_mag,
-                       d_magmax);
 }
 
 void launch_magmax(const float *d_mag, int n_clips, int64_t per_clip, unsigned *d_magmax, hipStream_t s)

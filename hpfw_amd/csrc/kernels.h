@@ -33,6 +33,7 @@ struct CqClassDev {
     int n_bands;        // bands in this class
     RadixList radix;
     const cf *tw;       // T_p   [p]
+    const cf *oct;      // first octant (cos, sin)(2 pi t / p), t = 0..p/8
     const cf *vrev;     // DFT_p(chirp) at digit-reversed positions [p]
     const int *band;    // band index j                 [n_bands]
 };

@@ -229,6 +229,27 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
             bc.p = (int)ps;
             make_radix_list(ps, bc.radix);
             bc.tw = twiddle_table(ps);
+            // first-octant table the kernels keep in LDS; T_p must follow from it exactly
+            bc.oct.resize((size_t)(ps / 8 + 1));
+            for (int64_t t = 0; t <= ps / 8; ++t) {
+                const double alpha = M_PI * (double)(8 * t) / (double)(4 * ps);
+                bc.oct[(size_t)t] = {(float)std::cos(alpha), (float)std::sin(alpha)};
+            }
+            for (int64_t mm = 0; mm < ps; ++mm) {
+                const int o = (int)(mm / (ps / 8));
+                const int64_t r = mm % (ps / 8);
+                const HostCf e = bc.oct[(size_t)((o & 1) ? ps / 8 - r : r)];
+                const bool swp = ((o + 1) & 2) != 0;
+                float c = swp ? e.i : e.r, s = swp ? e.r : e.i;
+                if ((o + 2) & 4) c = -c;
+                if (o & 4) s = -s;
+                const HostCf want = bc.tw[(size_t)mm];
+                const float ni = -s;
+                if (std::memcmp(&c, &want.r, 4) != 0 || std::memcmp(&ni, &want.i, 4) != 0) {
+                    why = "internal: octant twiddle table does not reproduce T_p";
+                    return false;
+                }
+            }
             std::vector<double> re((size_t)ps, 0.0), im((size_t)ps, 0.0);
             for (int64_t mm = -(ps - p.c); mm <= p.c - 1; ++mm) { // v[m mod P] = e^{-i pi 3 m^2 / M}
                 double cc, ss;

@@ -15,6 +15,7 @@ struct BluesteinClass {
     int p = 0;
     std::vector<int> radix;
     std::vector<HostCf> tw;    // T_p
+    std::vector<HostCf> oct;   // (cos, sin)(2 pi t / p), t = 0..p/8: first octant, T_p follows by symmetry
     std::vector<HostCf> vrev;  // DFT_p(chirp) at digit-reversed positions
     std::vector<int> bands;    // bands using this size
 };
