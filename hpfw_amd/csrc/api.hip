@@ -275,6 +275,8 @@ int run_chain(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, uint64_t *
 extern "C" {
 
 const char *hpfw_gpu_last_error(void) { return g_err.c_str(); }
+// used by legacy.cpp so that the file entry points report through the same thread-local message
+void hpfw_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
 const char *hpfw_gpu_version(void) { return "hpfw-gpu 0.1 (gfx950)"; }
 
 int hpfw_gpu_create(int device, hpfw_gpu **out)

@@ -19,9 +19,9 @@
 
 #include "../../include/hpfw_gpu.h"
 
-namespace {
+extern "C" void hpfw_internal_set_error(const char *msg); // api.hip: feeds hpfw_gpu_last_error()
 
-thread_local std::string g_legacy_err;
+namespace {
 
 bool read_wav_pcm16_mono(const std::string &path, std::vector<int16_t> &out, std::string &why)
 {
@@ -164,9 +164,16 @@ uint64_t *par_collector_calc_hashprint(hpfw_legacy_collector *c, const char *fil
     if (!c || !filename || !size) return nullptr;
     std::vector<int16_t> pcm;
     std::string why;
-    if (!read_wav_pcm16_mono(filename, pcm, why)) return nullptr;
+    if (!read_wav_pcm16_mono(filename, pcm, why)) {
+        hpfw_internal_set_error(why.c_str());
+        return nullptr;
+    }
     hpfw_geometry g;
-    if (hpfw_gpu_geometry(c->gpu, (int64_t)pcm.size(), &g) != 0 || g.n_hp <= 0) return nullptr;
+    if (hpfw_gpu_geometry(c->gpu, (int64_t)pcm.size(), &g) != 0) return nullptr;
+    if (g.n_hp <= 0) {
+        hpfw_internal_set_error((std::string(filename) + ": clip too short to yield a hashprint").c_str());
+        return nullptr;
+    }
     auto *hp = new uint64_t[(size_t)g.n_hp];
     if (hpfw_gpu_extract_pcm16_host(c->gpu, pcm.data(), (int64_t)pcm.size(), 1, hp) != 0) {
         delete[] hp;

@@ -1,0 +1,122 @@
+"""GPU tests of the drop-in surface: the reference's eight FFI symbols (through the pyhpfw twin),
+the cereal filter file, the C++ LiveSongIdentification facade (config 0: a handful of WAVs indexed
+and queried end to end) and the error behaviour of the C-ABI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import hpfw_amd  # noqa: E402
+from hpfw_amd import _lib, synth  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_filters(cache_dir, filt):
+    os.makedirs(cache_dir, exist_ok=True)
+    with open(os.path.join(cache_dir, "filters.cereal"), "wb") as f:      # utils.h:84-90
+        f.write(np.array([64, 2420], np.int32).tobytes())
+        f.write(np.ascontiguousarray(filt, np.float32).tobytes())
+
+
+@pytest.fixture(scope="module")
+def wav_set(tmp_path_factory, torch_cuda):
+    d = tmp_path_factory.mktemp("wavs")
+    clips = [synth.gen_clip(500 + i, 8.0) for i in range(4)]
+    paths = []
+    for i, c in enumerate(clips):
+        p = str(d / f"track{i:02d}.wav")
+        synth.write_wav(p, c)
+        paths.append(p)
+    qpaths = []
+    for q in range(3):
+        pcm, ci, start = synth.gen_query(clips, q, seconds=3.0)
+        p = str(d / f"live_track{ci:02d}_take{q}.wav")
+        synth.write_wav(p, pcm)
+        qpaths.append((p, ci, start))
+    return d, clips, paths, qpaths
+
+
+def test_legacy_ffi_through_python_twin(wav_set, oracle, filters):
+    d, clips, paths, qpaths = wav_set
+    cache = str(d / "cache") + "/"
+    _write_filters(cache, filters)
+    pc = hpfw_amd.ParallelCollector()
+    with pytest.raises(hpfw_amd.HpfwError):            # no filters yet: an error, never garbage (D-9)
+        pc.calc_hashprint(paths[0])
+    pc.load(cache)
+    res = pc.prepare(paths + [str(d / "missing.wav")])  # a bad file is skipped, as parallel_collector.h:101-103
+    assert [name for _, name in res] == [f"track{i:02d}" for i in range(4)]
+    plan = oracle.Plan(clips[0].size)
+    for (hp, _), c in zip(res, clips):
+        assert hp.dtype == np.uint64 and np.array_equal(hp, plan.extract(filters, c))
+    q = pc.calc_hashprint(qpaths[0][0])
+    assert np.array_equal(q, oracle.Plan(3 * 44100).extract(filters, synth.gen_query(clips, 0, seconds=3.0)[0]))
+    pc.save(str(d / "cache2"))
+    raw = open(str(d / "cache2" / "filters.cereal"), "rb").read()
+    assert raw[:8] == np.array([64, 2420], np.int32).tobytes() and raw[8:] == np.asarray(filters, np.float32).tobytes()
+
+
+def test_stereo_and_unsupported_wav(wav_set, filters, tmp_path):
+    d, clips, _, _ = wav_set
+    pc = hpfw_amd.ParallelCollector()
+    pc.load(str(d / "cache") + "/")
+    stereo = np.stack([clips[0], clips[0]], axis=1)      # identical channels: the "mix" downmix returns the clip
+    p = str(tmp_path / "stereo.wav")
+    synth.write_wav(p, stereo, channels=2)
+    mono = str(tmp_path / "mono.wav")
+    synth.write_wav(mono, clips[0])
+    assert np.array_equal(pc.calc_hashprint(p), pc.calc_hashprint(mono))
+    bad = str(tmp_path / "odd.wav")
+    synth.write_wav(bad, clips[0][:44100 * 8 - 1])       # 352799 samples: prime factor 13 -> unsupported length
+    with pytest.raises(hpfw_amd.HpfwError) as e:
+        pc.calc_hashprint(bad)
+    assert "prime factor" in str(e.value)
+    with pytest.raises(hpfw_amd.HpfwError):
+        pc.calc_hashprint(str(tmp_path / "nope.wav"))
+
+
+def test_cpp_live_song_identification(wav_set, filters, tmp_path):
+    """config 0 plumbing: index + search through hpfw::LiveSongIdentification<GpuCollector, GpuStorage>"""
+    d, clips, paths, qpaths = wav_set
+    exe = str(tmp_path / "live_id")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["g++", "-std=c++20", "-O1", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "live_id.cpp"), "-o", exe, "-L", libdir, "-lhpfw_gpu",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    work = tmp_path / "run"
+    _write_filters(str(work / "cache"), filters)
+    r = subprocess.run([exe, "--index"] + paths + ["--search"] + [q[0] for q in qpaths], cwd=str(work),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("=> ")]
+    assert lines[-1] == "=> 0 1"                         # live_song_id.h:53: wrong count, accuracy
+    hop = 3.0 * (8 * 44100) / round((2 ** (1 / 24) - 2 ** (-1 / 24)) * 130.81 * 32 * 8)   # samples per column
+    for (qp, ci, start), k in zip(qpaths, range(3)):
+        assert lines[2 * k] == f"=> Finding {qp}"
+        name, cnt, off = lines[2 * k + 1][3:].split()
+        assert name == f"track{ci:02d}" and int(cnt) > 0 and abs(int(off) - start / hop) <= 2
+
+
+def test_c_abi_error_codes(torch_cuda):
+    L = hpfw_amd.lib()
+    g = hpfw_amd.Gpu(0)
+    pcm = np.zeros((1, 132300), np.int16)
+    with pytest.raises(hpfw_amd.HpfwError) as e:
+        g.extract(pcm)
+    assert "-3" in str(e.value) and "filters" in str(e.value)        # HPFW_E_NOFILTERS
+    with pytest.raises(hpfw_amd.HpfwError) as e:
+        g.geometry(132301)
+    assert "-2" in str(e.value)                                       # HPFW_E_UNSUPPORTED
+    import ctypes
+    h = ctypes.c_void_p()
+    assert L.hpfw_gpu_create(99, ctypes.byref(h)) == -1               # HPFW_E_INVALID: no such device
+    assert b"device" in L.hpfw_gpu_last_error()
+    g.set_filters(synth.make_filters())
+    hp = g.extract(pcm)                                               # silence: every delta is 0 -> all ones
+    assert (hp == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    g.close()

@@ -222,3 +222,38 @@ def test_full_size_properties(gpu, torch_cuda, oracle, filters):
     for qi, (_, ci, start) in enumerate(queries):
         assert hits[qi, 0]["clip"] == ci
         assert abs(hits[qi, 0]["offset"] - start / hop) <= 2
+
+
+def test_golden_vectors_on_gpu(gpu, torch_cuda):
+    """the committed fixtures (tests/golden, generated by make_golden.py) through the HIP path"""
+    import os
+    import sys
+    import hpfw_amd
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import gen
+    g = np.load(os.path.join(here, "golden", "extract.npz"))
+    h = hpfw_amd.Gpu(0)
+    h.set_filters(gen.golden_filters())
+    two = np.stack([gen.golden_pcm(110250, 1), gen.golden_pcm(110250, 2)])
+    hp = h.extract(two)
+    assert np.array_equal(hp[0], g["a_hp"]) and np.array_equal(hp[1], g["b_hp"])
+    assert np.array_equal(h.extract(gen.golden_pcm(88200, 3))[0], g["c_hp"])
+    torch = torch_cuda
+    d_pcm = _dev(torch, two)
+    geo = g["a_geometry"]
+    nk, c = int(geo[3] - geo[2]), int(geo[5])
+    d_x = torch.empty((2, nk, 2), dtype=torch.float32, device="cuda")
+    h.stage_spectrum_dev(d_pcm.data_ptr(), 110250, 2, d_x.data_ptr())
+    d_mag = torch.empty((2, 121, c), dtype=torch.float32, device="cuda")
+    h.stage_cqmag_dev(d_x.data_ptr(), 110250, 2, d_mag.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_x.cpu().numpy()[1][::97], g["b_x_every97"])
+    mag = d_mag.cpu().numpy()
+    assert np.array_equal(mag[0][::4, ::8], g["a_mag_f32_every8"])
+    m64 = g["a_mag_f64_every8"]
+    assert (np.abs(mag[0][::4, ::8] - m64).max(axis=1) / m64.max(axis=1)).max() < 1e-4   # north_star tolerance
+    s = np.load(os.path.join(here, "golden", "search.npz"))
+    h.index_add(s["db"], s["db_off"])
+    assert np.array_equal(h.search_topk(s["q"], s["q_off"], 5), s["top5"])
+    h.close()

@@ -1,0 +1,96 @@
+"""CPU tests of the product library's host side: it loads, exports every symbol the header
+declares, builds the same constant tables as the oracle, and its host-only helpers behave.
+No compute call is made here (there is no GPU in this environment and no CPU fallback to call)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import hpfw_amd
+from hpfw_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "hpfw_gpu.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b((?:hpfw_gpu|par_collector)_\w+|prepare_result_free|calc_hashprint_result_free)\s*\(",
+                              header))
+    assert len(declared) >= 34
+    L = hpfw_amd.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS)
+    assert b"gfx950" in L.hpfw_gpu_version()
+
+
+def test_library_contains_gfx950_code_object():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-S", _lib.LIB_PATH], capture_output=True, text=True)
+    assert ".hip_fatbin" in out.stdout
+    strings = subprocess.run(["strings", "-n", "6", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in strings and "hamming_scan_kernel" in strings and "project_kernel" in strings
+
+
+@pytest.mark.parametrize("n", [1323000, 220500, 441000, 132300, 110250, 88200])
+def test_plan_tables_identical_to_oracle(oracle, n):
+    """twiddles, digit reversal, band geometry, window*chirp and chirp spectra: the product's host
+    code (hpfw_amd/csrc/plan.cpp) and the oracle build them independently; FNV-1a checksums agree"""
+    want = np.zeros(8, np.uint64)
+    plan = oracle.Plan(n)
+    oracle.lib().hpfw_oracle_plan_checksum.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    oracle.lib().hpfw_oracle_plan_checksum(plan._h, want.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(hpfw_amd.plan_checksum(n), want)
+
+
+def test_unsupported_lengths_fail_loudly():
+    for n in (1323001, 4410, 1, 44100 * 60):       # prime factor 11 ..., too short, too long for the LDS
+        with pytest.raises(hpfw_amd.HpfwError):
+            hpfw_amd.plan_checksum(n)
+
+
+def test_merge_topk_host():
+    h = np.zeros((3, 2, 3), hpfw_amd.HIT_DTYPE)
+    h["dist"] = 0xFFFFFFFF
+    h["clip"] = 0xFFFFFFFF
+    h[0, 0] = [(5, 0, 1, 0), (9, 3, 2, 0), (9, 4, 7, 0)]
+    h[1, 0] = [(5, 10, 1, 0), (6, 11, 0, 0), (0xFFFFFFFF, 0xFFFFFFFF, 0, 0)]
+    h[2, 0] = [(4, 20, 9, 0), (9, 21, 0, 0), (12, 22, 0, 0)]
+    h[1, 1, 0] = (7, 12, 3, 0)
+    m = hpfw_amd.merge_topk(h, 3)
+    assert [tuple(int(v) for v in x)[:3] for x in m[0]] == [(4, 20, 9), (5, 0, 1), (5, 10, 1)]
+    assert tuple(int(v) for v in m[1, 0])[:3] == (7, 12, 3) and m[1, 1]["clip"] == 0xFFFFFFFF
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhpfw_gpu.so")
+    with pytest.raises(hpfw_amd.HpfwError):
+        _lib.lib()
+
+
+def test_no_product_file_touches_the_oracle():
+    """the oracle is test infrastructure: nothing under hpfw_amd/ or include/ may name it"""
+    bad = []
+    for base in ("hpfw_amd", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
+                    text = open(os.path.join(d, f), errors="ignore").read()
+                    if re.search(r"hpfw_oracle|from oracle|import oracle|oracle/", text):
+                        bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_cpp_facade_compiles_and_links(tmp_path):
+    """the drop-in C++ surface: LiveSongIdentification<GpuCollector, GpuStorage>"""
+    exe = tmp_path / "live_id"
+    cmd = ["g++", "-std=c++20", "-O1", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "live_id.cpp"), "-o", str(exe),
+           "-L", os.path.dirname(_lib.LIB_PATH), "-lhpfw_gpu", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH),
+           "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

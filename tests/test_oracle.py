@@ -1,0 +1,174 @@
+"""CPU tests of the oracle: against an independent float64 statement of the mathematics
+(oracle/nsgt_f64.py, numpy FFT), against plain-Python restatements of the integer stages, and
+against the committed golden vectors.  The oracle is the checker for the GPU tests; these tests
+are what pins it (the reference has no fixtures: DESIGN.md "Oracle", parity unpinned)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import gen  # noqa: E402
+from oracle import nsgt_f64  # noqa: E402
+
+
+def test_geometry_of_baseline_configs(oracle):
+    """30 s -> M 7255, C 2419, 2400 frames, 2320 hashprints; 5 s -> M 1209,
+    403 valid columns, 304 hashprints (the uninitialised 404th column of cqt.h:73 is dropped)."""
+    p = oracle.Plan(1323000)
+    assert (p.m, p.c, p.n_frames, p.n_hp) == (7255, 2419, 2400, 2320)
+    assert p.n1 * p.n2 == 1323000 and p.lg.min() == 227 and p.lg.max() == 7255 and int(p.lg.sum()) == 247102
+    q = oracle.Plan(220500)
+    assert (q.m, q.c, q.n_frames, q.n_hp) == (1209, 403, 384, 304)
+    assert q.lg.min() == 96                                  # minimumWindow clamp, cqt.h:58
+    posit, lg = nsgt_f64.bands(1323000)
+    assert np.array_equal(lg, p.lg) and np.array_equal(posit - lg // 2, p.start)
+    with pytest.raises(ValueError):
+        oracle.Plan(1323001)                                 # 11 * 120273: not 7-smooth
+    with pytest.raises(ValueError):
+        oracle.Plan(4410)                                    # bands leave the half spectrum
+
+
+@pytest.mark.parametrize("n,radix", [(4, [4]), (6, [3, 2]), (35, [7, 5]), (420, [7, 5, 4, 3]),
+                                     (14700, [7, 7, 5, 5, 4, 3]), (4096, [4] * 6), (8192, [4] * 6 + [2])])
+def test_fft_passes_against_numpy(oracle, n, radix):
+    rng = np.random.default_rng(n)
+    a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    pos = np.array([oracle.digit_pos(k, n, radix) for k in range(n)])
+    ref = np.fft.fft(a.astype(np.complex128))
+    got = oracle.fft_dif(a, radix)
+    assert np.abs(got[pos] - ref).max() / np.abs(ref).max() < 5e-7
+    rev = np.zeros(n, np.complex64)
+    rev[pos] = ref.astype(np.complex64)
+    back = oracle.fft_idit(rev, radix)
+    assert np.abs(back / n - a).max() < 2e-6
+
+
+def test_twiddles_are_exactly_symmetric(oracle):
+    assert oracle.twiddle(0, 8) == (1.0, -0.0)
+    assert oracle.twiddle(2, 8) == (-0.0, -1.0) and oracle.twiddle(4, 8) == (-1.0, 0.0)
+    for n in (14700, 4096, 90):
+        for m in (1, 7, n // 3):
+            c, s = oracle.twiddle(m, n)
+            c2, s2 = oracle.twiddle(n - m, n)
+            assert (c, s) == (c2, -s2)
+            assert abs(c - np.cos(2 * np.pi * m / n)) < 6e-8 and abs(s + np.sin(2 * np.pi * m / n)) < 6e-8
+
+
+def test_log10_spec(oracle):
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([10.0 ** rng.uniform(-12, 12, 3000), [1.0, 2.0, 0.5, 1e-10, 1.4142135623730951]])
+    assert max(abs(oracle.log10(x) - np.log10(x)) for x in xs) < 2e-15
+
+
+@pytest.mark.parametrize("n", [88200, 110250, 220500])
+def test_front_end_against_float64_definition(oracle, n):
+    pcm = gen.golden_pcm(n, 5)
+    plan = oracle.Plan(n)
+    x = plan.spectrum(pcm)
+    ref = np.fft.fft(pcm / 32768.0)[plan.kmin:plan.kmax]
+    assert np.abs((x[:, 0] + 1j * x[:, 1]) - ref).max() / np.abs(ref).max() < 1e-6
+    mag = plan.cqmag(x)
+    m64 = nsgt_f64.cq_magnitudes(pcm)
+    assert mag.shape == m64.shape
+    assert (np.abs(mag - m64).max(axis=1) / m64.max(axis=1)).max() < 1e-5   # north_star asks 1e-4
+    s = oracle.db(mag)
+    assert s.max() == 0.0 and s.min() >= -80.0
+    assert np.abs(s - nsgt_f64.amplitude_to_db(m64)).max() < 0.02
+
+
+def test_db_floor_and_silence(oracle):
+    assert (oracle.db(np.zeros((121, 30), np.float32)) == 0.0).all()   # all at the 1e-10 floor: 0 dB
+    m = np.full((121, 30), 1e-7, np.float32)
+    m[3, 4] = 1.0
+    s = oracle.db(m)
+    assert s[3, 4] == 0.0 and (np.delete(s.ravel(), 3 * 30 + 4) == -80.0).all()
+    m[0, 0] = 1e-3                                          # -60 dB
+    assert abs(oracle.db(m)[0, 0] + 60.0) < 1e-4
+
+
+def test_projection_and_packing(oracle):
+    """layout k = bin * 20 + t (hashprint_handle.h:84-90) and MSB-first bits (:137-142)"""
+    rng = np.random.default_rng(8)
+    s = rng.uniform(-80, 0, (121, 140)).astype(np.float32)
+    f_rows = rng.standard_normal((64, 2420)).astype(np.float32) / 50
+    f_cm = np.ascontiguousarray(f_rows.T).ravel()
+    pr = oracle.project(f_cm, s)
+    assert pr.shape == (64, 121)
+    assert np.abs(pr - nsgt_f64.project(f_rows, s)).max() < 2e-2
+    one = np.zeros((64, 2420), np.float32)
+    one[5, 7 * 20 + 3] = 1.0                                 # filter 5 reads bin 7, context column 3
+    assert np.array_equal(oracle.project(np.ascontiguousarray(one.T).ravel(), s)[5], s[7, 3:3 + 121])
+    hp = oracle.pack(pr)
+    assert hp.shape == (41,) and np.array_equal(hp, nsgt_f64.pack(pr.astype(np.float64)))
+    p2 = np.zeros((64, 90), np.float32)
+    p2[0, :10] = 1.0                                         # row 0 decreasing over the lag -> MSB
+    p2[63, 80:] = -1.0                                       # row 63 -> LSB ... and zeros count as >= 0
+    h2 = oracle.pack(p2)
+    assert h2[0] == np.uint64(0xFFFFFFFFFFFFFFFF) and h2.shape == (10,)
+    p2[0, 80:] = 2.0
+    assert oracle.pack(p2)[0] == np.uint64(0x7FFFFFFFFFFFFFFF)
+
+
+def _popcount(a):
+    return sum(bin(int(v)).count("1") for v in a)
+
+
+def test_match_clip_semantics(oracle):
+    """storage.h:33-54: k clamps to the clip length, first strict minimum wins"""
+    rng = np.random.default_rng(9)
+    r = rng.integers(0, 2 ** 64, size=60, dtype=np.uint64)
+    assert oracle.match_clip(r[17:37], r) == (0, 17)
+    q = r[17:37].copy()
+    q[3] ^= np.uint64(0b1011)
+    assert oracle.match_clip(q, r) == (3, 17)
+    long_q = np.concatenate([r, rng.integers(0, 2 ** 64, size=10, dtype=np.uint64)])
+    assert oracle.match_clip(long_q, r) == (0, 0)            # only the first 60 words are compared
+    rep = np.concatenate([r[:10], r[:10], r[:10]])
+    assert oracle.match_clip(r[:10], rep) == (0, 0)
+    d, off = oracle.match_clip(q, rng.integers(0, 2 ** 64, size=25, dtype=np.uint64))
+    assert 0 <= off <= 5 and d > 0
+
+
+def test_golden_extract(oracle):
+    g = np.load(os.path.join(HERE, "golden", "extract.npz"))
+    filt = gen.golden_filters()
+    for tag in "abc":
+        n, seed = int(g[f"{tag}_n"]), int(g[f"{tag}_seed"])
+        pcm = gen.golden_pcm(n, seed)
+        plan = oracle.Plan(n)
+        geo = [plan.n1, plan.n2, plan.kmin, plan.kmax, plan.m, plan.c, plan.n_frames, plan.n_hp]
+        assert geo == g[f"{tag}_geometry"].tolist()
+        x = plan.spectrum(pcm)
+        assert np.array_equal(x[::97], g[f"{tag}_x_every97"])
+        mag = plan.cqmag(x)
+        assert np.array_equal(mag[::4, ::8], g[f"{tag}_mag_f32_every8"])
+        m64 = g[f"{tag}_mag_f64_every8"]
+        assert (np.abs(mag[::4, ::8] - m64).max(axis=1) / m64.max(axis=1)).max() < 1e-5
+        s = oracle.db(mag)
+        assert np.array_equal(s[::4, ::8], g[f"{tag}_db_every8"])
+        pr = oracle.project(filt, s)
+        assert np.array_equal(pr[::8, ::8], g[f"{tag}_proj_every8"])
+        assert np.array_equal(oracle.pack(pr), g[f"{tag}_hp"])
+        assert np.array_equal(plan.extract(filt, pcm), g[f"{tag}_hp"])
+    two = np.stack([gen.golden_pcm(110250, 1), gen.golden_pcm(110250, 2)])
+    hp = oracle.Plan(110250).extract_batch(filt, two, n_threads=2)
+    assert np.array_equal(hp[0], g["a_hp"]) and np.array_equal(hp[1], g["b_hp"])
+
+
+def test_golden_search(oracle):
+    g = np.load(os.path.join(HERE, "golden", "search.npz"))
+    for threads in (1, 3):
+        top = oracle.search_topk(g["db"], g["db_off"], g["q"], g["q_off"], 5, n_threads=threads)
+        assert np.array_equal(top, g["top5"])
+    t = g["top5"]
+    assert (t[0, 0]["clip"], t[0, 0]["offset"], t[0, 0]["dist"]) == (0, 20, 0)
+    assert (t[0, 1]["clip"], t[0, 1]["offset"], t[0, 1]["dist"]) == (4, 20, 0)   # duplicate clip: id order
+    # storage.h:37-39 clamps k to the clip length: the 1-word clip 2 and the 5-word clip 6 outrank
+    # the planted slice (100 hashprints, two flipped bits each), which comes third at its offset
+    assert [int(c) for c in t[1]["clip"][:3]] == [2, 6, 3]
+    assert (t[1, 2]["offset"], t[1, 2]["dist"]) == (10, 200)
+    top1 = oracle.search_topk(g["db"], g["db_off"], g["q"], g["q_off"], 1)
+    assert np.array_equal(top1[:, 0], t[:, 0])
