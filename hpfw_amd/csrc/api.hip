@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -61,6 +62,7 @@ hpfw::RadixList to_radix(const std::vector<int> &r)
 struct DevPlan {
     hpfw::HostPlan hp;
     hpfw::FwdPlanDev fwd;
+    hpfw::RowsArgs rows;
     hpfw::CqPlanDev cq;
     std::vector<hpfw::CqClassDev> cls;
     std::vector<void *> owned;
@@ -88,8 +90,8 @@ struct hpfw_gpu {
     std::map<int64_t, std::unique_ptr<DevPlan>> plans;
     int batch = 256; // clips per pass: ~2.4 GB of workspace at 30 s; fills the 256 CUs several times over
     // extraction workspace
-    size_t ws_bytes[5] = {0, 0, 0, 0, 0};
-    void *ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // yp, x, mag, proj, magmax
+    size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
+    void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // yp, x, mag, proj, magmax, pairs
     // index
     uint64_t *d_db = nullptr;
     size_t db_cap = 0;
@@ -188,6 +190,23 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     if ((rc = upload(p.tw_n1, reinterpret_cast<const hpfw::HostCf **>(&f.tw_n1), dp->owned))) return rc;
     if ((rc = upload(p.tw_big, reinterpret_cast<const hpfw::HostCf **>(&f.tw_big), dp->owned))) return rc;
     if ((rc = upload(p.pos_n2, &f.pos_n2, dp->owned))) return rc;
+    hpfw::RowsArgs &ra = dp->rows;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.n1 = p.n1;
+    ra.n2 = p.n2;
+    ra.h = p.h;
+    ra.quad = p.rows_quad;
+    ra.groups.n = (int)p.groups.size();
+    for (size_t g = 0; g < p.groups.size(); ++g) {
+        ra.groups.r1[g] = p.groups[g].first;
+        ra.groups.r2[g] = p.groups[g].second;
+    }
+    ra.tw_n2 = f.tw_n2;
+    ra.tw_big = f.tw_big;
+    ra.pos_n2 = f.pos_n2;
+    if (hpfw::fwd_rows_lds_bytes(ra) > 160 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
+    if (std::getenv("HPFW_DEBUG_ROWS_NOGROUPS")) ra.groups.n = 0; // timing ablation only (wrong results)
+    if (std::getenv("HPFW_DEBUG_ROWS_NOEPI")) ra.h = 0;
     hpfw::CqPlanDev &c = dp->cq;
     c.kmin = p.kmin;
     c.nk = p.kmax - p.kmin;
@@ -214,33 +233,34 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     return 0;
 }
 
-int ensure_ws(hpfw_gpu *h, const hpfw::HostPlan &p, int nb)
+// nb: clips per front-end pass (large intermediates); ns: clips per back-end pass (S and P only)
+int ensure_ws(hpfw_gpu *h, const hpfw::HostPlan &p, int nb, int ns)
 {
-    const size_t need[5] = {(size_t)nb * p.n1 * p.h * 8, (size_t)nb * (p.kmax - p.kmin) * 8,
-                            (size_t)nb * 121 * p.c * 4, (size_t)nb * 64 * (size_t)std::max(p.n_frames, 1) * 4,
-                            (size_t)nb * 4};
-    for (int i = 0; i < 5; ++i) {
+    const size_t need[6] = {(size_t)nb * p.n1 * p.h * 8, (size_t)nb * (p.kmax - p.kmin) * 8,
+                            (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4,
+                            (size_t)ns * 4, (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4};
+    for (int i = 0; i < 6; ++i) {
         int rc = ensure(&h->ws[i], &h->ws_bytes[i], need[i]);
         if (rc) return rc;
     }
     return 0;
 }
 
-// the chain for nb clips already sized into the workspace
-int run_chain(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, uint64_t *d_hp, hipStream_t s)
+// front end for nb clips: PCM -> dB spectrogram, written at clip slot `slot` of the S workspace
+int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, hipStream_t s)
 {
     using hpfw::cf;
     const hpfw::HostPlan &p = dp->hp;
     cf *yp = (cf *)h->ws[0];
     cf *x = (cf *)h->ws[1];
-    float *mag = (float *)h->ws[2];
-    float *proj = (float *)h->ws[3];
-    unsigned *mm = (unsigned *)h->ws[4];
+    float *mag = (float *)h->ws[2] + (size_t)slot * 121 * p.c;
+    unsigned *mm = (unsigned *)h->ws[4] + slot;
     int rc;
     HIP_TRY(hipMemsetAsync(mm, 0, (size_t)nb * 4, s));
     {
         Timed t(h, K_ROWS, s);
-        hpfw::launch_fwd_rows(dp->fwd, d_pcm, nb, yp, s);
+        hpfw::launch_pcm_pairs(p.n, p.n1, p.n2, d_pcm, nb, (hpfw::i16x2 *)h->ws[5], s);
+        hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, yp, s);
     }
     if ((rc = check_launch("fwd_rows"))) return rc;
     {
@@ -257,18 +277,29 @@ int run_chain(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, uint64_t *
         Timed t(h, K_DB, s);
         hpfw::launch_db(mag, mm, nb, (int64_t)121 * p.c, mag, s);
     }
-    if ((rc = check_launch("db"))) return rc;
+    return check_launch("db");
+}
+
+// back end for ns clips: dB spectrograms of the S workspace -> hashprints
+int run_back(hpfw_gpu *h, DevPlan *dp, int ns, uint64_t *d_hp, hipStream_t s)
+{
+    const hpfw::HostPlan &p = dp->hp;
+    float *sdb = (float *)h->ws[2];
+    float *proj = (float *)h->ws[3];
+    int rc;
     {
         Timed t(h, K_PROJECT, s);
-        hpfw::launch_project(h->d_fpack, mag, nb, p.c, proj, s);
+        hpfw::launch_project(h->d_fpack, sdb, ns, p.c, proj, s);
     }
     if ((rc = check_launch("project"))) return rc;
     {
         Timed t(h, K_PACK, s);
-        hpfw::launch_pack(proj, nb, p.n_frames, d_hp, s);
+        hpfw::launch_pack(proj, ns, p.n_frames, d_hp, s);
     }
     return check_launch("delta_pack");
 }
+
+constexpr int kBackBatch = 1024; // clips per projection launch: ~10^4 workgroups, a small launch tail
 
 } // namespace
 
@@ -366,10 +397,16 @@ int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
     if (dp->hp.n_hp <= 0) return fail(HPFW_E_UNSUPPORTED, "clip too short to yield a hashprint");
     hipStream_t s = (hipStream_t)stream;
     const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
-    if ((rc = ensure_ws(h, dp->hp, nbmax))) return rc;
-    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
-        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        rc = run_chain(h, dp, d_pcm + c0 * n_samples, nb, d_hp + c0 * dp->hp.n_hp, s);
+    const int nsmax = (int)std::min<int64_t>(std::max(kBackBatch, nbmax), std::max<int64_t>(n_clips, 1));
+    if ((rc = ensure_ws(h, dp->hp, nbmax, nsmax))) return rc;
+    for (int64_t s0 = 0; s0 < n_clips; s0 += nsmax) {
+        const int ns = (int)std::min<int64_t>(nsmax, n_clips - s0);
+        for (int c0 = 0; c0 < ns; c0 += nbmax) {
+            const int nb = std::min(nbmax, ns - c0);
+            rc = run_front(h, dp, d_pcm + (s0 + c0) * n_samples, nb, c0, s);
+            if (rc) return rc;
+        }
+        rc = run_back(h, dp, ns, d_hp + s0 * dp->hp.n_hp, s);
         if (rc) return rc;
     }
     return 0;
@@ -414,11 +451,12 @@ int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
-    if ((rc = ensure_ws(h, dp->hp, nbmax))) return rc;
+    if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        hpfw::launch_fwd_rows(dp->fwd, d_pcm + c0 * n_samples, nb, (hpfw::cf *)h->ws[0], s);
+        hpfw::launch_pcm_pairs(dp->hp.n, dp->hp.n1, dp->hp.n2, d_pcm + c0 * n_samples, nb, (hpfw::i16x2 *)h->ws[5], s);
+        hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, (hpfw::cf *)h->ws[0], s);
         if ((rc = check_launch("fwd_rows"))) return rc;
         hpfw::launch_fwd_cols(dp->fwd, (hpfw::cf *)h->ws[0], nb, (hpfw::cf *)d_x + c0 * nk, s);
         if ((rc = check_launch("fwd_cols"))) return rc;
@@ -436,7 +474,7 @@ int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
-    if ((rc = ensure_ws(h, dp->hp, nbmax))) return rc;
+    if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);

@@ -8,43 +8,55 @@
 //              Hermitian symmetry, multiplied by T_N[a k2] and written as half spectra.
 //   fwd_cols : the remaining length-n1 DFT, only for the rows k1 that hold consumed bins, as one fma
 //              chain per output over a ascending (only ~10 % of the N/2 bins feed the 121 bands).
+//   pcm_pairs: coalescing pre-pass.  The clip is an [n2][n1] row-major matrix of samples; residue pair
+//              (2p, 2p+1) is a 4-byte column of it.  A workgroup transposes a tile of 64 time steps
+//              through LDS so that fwd_rows reads its pair stream contiguously.
 #include "kernels.h"
 
 namespace hpfw {
 
 extern __shared__ __align__(16) unsigned char smem_raw[];
 
-constexpr int kFwdThreads = 1024;
+constexpr int kPairsTile = 64;
 
-__global__ __launch_bounds__(kFwdThreads) void fwd_rows_kernel(FwdPlanDev fp, const int16_t *__restrict__ pcm,
+__global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n2, const int16_t *__restrict__ pcm,
+                                                        i16x2 *__restrict__ pairs)
+{
+    int16_t *tile = reinterpret_cast<int16_t *>(smem_raw); // [kPairsTile][n1]
+    const int tid = threadIdx.x;
+    const int clip = blockIdx.y;
+    const int t0 = blockIdx.x * kPairsTile;
+    const int nt = min(kPairsTile, n2 - t0);
+    const int np = (n1 + 1) / 2;
+    const int16_t *src = pcm + (int64_t)clip * n + (int64_t)t0 * n1;
+    for (int i = tid; i < nt * n1; i += 256) tile[i] = src[i];
+    __syncthreads();
+    i16x2 *dst = pairs + (int64_t)clip * np * n2 + t0;
+    for (int i = tid; i < np * kPairsTile; i += 256) {
+        const int p = i / kPairsTile, tt = i - p * kPairsTile;
+        if (tt < nt) {
+            i16x2 v;
+            v.x = tile[tt * n1 + 2 * p];
+            v.y = (2 * p + 1 < n1) ? tile[tt * n1 + 2 * p + 1] : (short)0;
+            dst[(int64_t)p * n2 + tt] = v;
+        }
+    }
+}
+
+constexpr int kFwdThreads = 768;
+
+// one workgroup = one residue pair of one clip; the body (fft_rows.h) is shared with tests/emu
+__global__ __launch_bounds__(kFwdThreads) void fwd_rows_kernel(RowsArgs a, const i16x2 *__restrict__ pairs,
                                                                cf *__restrict__ yp)
 {
-    cf *z = reinterpret_cast<cf *>(smem_raw);
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int a = 2 * blockIdx.x;
+    cf *lds = reinterpret_cast<cf *>(smem_raw);
+    const int p = blockIdx.x;
     const int clip = blockIdx.y;
-    const bool has_b = (a + 1 < fp.n1);
-    const int16_t *x = pcm + (int64_t)clip * fp.n;
-    for (int t = tid; t < fp.n2; t += nt) {
-        const int64_t idx = a + (int64_t)fp.n1 * t;
-        const float re = (float)x[idx] / 32768.0f;
-        const float im = has_b ? (float)x[idx + 1] / 32768.0f : 0.0f;
-        z[t] = {re, im};
-    }
-    __syncthreads();
-    lds_fft_dif(z, fp.n2, fp.radix, fp.tw_n2, tid, nt);
-    cf *ya = yp + ((int64_t)clip * fp.n1 + a) * fp.h;
-    cf *yb = ya + fp.h;
-    const cf *twa = fp.tw_big + (int64_t)a * fp.h;
-    const cf *twb = twa + fp.h;
-    for (int k2 = tid; k2 < fp.h; k2 += nt) {
-        const cf zk = z[fp.pos_n2[k2]];
-        const cf zm = z[fp.pos_n2[k2 == 0 ? 0 : fp.n2 - k2]];
-        const cf va = {0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
-        const cf vb = {0.5f * (zk.i + zm.i), 0.5f * (zm.r - zk.r)};
-        ya[k2] = c_mul(va, twa[k2]);
-        if (has_b) yb[k2] = c_mul(vb, twb[k2]);
-    }
+    const int np = (a.n1 + 1) / 2;
+    const int a0 = 2 * p;
+    cf *ya = yp + ((int64_t)clip * a.n1 + a0) * a.h;
+    cf *yb = (a0 + 1 < a.n1) ? ya + a.h : nullptr;
+    rows_body(lds, a, (int)blockDim.x, pairs + ((int64_t)clip * np + p) * a.n2, a0, ya, yb);
 }
 
 constexpr int kColsThreads = 256;
@@ -112,16 +124,24 @@ __global__ __launch_bounds__(kColsThreads) void fwd_cols_kernel(FwdPlanDev fp, c
 
 static int g_rows_lds_set = 0;
 
-void launch_fwd_rows(const FwdPlanDev &fp, const int16_t *d_pcm, int n_clips, cf *d_yp, hipStream_t s)
+void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s)
 {
-    const size_t lds = (size_t)fp.n2 * sizeof(cf);
+    dim3 grid((n2 + kPairsTile - 1) / kPairsTile, n_clips);
+    hipLaunchKernelGGL(pcm_pairs_kernel, grid, dim3(256), (size_t)kPairsTile * n1 * sizeof(int16_t), s, n, n1, n2,
+                       d_pcm, d_pairs);
+}
+
+size_t fwd_rows_lds_bytes(const RowsArgs &a) { return ((size_t)a.n2 + (a.quad ? a.n2 / 4 : 0)) * sizeof(cf); }
+
+void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, cf *d_yp, hipStream_t s)
+{
     if (!g_rows_lds_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_rows_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         g_rows_lds_set = 1;
     }
-    dim3 grid((fp.n1 + 1) / 2, n_clips);
-    hipLaunchKernelGGL(fwd_rows_kernel, grid, dim3(kFwdThreads), lds, s, fp, d_pcm, d_yp);
+    dim3 grid((a.n1 + 1) / 2, n_clips);
+    hipLaunchKernelGGL(fwd_rows_kernel, grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, d_pairs, d_yp);
 }
 
 void launch_fwd_cols(const FwdPlanDev &fp, const cf *d_yp, int n_clips, cf *d_x, hipStream_t s)

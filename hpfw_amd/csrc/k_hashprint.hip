@@ -6,8 +6,8 @@
 // (hashprint_handle.h:115-142).
 //
 // project_kernel: implicit im2col.  frames[b*20 + t, n] = S[b, n + t] is never materialised; the
-// workgroup keeps an [11 bins][256 + 19 columns] slab of S and the matching 220-deep slab of the
-// filters in LDS and feeds v_mfma_f32_32x32x2_f32.  The accumulation over k = b*20 + t is one
+// workgroup keeps an [11 bins][256 + 19 columns] slab of S in LDS, streams the filter operand from
+// L2 into registers and feeds v_mfma_f32_32x32x2_f32.  The accumulation over k = b*20 + t is one
 // chain per output in ascending k (the MFMA adds k, k+1 in order and chains across instructions),
 // which is bit for bit the fmaf chain of DESIGN.md S9.
 #include "kernels.h"
@@ -23,15 +23,17 @@ constexpr int kPjTileN = 256;              // frames per workgroup
 constexpr int kPjBinsPerChunk = 11;        // 121 = 11 * 11
 constexpr int kPjCols = kPjTileN + kCtx - 1;   // 275 spectrogram columns per slab row
 constexpr int kPjRow = 276;                // LDS row stride in floats
-constexpr int kPjKp = kPjBinsPerChunk * kCtx / 2; // 110 k-pairs per chunk
-constexpr size_t kPjLds = (size_t)kPjBinsPerChunk * kPjRow * 4 + (size_t)kPjKp * 64 * 8;
+constexpr int kPjTp = kCtx / 2;            // 10 MFMA k-steps (k, k+1) per bin
 
+// LDS holds only the [11 bins][275 columns] slab of S (12 KB, so several workgroups share a CU and
+// one's staging hides behind another's MFMAs).  The filter operand is streamed straight from L2 into
+// registers, one bin (10 k-steps, 80 B per lane) ahead of its use: fpack is laid out
+// [bin][lane][k-step][filter tile] so that a wave reads 5 KB contiguously per bin.
 __global__ __launch_bounds__(kPjThreads) void project_kernel(const float *__restrict__ fpack,
                                                              const float *__restrict__ sdb, int c, int nf,
                                                              float *__restrict__ proj)
 {
-    float *s_tile = reinterpret_cast<float *>(smem_raw);
-    float2 *f_tile = reinterpret_cast<float2 *>(smem_raw + (size_t)kPjBinsPerChunk * kPjRow * 4);
+    __shared__ float s_tile[kPjBinsPerChunk * kPjRow];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5;
@@ -40,34 +42,59 @@ __global__ __launch_bounds__(kPjThreads) void project_kernel(const float *__rest
     const float *S = sdb + (int64_t)clip * kBins * c;
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0}; // [filter tile][frame tile]
     const int nl = wave * 64 + (lane & 31);
+    const float4 *ap = reinterpret_cast<const float4 *>(fpack) + lane * (kPjTp / 2);
+    float4 a_cur[kPjTp / 2], a_nxt[kPjTp / 2];
+#pragma unroll
+    for (int i = 0; i < kPjTp / 2; ++i) a_cur[i] = ap[i];
 
-    for (int chunk = 0; chunk < kBins / kPjBinsPerChunk; ++chunk) {
-        __syncthreads();
-        for (int i = tid; i < kPjBinsPerChunk * kPjCols; i += kPjThreads) {
+    // S slab staging split in two (load to registers early, write to LDS late): the loads of chunk
+    // i + 1 are in flight while chunk i feeds the MFMAs, so HBM latency never stalls the matrix pipe
+    constexpr int kStage = (kPjBinsPerChunk * kPjCols + kPjThreads - 1) / kPjThreads; // 12 words per thread
+    float stage[kStage];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) {
+            const int i = tid + j * kPjThreads;
             const int b = i / kPjCols;
             const int col = i - b * kPjCols;
             const int gc = n0 + col;
-            s_tile[b * kPjRow + col] = gc < c ? S[(int64_t)(chunk * kPjBinsPerChunk + b) * c + gc] : 0.0f;
+            stage[j] = (i < kPjBinsPerChunk * kPjCols && gc < c)
+                           ? S[(int64_t)(chunk * kPjBinsPerChunk + b) * c + gc] : 0.0f;
         }
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(fpack + (size_t)chunk * kPjKp * 128);
-            float4 *dst = reinterpret_cast<float4 *>(f_tile);
-            for (int i = tid; i < kPjKp * 32; i += kPjThreads) dst[i] = src[i];
+    };
+    stage_load(0);
+    for (int chunk = 0; chunk < kBins / kPjBinsPerChunk; ++chunk) {
+        __syncthreads(); // every wave is done reading the previous slab
+#pragma unroll
+        for (int j = 0; j < kStage; ++j) {
+            const int i = tid + j * kPjThreads;
+            const int b = i / kPjCols;
+            if (i < kPjBinsPerChunk * kPjCols) s_tile[b * kPjRow + (i - b * kPjCols)] = stage[j];
         }
         __syncthreads();
+        if (chunk + 1 < kBins / kPjBinsPerChunk) stage_load(chunk + 1);
+        if (n0 + wave * 64 >= nf) continue; // a wave whose 64 frames lie past the clip only helps staging
+#pragma unroll 1
         for (int b = 0; b < kPjBinsPerChunk; ++b) {
-            const float *srow = s_tile + b * kPjRow + nl + kh;
-            const float2 *frow = f_tile + (b * (kCtx / 2)) * 64 + lane;
+            const int bin = chunk * kPjBinsPerChunk + b;
+            const int nbin = bin + 1 < kBins ? bin + 1 : bin; // the last prefetch re-reads the last bin
 #pragma unroll
-            for (int tp = 0; tp < kCtx / 2; ++tp) {
-                const float2 av = frow[tp * 64];
+            for (int i = 0; i < kPjTp / 2; ++i) a_nxt[i] = ap[(size_t)nbin * 64 * (kPjTp / 2) + i];
+            const float *srow = s_tile + b * kPjRow + nl + kh;
+#pragma unroll
+            for (int tp = 0; tp < kPjTp; ++tp) {
+                const float4 a4 = a_cur[tp >> 1];
+                const float a0 = (tp & 1) ? a4.z : a4.x; // filter tile 0
+                const float a1 = (tp & 1) ? a4.w : a4.y; // filter tile 1
                 const float b0 = srow[2 * tp];
                 const float b1 = srow[2 * tp + 32];
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc11, 0, 0, 0);
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < kPjTp / 2; ++i) a_cur[i] = a_nxt[i];
         }
     }
     // D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -106,28 +133,23 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *__restrict__ pro
 
 void pack_filters_for_mfma(const float *f, float *fpack)
 {
-    // operand image of v_mfma_f32_32x32x2_f32: lane l supplies A[row = l & 31][k = l >> 5]
-    for (int kp = 0; kp < kFrame / 2; ++kp)
+    // operand image of v_mfma_f32_32x32x2_f32: lane l supplies A[row = l & 31][k = l >> 5];
+    // order [bin][lane][k-step][filter tile], k = bin * 20 + 2 * step + (l >> 5)
+    for (int bin = 0; bin < kBins; ++bin)
         for (int l = 0; l < 64; ++l)
-            for (int tile = 0; tile < 2; ++tile) {
-                const int r = tile * 32 + (l & 31);
-                const int k = 2 * kp + (l >> 5);
-                fpack[((size_t)kp * 64 + l) * 2 + tile] = f[(size_t)r + 64 * (size_t)k];
-            }
+            for (int tp = 0; tp < kPjTp; ++tp)
+                for (int tile = 0; tile < 2; ++tile) {
+                    const int r = tile * 32 + (l & 31);
+                    const int k = bin * kCtx + 2 * tp + (l >> 5);
+                    fpack[(((size_t)bin * 64 + l) * kPjTp + tp) * 2 + tile] = f[(size_t)r + 64 * (size_t)k];
+                }
 }
-
-static int g_pj_lds_set = 0;
 
 void launch_project(const float *d_fpack, const float *d_db, int n_clips, int c, float *d_proj, hipStream_t s)
 {
-    if (!g_pj_lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(project_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        g_pj_lds_set = 1;
-    }
     const int nf = c - (kCtx - 1);
     dim3 grid((nf + kPjTileN - 1) / kPjTileN, n_clips);
-    hipLaunchKernelGGL(project_kernel, grid, dim3(kPjThreads), kPjLds, s, d_fpack, d_db, c, nf, d_proj);
+    hipLaunchKernelGGL(project_kernel, grid, dim3(kPjThreads), 0, s, d_fpack, d_db, c, nf, d_proj);
 }
 
 void launch_pack(const float *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s)

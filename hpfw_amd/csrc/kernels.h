@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "device_math.h"
+#include "fft_rows.h"
 
 namespace hpfw {
 
@@ -47,8 +48,11 @@ struct CqPlanDev {
     const cf *g;        // window * chirp / (M P)       [sum lg]
 };
 
-// a1 + forward FFT of residue pairs: pcm [n_clips][n] -> yp [n_clips][n1][h] (twiddled half spectra)
-void launch_fwd_rows(const FwdPlanDev &fp, const int16_t *d_pcm, int n_clips, cf *d_yp, hipStream_t s);
+// coalescing pre-pass: pcm [n_clips][n2][n1] -> pairs [n_clips][(n1+1)/2][n2] (two residues per word)
+void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s);
+// a1 + forward FFT of residue pairs: pairs -> yp [n_clips][n1][h] (twiddled half spectra)
+void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, cf *d_yp, hipStream_t s);
+size_t fwd_rows_lds_bytes(const RowsArgs &a);
 // length-n1 DFT across residues as fma chains: yp -> x [n_clips][kmax-kmin]
 void launch_fwd_cols(const FwdPlanDev &fp, const cf *d_yp, int n_clips, cf *d_x, hipStream_t s);
 // band chirp-z transforms: x -> mag [n_clips][121][c]; also atomically maxes d_magmax[clip] (bits)

@@ -189,9 +189,16 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
     }
     const int64_t n2 = n / n1;
     std::vector<int> tmp;
-    if (!make_radix_list(n2, p.radix) || !make_radix_list(n1, tmp)) {
+    std::vector<int> desc;
+    if (!make_radix_list(n2, desc) || !make_radix_list(n1, tmp)) {
         why = "clip length has a prime factor other than 2, 3, 5, 7";
         return false;
+    }
+    // pass order of the row transform: the descending list taken alternately from its front and its
+    // back ([7,7,5,5,4,3] -> [7,3,7,4,5,5]) so that neighbouring passes have small products
+    for (size_t lo = 0, hi = desc.size(); lo < hi;) {
+        p.radix.push_back(desc[lo++]);
+        if (lo < hi) p.radix.push_back(desc[--hi]);
     }
     if (n1 > 8192) {
         why = "clip too long";
@@ -204,6 +211,32 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
     p.k1hi = (int)((kmax - 1) / n2);
     p.tw_n2 = twiddle_table(n2);
     p.tw_n1 = twiddle_table(n1);
+    // fuse consecutive passes in pairs of at most 36 points (kernel-side scheduling, same arithmetic;
+    // a 49-point pair spills registers)
+    for (size_t i = 0; i < p.radix.size();) {
+        if (i + 1 < p.radix.size() && p.radix[i] * p.radix[i + 1] <= 36) {
+            p.groups.push_back({p.radix[i], p.radix[i + 1]});
+            i += 2;
+        } else {
+            p.groups.push_back({p.radix[i], 1});
+            i += 1;
+        }
+    }
+    if (p.groups.size() > 12) {
+        why = "too many radix passes";
+        return false;
+    }
+    // quadrant rule used by the row kernel: T[m + q n2/4] = (-i)^q T[m]; keep it only if it is exact
+    p.rows_quad = (n2 % 4 == 0) ? 1 : 0;
+    for (int64_t m = 0; p.rows_quad && m < n2; ++m) {
+        const int64_t nq = n2 / 4, q = m / nq;
+        const HostCf e = p.tw_n2[(size_t)(m - q * nq)];
+        float re = (q & 1) ? e.i : e.r, im = (q & 1) ? e.r : e.i;
+        if (q == 2 || q == 3) re = -re;
+        if (q == 1 || q == 2) im = -im;
+        const HostCf want = p.tw_n2[(size_t)m];
+        if (std::memcmp(&re, &want.r, 4) != 0 || std::memcmp(&im, &want.i, 4) != 0) p.rows_quad = 0;
+    }
     p.tw_big.resize((size_t)n1 * p.h);
     for (int64_t a = 0; a < n1; ++a)
         for (int64_t k2 = 0; k2 < p.h; ++k2) p.tw_big[(size_t)(a * p.h + k2)] = twiddle_f(a * k2, n);

@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace hpfw {
@@ -26,6 +27,8 @@ struct HostPlan {
     int kmin = 0, kmax = 0, k1lo = 0, k1hi = 0;
     int m = 0, c = 0, n_frames = 0, n_hp = 0;
     std::vector<int> radix;                 // passes of the length-n2 FFT
+    std::vector<std::pair<int, int>> groups; // the same passes, fused in pairs (second = 1: single pass)
+    int rows_quad = 0;                      // 4 | n2: T_n2 follows exactly from its first quarter
     std::vector<HostCf> tw_n2, tw_n1, tw_big;
     std::vector<int> pos_n2;
     int start[121], lg[121], psize[121];

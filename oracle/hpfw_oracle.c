@@ -278,6 +278,21 @@ static int make_radix_list(int64_t n, int32_t *radix)
     return nr;
 }
 
+/* pass order of the length-n2 row transform: the descending list taken alternately from its front
+ * and its back ([7,7,5,5,4,3] -> [7,3,7,4,5,5]), so that neighbouring passes have small products */
+static int make_rows_radix_list(int64_t n, int32_t *radix)
+{
+    int32_t d[HPFW_O_MAXRADIX];
+    int nr = make_radix_list(n, d);
+    if (nr < 0) return nr;
+    int lo = 0, hi = nr - 1, w = 0;
+    while (lo <= hi) {
+        radix[w++] = d[lo++];
+        if (lo <= hi) radix[w++] = d[hi--];
+    }
+    return nr;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* plan                                                                                        */
 /* ------------------------------------------------------------------------------------------ */
@@ -455,7 +470,7 @@ hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n)
     p->info.n1 = n1;
     p->info.n2 = n2;
     p->info.h = n2 / 2 + 1;
-    p->info.n_radix = make_radix_list(n2, p->info.radix);
+    p->info.n_radix = make_rows_radix_list(n2, p->info.radix);
     if (p->info.n_radix < 0 || make_bands(p) != 0) {
         free(p);
         return NULL;
