@@ -61,7 +61,7 @@ hpfw::RadixList to_radix(const std::vector<int> &r)
 
 struct DevPlan {
     hpfw::HostPlan hp;
-    hpfw::FwdPlanDev fwd;
+    hpfw::ColsArgs cols;
     hpfw::RowsArgs rows;
     hpfw::CqPlanDev cq;
     std::vector<hpfw::CqClassDev> cls;
@@ -174,39 +174,44 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n) + ": " + why);
     const hpfw::HostPlan &p = dp->hp;
     using hpfw::cf;
-    hpfw::FwdPlanDev &f = dp->fwd;
-    f.n = p.n;
-    f.n1 = p.n1;
-    f.n2 = p.n2;
-    f.h = p.h;
-    f.kmin = p.kmin;
-    f.kmax = p.kmax;
-    f.k1lo = p.k1lo;
-    f.k1hi = p.k1hi;
-    f.radix = to_radix(p.radix);
     int rc;
     static_assert(sizeof(hpfw::HostCf) == sizeof(cf), "complex layout");
-    if ((rc = upload(p.tw_n2, reinterpret_cast<const hpfw::HostCf **>(&f.tw_n2), dp->owned))) return rc;
-    if ((rc = upload(p.tw_n1, reinterpret_cast<const hpfw::HostCf **>(&f.tw_n1), dp->owned))) return rc;
-    if ((rc = upload(p.tw_big, reinterpret_cast<const hpfw::HostCf **>(&f.tw_big), dp->owned))) return rc;
-    if ((rc = upload(p.pos_n2, &f.pos_n2, dp->owned))) return rc;
     hpfw::RowsArgs &ra = dp->rows;
     std::memset(&ra, 0, sizeof(ra));
     ra.n1 = p.n1;
     ra.n2 = p.n2;
     ra.h = p.h;
-    ra.quad = p.rows_quad;
+    ra.hpad = (p.h + 31) / 32 * 32;
     ra.groups.n = (int)p.groups.size();
     for (size_t g = 0; g < p.groups.size(); ++g) {
         ra.groups.r1[g] = p.groups[g].first;
         ra.groups.r2[g] = p.groups[g].second;
+        ra.groups.tw_off[g] = p.rows_gtw_off[g];
     }
-    ra.tw_n2 = f.tw_n2;
-    ra.tw_big = f.tw_big;
-    ra.pos_n2 = f.pos_n2;
+    if ((rc = upload(p.rows_gtw, reinterpret_cast<const hpfw::HostCf **>(&ra.gtw), dp->owned))) return rc;
+    if ((rc = upload(p.tw_big, reinterpret_cast<const hpfw::HostCf **>(&ra.tw_big), dp->owned))) return rc;
+    if ((rc = upload(p.pos_n2, &ra.pos_n2, dp->owned))) return rc;
     if (hpfw::fwd_rows_lds_bytes(ra) > 160 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
-    if (std::getenv("HPFW_DEBUG_ROWS_NOGROUPS")) ra.groups.n = 0; // timing ablation only (wrong results)
+    if (std::getenv("HPFW_DEBUG_ROWS_NOGROUPS")) ra.groups.n = 0; // timing ablations only (wrong results)
     if (std::getenv("HPFW_DEBUG_ROWS_NOEPI")) ra.h = 0;
+    // column DFT: coefficient image for the MFMA A operand
+    hpfw::ColsArgs &ca = dp->cols;
+    std::memset(&ca, 0, sizeof(ca));
+    ca.n1 = p.n1;
+    ca.n2 = p.n2;
+    ca.h = p.h;
+    ca.hpad = ra.hpad;
+    ca.kmin = p.kmin;
+    ca.kmax = p.kmax;
+    ca.k1lo = p.k1lo;
+    ca.k1n = p.k1hi - p.k1lo + 1;
+    ca.n_tiles = (2 * ca.k1n + 15) / 16;
+    {
+        std::vector<float> apack((size_t)p.n1 * ca.n_tiles * 64);
+        hpfw::pack_cols_coefficients(p.n1, ca.k1lo, ca.k1n, reinterpret_cast<const float *>(p.tw_n1.data()),
+                                     ca.n_tiles, apack.data());
+        if ((rc = upload(apack, &ca.apack, dp->owned))) return rc;
+    }
     hpfw::CqPlanDev &c = dp->cq;
     c.kmin = p.kmin;
     c.nk = p.kmax - p.kmin;
@@ -236,7 +241,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
 // nb: clips per front-end pass (large intermediates); ns: clips per back-end pass (S and P only)
 int ensure_ws(hpfw_gpu *h, const hpfw::HostPlan &p, int nb, int ns)
 {
-    const size_t need[6] = {(size_t)nb * p.n1 * p.h * 8, (size_t)nb * (p.kmax - p.kmin) * 8,
+    const size_t need[6] = {(size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4, (size_t)nb * (p.kmax - p.kmin) * 8,
                             (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4,
                             (size_t)ns * 4, (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4};
     for (int i = 0; i < 6; ++i) {
@@ -251,7 +256,7 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
 {
     using hpfw::cf;
     const hpfw::HostPlan &p = dp->hp;
-    cf *yp = (cf *)h->ws[0];
+    float *yp = (float *)h->ws[0];
     cf *x = (cf *)h->ws[1];
     float *mag = (float *)h->ws[2] + (size_t)slot * 121 * p.c;
     unsigned *mm = (unsigned *)h->ws[4] + slot;
@@ -265,7 +270,7 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
     if ((rc = check_launch("fwd_rows"))) return rc;
     {
         Timed t(h, K_COLS, s);
-        hpfw::launch_fwd_cols(dp->fwd, yp, nb, x, s);
+        hpfw::launch_fwd_cols(dp->cols, yp, nb, x, s);
     }
     if ((rc = check_launch("fwd_cols"))) return rc;
     for (const hpfw::CqClassDev &cd : dp->cls) {
@@ -456,9 +461,9 @@ int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
         hpfw::launch_pcm_pairs(dp->hp.n, dp->hp.n1, dp->hp.n2, d_pcm + c0 * n_samples, nb, (hpfw::i16x2 *)h->ws[5], s);
-        hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, (hpfw::cf *)h->ws[0], s);
+        hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, (float *)h->ws[0], s);
         if ((rc = check_launch("fwd_rows"))) return rc;
-        hpfw::launch_fwd_cols(dp->fwd, (hpfw::cf *)h->ws[0], nb, (hpfw::cf *)d_x + c0 * nk, s);
+        hpfw::launch_fwd_cols(dp->cols, (const float *)h->ws[0], nb, (hpfw::cf *)d_x + c0 * nk, s);
         if ((rc = check_launch("fwd_cols"))) return rc;
     }
     return 0;

@@ -1,8 +1,10 @@
 // fft_rows.h -- the length-n2 mixed-radix FFT of one pair of residue sequences, held in LDS
 // (DESIGN.md S4, S6).  Same arithmetic as the specification's radix-7/5/4/3/2 passes; two
-// consecutive passes are fused in registers (up to 49 points per thread and LDS round trip) and,
-// when 4 | n2, the twiddles T_n2[m] come from the first quarter of the table kept in LDS
-// (T[m + n2/4] = -i T[m] exactly, by the table's construction).
+// consecutive passes are fused in registers (up to 36 points per thread and LDS round trip).
+// The twiddles of a fused group are read from a per-butterfly table in global memory (L2 resident,
+// built by the host from T_n2: entry e of butterfly b at [e][b], so a wave reads 512 contiguous
+// bytes per entry): no index arithmetic and no LDS traffic for twiddles.  n2 <= 6826 keeps the data
+// under 55 KB of LDS, so several workgroups share a CU and one's loads hide behind another's passes.
 #pragma once
 #include "device_math.h"
 
@@ -19,42 +21,28 @@ struct RowGroups {
     int n;                    // number of fused groups
     int r1[kRowsMaxGroups];   // first radix of the group
     int r2[kRowsMaxGroups];   // second radix, or 1
+    int tw_off[kRowsMaxGroups]; // offset of the group's twiddle table in gtw (complex elements)
 };
 
 struct RowsArgs {
     int n1, n2, h;            // N = n1 * n2, h = n2 / 2 + 1
-    int quad;                 // 1: quadrant twiddle table in LDS (4 | n2), 0: global table
+    int hpad;                 // row stride (floats) of the planar output, a multiple of 32
     RowGroups groups;
-    const cf *tw_n2;          // T_{n2} (global)
+    const cf *gtw;            // per-butterfly twiddles of every group (see group_twiddle_count)
     const cf *tw_big;         // T_N[a * k2]  [n1][h]
     const int *pos_n2;        // digit-reversed position of output k2
 };
 
-// T_n2[m], 0 <= m < n2
-template <class Lds>
-HPFW_DEVICE cf rows_tw(const Lds &lds, const RowsArgs &a, int m)
-{
-    if (a.quad) {
-        const int nq = a.n2 >> 2;
-        const int q = (m >= nq) + (m >= 2 * nq) + (m >= 3 * nq);
-        const cf e = lds[a.n2 + (m - q * nq)];
-        // (-i)^q * e
-        const float re = (q & 1) ? e.i : e.r;
-        const float im = (q & 1) ? e.r : e.i;
-        const bool neg_re = (q == 2) || (q == 3);
-        const bool neg_im = (q == 1) || (q == 2);
-        return {neg_re ? -re : re, neg_im ? -im : im};
-    }
-    return a.tw_n2[m];
-}
+// entries per butterfly of a fused (R1, R2) group: stage 1 has (R1 - 1) R2, stage 2 has R2 - 1;
+// entry q2 (R1 - 1) + (s - 1) = T_n[ts1 (j0 + q2 m2) s], entry (R1 - 1) R2 + (s2 - 1) = T_n[ts2 j0 s2]
+constexpr int group_twiddle_count(int r1, int r2) { return (r1 - 1) * r2 + (r2 - 1); }
 
 // one fused group of the forward DIF at sub-length len: radix R1, then radix R2 (or 1)
 template <int R1, int R2, class Lds>
-HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, int len, int tid, int nthreads)
+HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int len, int tid, int nthreads)
 {
     const int n = a.n2;
     const int m1 = len / R1, m2 = m1 / R2;
-    const int ts1 = n / len, ts2 = n / m1;
     const int nb = n / (R1 * R2);
     const float inv_m2 = 1.0f / (float)m2;
     for (int b = tid; b < nb; b += nthreads) {
@@ -63,17 +51,17 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, int len, int tid, int n
         if ((blk + 1) * m2 <= b) ++blk;
         const int j0 = b - blk * m2;
         const int base = blk * len + j0;
+        const cf *__restrict__ tb = gt + b;
         cf e[R1][R2];
 #pragma unroll
         for (int q2 = 0; q2 < R2; ++q2) {
-            const int j = j0 + q2 * m2;
             cf u[R1];
 #pragma unroll
             for (int q = 0; q < R1; ++q) u[q] = lds[base + q2 * m2 + q * m1];
             Dft<R1>::run(u);
             e[0][q2] = u[0];
 #pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], rows_tw(lds, a, ts1 * j * s));
+            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tb[(q2 * (R1 - 1) + (s - 1)) * nb]);
         }
 #pragma unroll
         for (int s = 0; s < R1; ++s) {
@@ -84,7 +72,8 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, int len, int tid, int n
                 Dft<R2>::run(v);
                 lds[base + s * m1] = v[0];
 #pragma unroll
-                for (int s2 = 1; s2 < R2; ++s2) lds[base + s * m1 + s2 * m2] = c_mul(v[s2], rows_tw(lds, a, ts2 * j0 * s2));
+                for (int s2 = 1; s2 < R2; ++s2)
+                    lds[base + s * m1 + s2 * m2] = c_mul(v[s2], tb[((R1 - 1) * R2 + (s2 - 1)) * nb]);
             } else {
                 lds[base + s * m1] = e[s][0];
             }
@@ -93,68 +82,152 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, int len, int tid, int n
 }
 
 template <int R1, class Lds>
-HPFW_DEVICE void rows_group_r2(Lds &lds, const RowsArgs &a, int len, int r2, int tid, int nthreads)
+HPFW_DEVICE void rows_group_r2(Lds &lds, const RowsArgs &a, const cf *gt, int len, int r2, int tid, int nthreads)
 {
     // the plan fuses two passes only when their product is <= kRowsMaxPoints (register budget)
     switch (r2) {
-    case 1: rows_group<R1, 1>(lds, a, len, tid, nthreads); break;
-    case 2: rows_group<R1, 2>(lds, a, len, tid, nthreads); break;
-    case 3: rows_group<R1, 3>(lds, a, len, tid, nthreads); break;
-    case 4: rows_group<R1, 4>(lds, a, len, tid, nthreads); break;
+    case 1: rows_group<R1, 1>(lds, a, gt, len, tid, nthreads); break;
+    case 2: rows_group<R1, 2>(lds, a, gt, len, tid, nthreads); break;
+    case 3: rows_group<R1, 3>(lds, a, gt, len, tid, nthreads); break;
+    case 4: rows_group<R1, 4>(lds, a, gt, len, tid, nthreads); break;
     case 5:
-        if constexpr (R1 * 5 <= kRowsMaxPoints) rows_group<R1, 5>(lds, a, len, tid, nthreads);
+        if constexpr (R1 * 5 <= kRowsMaxPoints) rows_group<R1, 5>(lds, a, gt, len, tid, nthreads);
         break;
     default:
-        if constexpr (R1 * 7 <= kRowsMaxPoints) rows_group<R1, 7>(lds, a, len, tid, nthreads);
+        if constexpr (R1 * 7 <= kRowsMaxPoints) rows_group<R1, 7>(lds, a, gt, len, tid, nthreads);
         break;
     }
 }
 
+// The group sequence either comes from the plan at run time (any 7-smooth n2) ...
+struct RuntimeGroups {
+    template <class Lds>
+    HPFW_DEVICE_STATIC void run(Lds &lds, const RowsArgs &a, int nthreads)
+    {
+        int len = a.n2;
+        for (int g = 0; g < a.groups.n; ++g) {
+            const int r1 = a.groups.r1[g], r2 = a.groups.r2[g];
+            const cf *gt = a.gtw + a.groups.tw_off[g];
+            HPFW_FOR_THREADS(tid, nthreads)
+            {
+                switch (r1) {
+                case 2: rows_group_r2<2>(lds, a, gt, len, r2, tid, nthreads); break;
+                case 3: rows_group_r2<3>(lds, a, gt, len, r2, tid, nthreads); break;
+                case 4: rows_group_r2<4>(lds, a, gt, len, r2, tid, nthreads); break;
+                case 5: rows_group_r2<5>(lds, a, gt, len, r2, tid, nthreads); break;
+                default: rows_group_r2<7>(lds, a, gt, len, r2, tid, nthreads); break;
+                }
+            }
+            HPFW_BARRIER();
+            len /= r1 * r2;
+        }
+    }
+};
+
+// ... or is fixed at compile time: the kernel then contains exactly these butterflies and its
+// register allocation is theirs (the run-time dispatcher is sized by its largest case).
+template <int... RS>
+struct StaticGroups;
+
+template <>
+struct StaticGroups<> {
+    template <class Lds>
+    HPFW_DEVICE_STATIC void run_from(Lds &, const RowsArgs &, int, int, int) {}
+    static bool matches(const RowGroups &, int g, int n) { return g == n; }
+};
+
+template <int R1, int R2, int... Rest>
+struct StaticGroups<R1, R2, Rest...> {
+    template <class Lds>
+    HPFW_DEVICE_STATIC void run_from(Lds &lds, const RowsArgs &a, int nthreads, int len, int g)
+    {
+        const cf *gt = a.gtw + a.groups.tw_off[g];
+        HPFW_FOR_THREADS(tid, nthreads) { rows_group<R1, R2>(lds, a, gt, len, tid, nthreads); }
+        HPFW_BARRIER();
+        StaticGroups<Rest...>::run_from(lds, a, nthreads, len / (R1 * R2), g + 1);
+    }
+    template <class Lds>
+    HPFW_DEVICE_STATIC void run(Lds &lds, const RowsArgs &a, int nthreads)
+    {
+        run_from(lds, a, nthreads, a.n2, 0);
+    }
+    static bool matches(const RowGroups &g, int i, int n)
+    {
+        return i < n && g.r1[i] == R1 && g.r2[i] == R2 && StaticGroups<Rest...>::matches(g, i + 1, n);
+    }
+};
+
+// n2 = 6300 = 7 3 5 3 5 4: every clip length that is a multiple of 1/7 s at 44.1 kHz up to 50 s
+using Groups6300 = StaticGroups<7, 3, 5, 3, 5, 4>;
+
 // The whole row transform of residues (a0, a0 + 1): pairs[t] = (x[a0 + n1 t], x[a0 + 1 + n1 t]) as
-// two int16 (second is 0 when a0 + 1 == n1).  lds: n2 (+ n2/4 when quad) complex slots.
-// ya / yb: rows a0 and a0 + 1 of Y' (yb may be null).
-template <class Lds>
+// two int16 (second is 0 when a0 + 1 == n1).  lds: n2 complex slots.
+// Output: rows 2 a0 .. 2 a0 + 3 of the planar matrix Y' [2 n1][hpad] (row 2a = Re, 2a + 1 = Im of
+// residue a) -- the B operand of the column-DFT MFMA kernel; ya / yb point at the Re rows of a0 and
+// a0 + 1 (yb may be null).
+template <class Groups, class Lds>
 HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x2 *__restrict__ pairs, int a0,
-                           cf *__restrict__ ya, cf *__restrict__ yb)
+                           float *__restrict__ ya, float *__restrict__ yb)
 {
     const int n2 = a.n2;
     HPFW_FOR_THREADS(tid, nthreads)
     {
-        if (a.quad)
-            for (int i = tid; i < (n2 >> 2); i += nthreads) lds[n2 + i] = a.tw_n2[i];
-        for (int t = tid; t < n2; t += nthreads) {
-            const i16x2 p = pairs[t];
-            lds[t] = {(float)p.x / 32768.0f, (float)p.y / 32768.0f};
+        // loads in batches of kLd so that their latencies overlap
+        constexpr int kLd = 6;
+        for (int t0 = tid; t0 < n2; t0 += kLd * nthreads) {
+            i16x2 p[kLd];
+#pragma unroll
+            for (int e = 0; e < kLd; ++e) {
+                const int t = t0 + e * nthreads;
+                p[e] = pairs[t < n2 ? t : 0];
+            }
+#pragma unroll
+            for (int e = 0; e < kLd; ++e) {
+                const int t = t0 + e * nthreads;
+                if (t < n2) lds[t] = {(float)p[e].x / 32768.0f, (float)p[e].y / 32768.0f};
+            }
         }
     }
     HPFW_BARRIER();
-    int len = n2;
-    for (int g = 0; g < a.groups.n; ++g) {
-        const int r1 = a.groups.r1[g], r2 = a.groups.r2[g];
-        HPFW_FOR_THREADS(tid, nthreads)
-        {
-            switch (r1) {
-            case 2: rows_group_r2<2>(lds, a, len, r2, tid, nthreads); break;
-            case 3: rows_group_r2<3>(lds, a, len, r2, tid, nthreads); break;
-            case 4: rows_group_r2<4>(lds, a, len, r2, tid, nthreads); break;
-            case 5: rows_group_r2<5>(lds, a, len, r2, tid, nthreads); break;
-            default: rows_group_r2<7>(lds, a, len, r2, tid, nthreads); break;
-            }
-        }
-        HPFW_BARRIER();
-        len /= r1 * r2;
-    }
-    const cf *twa = a.tw_big + (int64_t)a0 * a.h;
-    const cf *twb = twa + a.h;
+    Groups::run(lds, a, nthreads);
+    // Hermitian split + twiddle.  The table reads (digit-reversal positions, T_N rows) of kEpi outputs
+    // are issued together before any store, so their latencies overlap instead of adding up.
+    const cf *__restrict__ twa = a.tw_big + (int64_t)a0 * a.h;
+    const cf *__restrict__ twb = yb ? twa + a.h : twa;
+    const int *__restrict__ pos = a.pos_n2;
+    constexpr int kEpi = 4;
     HPFW_FOR_THREADS(tid, nthreads)
     {
-        for (int k2 = tid; k2 < a.h; k2 += nthreads) {
-            const cf zk = lds[a.pos_n2[k2]];
-            const cf zm = lds[a.pos_n2[k2 == 0 ? 0 : n2 - k2]];
-            const cf va = {0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
-            const cf vb = {0.5f * (zk.i + zm.i), 0.5f * (zm.r - zk.r)};
-            ya[k2] = c_mul(va, twa[k2]);
-            if (yb) yb[k2] = c_mul(vb, twb[k2]);
+        for (int k0 = tid; k0 < a.h; k0 += kEpi * nthreads) {
+            int pk[kEpi], pm[kEpi];
+            cf wa[kEpi], wb[kEpi];
+#pragma unroll
+            for (int e = 0; e < kEpi; ++e) {
+                const int k2 = k0 + e * nthreads;
+                const int kk = k2 < a.h ? k2 : 0;
+                pk[e] = pos[kk];
+                pm[e] = pos[kk == 0 ? 0 : n2 - kk];
+                wa[e] = twa[kk];
+                wb[e] = twb[kk];
+            }
+#pragma unroll
+            for (int e = 0; e < kEpi; ++e) {
+                const int k2 = k0 + e * nthreads;
+                if (k2 < a.h) {
+                    const cf zk = lds[pk[e]];
+                    const cf zm = lds[pm[e]];
+                    const cf va = {0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
+                    const cf vb = {0.5f * (zk.i + zm.i), 0.5f * (zm.r - zk.r)};
+                    const cf oa = c_mul(va, wa[e]);
+                    ya[k2] = oa.r;
+                    ya[a.hpad + k2] = oa.i;
+                    if (yb) {
+                        const cf ob = c_mul(vb, wb[e]);
+                        yb[k2] = ob.r;
+                        yb[a.hpad + k2] = ob.i;
+                    }
+                }
+            }
         }
     }
 }

@@ -2,20 +2,24 @@
 //
 // Replaces essentia MonoLoader (PCM16 mono 44.1 kHz case) and the length-N FFT inside essentia
 // NSGConstantQ::compute, called from CQT<>::spectrogram (reference include/hpfw/spectrum/cqt.h:45-52,
-// 66-71).  N = n1 * n2:
-//   fwd_rows : one workgroup per pair of residues (a, a+1) mod n1: the two real sequences
-//              x[a + n1 t], x[a+1 + n1 t] ride one complex length-n2 FFT held in LDS, are split by
-//              Hermitian symmetry, multiplied by T_N[a k2] and written as half spectra.
-//   fwd_cols : the remaining length-n1 DFT, only for the rows k1 that hold consumed bins, as one fma
-//              chain per output over a ascending (only ~10 % of the N/2 bins feed the 121 bands).
+// 66-71).  N = n1 * n2 (n2 = 6300, n1 = 210 for a 30 s clip):
 //   pcm_pairs: coalescing pre-pass.  The clip is an [n2][n1] row-major matrix of samples; residue pair
 //              (2p, 2p+1) is a 4-byte column of it.  A workgroup transposes a tile of 64 time steps
 //              through LDS so that fwd_rows reads its pair stream contiguously.
+//   fwd_rows : one workgroup per pair of residues (a, a+1) mod n1: the two real sequences
+//              x[a + n1 t], x[a+1 + n1 t] ride one complex length-n2 FFT held in LDS (fft_rows.h), are
+//              split by Hermitian symmetry, multiplied by T_N[a k2] and written as planar half spectra.
+//   fwd_cols : the remaining length-n1 DFT, only for the rows k1 that hold consumed bins (about 10 % of
+//              the N/2 bins feed the 121 bands): a dense [4 K1 x 2 n1] . [2 n1 x h] real contraction on
+//              v_mfma_f32_32x32x2_f32.  The MFMA chains its k index in ascending order, which is the
+//              specification's fma chain over residues (Re then Im part of each), bit for bit.
 #include "kernels.h"
 
 namespace hpfw {
 
 extern __shared__ __align__(16) unsigned char smem_raw[];
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kPairsTile = 64;
 
@@ -43,86 +47,96 @@ __global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n
     }
 }
 
-constexpr int kFwdThreads = 768;
+// one workgroup = one residue pair of one clip; the body (fft_rows.h) is shared with tests/emu.
+// 384 threads x <= 168 VGPRs and <= 80 KB of LDS: two workgroups per CU.
+constexpr int kFwdThreads = 384;
 
-// one workgroup = one residue pair of one clip; the body (fft_rows.h) is shared with tests/emu
-__global__ __launch_bounds__(kFwdThreads) void fwd_rows_kernel(RowsArgs a, const i16x2 *__restrict__ pairs,
-                                                               cf *__restrict__ yp)
+template <class Groups>
+__global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, const i16x2 *__restrict__ pairs,
+                                                                  float *__restrict__ yp)
 {
     cf *lds = reinterpret_cast<cf *>(smem_raw);
     const int p = blockIdx.x;
     const int clip = blockIdx.y;
     const int np = (a.n1 + 1) / 2;
     const int a0 = 2 * p;
-    cf *ya = yp + ((int64_t)clip * a.n1 + a0) * a.h;
-    cf *yb = (a0 + 1 < a.n1) ? ya + a.h : nullptr;
-    rows_body(lds, a, (int)blockDim.x, pairs + ((int64_t)clip * np + p) * a.n2, a0, ya, yb);
+    float *ya = yp + ((int64_t)clip * 2 * a.n1 + 2 * a0) * a.hpad;
+    float *yb = (a0 + 1 < a.n1) ? ya + 2 * (int64_t)a.hpad : nullptr;
+    rows_body<Groups>(lds, a, (int)blockDim.x, pairs + ((int64_t)clip * np + p) * a.n2, a0, ya, yb);
 }
 
-constexpr int kColsThreads = 256;
-constexpr int kColsRows = 4; // direct rows per thread (+ the same number of mirrored rows)
+// ---- column DFT on the matrix cores --------------------------------------------------------
+// D[row][k2] = sum_k A[row][k] B[k][k2], k = 2 a + part: B = planar Y' (row 2a = Re, 2a+1 = Im of
+// residue a); A rows come in (Re, Im) pairs per wanted k1, "complex row" cr:
+//   cr <  K1 : k1 = k1lo + cr           -> X[n2 k1 + k2]
+//   cr >= K1 : k1' = n1 - 1 - k1        -> X[n2 k1 + (n2 - k2)] = conj(.)      (X[k] = conj X[N - k])
+// One wave = one tile of 32 columns x NT row tiles of 32 (16 complex rows each); no LDS, no barriers.
+constexpr int kColsStep = 8; // MFMA k-steps (residues) per register block
 
-__global__ __launch_bounds__(kColsThreads) void fwd_cols_kernel(FwdPlanDev fp, const cf *__restrict__ yp,
-                                                                cf *__restrict__ x)
+template <int NT>
+__global__ __launch_bounds__(256) void fwd_cols_kernel(ColsArgs ca, int tile0, const float *__restrict__ yp,
+                                                       cf *__restrict__ x)
 {
-    cf *tw1 = reinterpret_cast<cf *>(smem_raw);
-    const int tid = threadIdx.x;
-    for (int i = tid; i < fp.n1; i += kColsThreads) tw1[i] = fp.tw_n1[i];
-    __syncthreads();
-    const int k2 = blockIdx.x * kColsThreads + tid;
-    const int clip = blockIdx.z;
-    if (k2 >= fp.h) return;
-    const int n1 = fp.n1;
-    int k1d[kColsRows], k1m[kColsRows], id[kColsRows], im[kColsRows];
-    float dr[kColsRows], di[kColsRows], mr[kColsRows], mi[kColsRows];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ctile = blockIdx.x * 4 + wave;
+    const int clip = blockIdx.y;
+    if (ctile * 32 >= ca.h) return;
+    const int hb = lane >> 5, j = lane & 31;
+    const float *bp = yp + (int64_t)clip * 2 * ca.n1 * ca.hpad + (int64_t)hb * ca.hpad + ctile * 32 + j;
+    const float *ap = ca.apack + (size_t)tile0 * 64 + lane; // [a][tile][lane]
+    const size_t astep = (size_t)ca.n_tiles * 64;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < kColsRows; ++i) {
-        int k1 = fp.k1lo + blockIdx.y * kColsRows + i;
-        if (k1 > fp.k1hi) k1 = fp.k1hi; // surplus rows repeat the last one and are not stored
-        k1d[i] = k1;
-        k1m[i] = n1 - 1 - k1;
-        id[i] = 0;
-        im[i] = 0;
-        dr[i] = di[i] = mr[i] = mi[i] = 0.0f;
-    }
-    const cf *y = yp + (int64_t)clip * n1 * fp.h + k2;
-    for (int a = 0; a < n1; ++a) {
-        const cf yv = y[(int64_t)a * fp.h];
+    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+    float a_cur[kColsStep][NT], b_cur[kColsStep], a_nxt[kColsStep][NT], b_nxt[kColsStep];
+    const int nblocks = (ca.n1 + kColsStep - 1) / kColsStep;
+    auto load = [&](int blk, float (&av)[kColsStep][NT], float (&bv)[kColsStep]) {
 #pragma unroll
-        for (int i = 0; i < kColsRows; ++i) {
-            const cf d = tw1[id[i]];
-            dr[i] = __builtin_fmaf(d.r, yv.r, dr[i]);
-            dr[i] = __builtin_fmaf(-d.i, yv.i, dr[i]);
-            di[i] = __builtin_fmaf(d.r, yv.i, di[i]);
-            di[i] = __builtin_fmaf(d.i, yv.r, di[i]);
-            id[i] += k1d[i];
-            if (id[i] >= n1) id[i] -= n1;
-            const cf e = tw1[im[i]];
-            mr[i] = __builtin_fmaf(e.r, yv.r, mr[i]);
-            mr[i] = __builtin_fmaf(-e.i, yv.i, mr[i]);
-            mi[i] = __builtin_fmaf(e.r, yv.i, mi[i]);
-            mi[i] = __builtin_fmaf(e.i, yv.r, mi[i]);
-            im[i] += k1m[i];
-            if (im[i] >= n1) im[i] -= n1;
+        for (int s = 0; s < kColsStep; ++s) {
+            int a = blk * kColsStep + s;
+            const bool ok = a < ca.n1;
+            a = ok ? a : ca.n1 - 1; // the tail re-reads the last residue with zero coefficients
+            bv[s] = bp[(int64_t)2 * a * ca.hpad];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) av[s][t] = ok ? ap[a * astep + (size_t)t * 64] : 0.0f;
+        }
+    };
+    load(0, a_cur, b_cur);
+#pragma unroll 1
+    for (int blk = 0; blk < nblocks; ++blk) {
+        if (blk + 1 < nblocks) load(blk + 1, a_nxt, b_nxt);
+#pragma unroll
+        for (int s = 0; s < kColsStep; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s][t], b_cur[s], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < kColsStep; ++s) {
+            b_cur[s] = b_nxt[s];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a_cur[s][t] = a_nxt[s][t];
         }
     }
-    const int nk = fp.kmax - fp.kmin;
-    cf *xo = x + (int64_t)clip * nk;
-    const bool has_mirror = (k2 >= 1) && (k2 <= fp.n2 - fp.h);
+    // D layout: column = lane & 31; registers (2q, 2q+1) of a tile are rows 2p, 2p+1 with
+    // p = (q & 1) + 4 (q >> 1) + 2 (lane >> 5): the Re / Im rows of complex row tile * 16 + p
+    const int k2 = ctile * 32 + j;
+    cf *xo = x + (int64_t)clip * (ca.kmax - ca.kmin);
 #pragma unroll
-    for (int i = 0; i < kColsRows; ++i) {
-        const int k1 = fp.k1lo + blockIdx.y * kColsRows + i;
-        if (k1 > fp.k1hi) continue;
-        const int64_t kd = (int64_t)fp.n2 * k1 + k2;
-        if (kd >= fp.kmin && kd < fp.kmax) xo[kd - fp.kmin] = {dr[i], di[i]};
-        if (has_mirror) { // X[k] = conj(X[N - k])
-            const int64_t km = (int64_t)fp.n2 * k1 + (fp.n2 - k2);
-            if (km >= fp.kmin && km < fp.kmax) xo[km - fp.kmin] = {mr[i], -mi[i]};
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cr = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
+            const float re = acc[t][2 * q], im = acc[t][2 * q + 1];
+            if (cr < ca.k1n) {
+                const int64_t k = (int64_t)ca.n2 * (ca.k1lo + cr) + k2;
+                if (k2 < ca.h && k >= ca.kmin && k < ca.kmax) xo[k - ca.kmin] = {re, im};
+            } else if (cr < 2 * ca.k1n) {
+                const int64_t k = (int64_t)ca.n2 * (ca.k1lo + cr - ca.k1n) + (ca.n2 - k2);
+                if (k2 >= 1 && k2 <= ca.n2 - ca.h && k >= ca.kmin && k < ca.kmax) xo[k - ca.kmin] = {re, -im};
+            }
         }
     }
 }
-
-static int g_rows_lds_set = 0;
 
 void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s)
 {
@@ -131,24 +145,61 @@ void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_cli
                        d_pcm, d_pairs);
 }
 
-size_t fwd_rows_lds_bytes(const RowsArgs &a) { return ((size_t)a.n2 + (a.quad ? a.n2 / 4 : 0)) * sizeof(cf); }
+size_t fwd_rows_lds_bytes(const RowsArgs &a) { return (size_t)a.n2 * sizeof(cf); }
 
-void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, cf *d_yp, hipStream_t s)
+template <class Groups>
+static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, float *d_yp, hipStream_t s)
 {
-    if (!g_rows_lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_rows_kernel),
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_rows_kernel<Groups>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        g_rows_lds_set = 1;
+        attr_set = true;
     }
     dim3 grid((a.n1 + 1) / 2, n_clips);
-    hipLaunchKernelGGL(fwd_rows_kernel, grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, d_pairs, d_yp);
+    hipLaunchKernelGGL(fwd_rows_kernel<Groups>, grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, d_pairs, d_yp);
 }
 
-void launch_fwd_cols(const FwdPlanDev &fp, const cf *d_yp, int n_clips, cf *d_x, hipStream_t s)
+void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, float *d_yp, hipStream_t s)
 {
-    const int rows = fp.k1hi - fp.k1lo + 1;
-    dim3 grid((fp.h + kColsThreads - 1) / kColsThreads, (rows + kColsRows - 1) / kColsRows, n_clips);
-    hipLaunchKernelGGL(fwd_cols_kernel, grid, dim3(kColsThreads), (size_t)fp.n1 * sizeof(cf), s, fp, d_yp, d_x);
+    if (Groups6300::matches(a.groups, 0, a.groups.n))
+        launch_rows_t<Groups6300>(a, d_pairs, n_clips, d_yp, s);
+    else
+        launch_rows_t<RuntimeGroups>(a, d_pairs, n_clips, d_yp, s);
+}
+
+void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s)
+{
+    dim3 grid(((ca.h + 31) / 32 + 3) / 4, n_clips);
+    for (int t0 = 0; t0 < ca.n_tiles; t0 += 3) {
+        const int nt = ca.n_tiles - t0 < 3 ? ca.n_tiles - t0 : 3;
+        if (nt == 3)
+            hipLaunchKernelGGL(fwd_cols_kernel<3>, grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
+        else if (nt == 2)
+            hipLaunchKernelGGL(fwd_cols_kernel<2>, grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
+        else
+            hipLaunchKernelGGL(fwd_cols_kernel<1>, grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
+    }
+}
+
+// host: coefficient image of the column DFT for the MFMA A operand, [a][tile][lane]:
+// lane l supplies A[row = 32 tile + (l & 31)][k = 2 a + (l >> 5)]; row 2 cr = Re row, 2 cr + 1 = Im row.
+void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, int n_tiles, float *apack)
+{
+    for (int a = 0; a < n1; ++a)
+        for (int t = 0; t < n_tiles; ++t)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 32 * t + (l & 31), cr = row >> 1, part = l >> 5;
+                float v = 0.0f;
+                if (cr < 2 * k1n) {
+                    const int k1 = cr < k1n ? k1lo + cr : n1 - 1 - (k1lo + cr - k1n);
+                    const int64_t idx = ((int64_t)a * k1) % n1;
+                    const float dr = tw_n1_ri[2 * idx], di = tw_n1_ri[2 * idx + 1];
+                    if ((row & 1) == 0) v = part == 0 ? dr : -di; // Re: fma(dr, yr), fma(-di, yi)
+                    else v = part == 0 ? di : dr;                  // Im: fma(di, yr), fma(dr, yi)
+                }
+                apack[((size_t)a * n_tiles + t) * 64 + l] = v;
+            }
 }
 
 } // namespace hpfw

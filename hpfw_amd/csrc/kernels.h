@@ -15,17 +15,13 @@ constexpr int kLag = 80;
 constexpr int kFilters = 64;
 constexpr int kFrame = kBins * kCtx;
 
-// Device-side description of the forward transform N = n1 * n2 (tables live in HBM).
-struct FwdPlanDev {
-    int64_t n;          // samples per clip
-    int n1, n2, h;      // h = n2 / 2 + 1
+// Column DFT (length n1 across residues) on the matrix cores: see k_forward.hip.
+struct ColsArgs {
+    int n1, n2, h, hpad;
     int kmin, kmax;     // forward bins consumed
-    int k1lo, k1hi;     // rows k1 of the length-n1 DFT that hold bins in [kmin, kmax)
-    RadixList radix;    // passes of the length-n2 FFT
-    const cf *tw_n2;    // T_{n2}            [n2]
-    const cf *tw_n1;    // T_{n1}            [n1]
-    const cf *tw_big;   // T_N[a * k2]       [n1][h]
-    const int *pos_n2;  // digit-reversed position of output k2   [n2]
+    int k1lo, k1n;      // wanted rows k1lo .. k1lo + k1n - 1 (and their mirrors)
+    int n_tiles;        // row tiles of 32 (16 complex rows each) covering 2 k1n complex rows
+    const float *apack; // coefficient image [n1][n_tiles][64]
 };
 
 // One Bluestein size class (all bands whose chirp-z length is p).
@@ -50,11 +46,12 @@ struct CqPlanDev {
 
 // coalescing pre-pass: pcm [n_clips][n2][n1] -> pairs [n_clips][(n1+1)/2][n2] (two residues per word)
 void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s);
-// a1 + forward FFT of residue pairs: pairs -> yp [n_clips][n1][h] (twiddled half spectra)
-void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, cf *d_yp, hipStream_t s);
+// a1 + forward FFT of residue pairs: pairs -> planar yp [n_clips][2 n1][hpad] (twiddled half spectra, Re and Im rows)
+void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, float *d_yp, hipStream_t s);
 size_t fwd_rows_lds_bytes(const RowsArgs &a);
-// length-n1 DFT across residues as fma chains: yp -> x [n_clips][kmax-kmin]
-void launch_fwd_cols(const FwdPlanDev &fp, const cf *d_yp, int n_clips, cf *d_x, hipStream_t s);
+// length-n1 DFT across residues on f32 MFMA: planar yp [n_clips][2 n1][hpad] -> x [n_clips][kmax-kmin]
+void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s);
+void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, int n_tiles, float *apack);
 // band chirp-z transforms: x -> mag [n_clips][121][c]; also atomically maxes d_magmax[clip] (bits)
 void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips,
                      float *d_mag, unsigned *d_magmax, hipStream_t s);

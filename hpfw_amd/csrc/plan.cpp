@@ -24,7 +24,7 @@ constexpr int kDown = 3;
 constexpr int kBins = 121;
 constexpr int kCtx = 20;
 constexpr int kLag = 80;
-constexpr int64_t kN2Max = 15360; // complex f32 elements of one in-LDS transform (120 KiB)
+constexpr int64_t kN2Max = 6826; // one in-LDS transform: with half of its twiddle table, two fit a CU's LDS
 
 HostCf twiddle_f(int64_t m, int64_t n)
 {
@@ -82,6 +82,26 @@ void fft_r2_double(std::vector<double> &re, std::vector<double> &im)
     }
 }
 } // namespace
+
+// Twiddles of one fused (r1, r2) DIF group at sub-length len of a length-n transform, laid out
+// [entry][butterfly] (nb = n / (r1 r2) butterflies): entry q2 (r1-1) + (s-1) = T_n[ts1 (j0 + q2 m2) s],
+// entry (r1-1) r2 + (s2-1) = T_n[ts2 j0 s2], with j0 = b mod m2.  The inverse DIT group uses the
+// same values (conjugated by the kernel).
+void append_group_twiddles(const std::vector<HostCf> &tw, int64_t n, int64_t len, int r1, int r2,
+                           std::vector<HostCf> &out)
+{
+    const int64_t m1 = len / r1, m2 = m1 / r2, ts1 = n / len, ts2 = n / m1, nb = n / (r1 * r2);
+    const size_t off = out.size();
+    out.resize(off + (size_t)((r1 - 1) * r2 + (r2 - 1)) * nb);
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t j0 = b % m2;
+        for (int q2 = 0; q2 < r2; ++q2)
+            for (int s = 1; s < r1; ++s)
+                out[off + (size_t)(q2 * (r1 - 1) + (s - 1)) * nb + b] = tw[(size_t)(ts1 * (j0 + q2 * m2) * s)];
+        for (int s2 = 1; s2 < r2; ++s2)
+            out[off + (size_t)((r1 - 1) * r2 + (s2 - 1)) * nb + b] = tw[(size_t)(ts2 * j0 * s2)];
+    }
+}
 
 void twiddle_d(int64_t m, int64_t n, double &re, double &im)
 {
@@ -179,13 +199,27 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
     if (p.n_frames < 0) p.n_frames = 0;
     if (p.n_hp < 0) p.n_hp = 0;
     // ---- forward split N = n1 * n2 ----
-    int64_t n1 = 0;
+    // d0 = the smallest divisor with N / d0 <= kN2Max; among the divisors in [d0, 5 d0 / 4] prefer an
+    // even n2 (its twiddle table halves exactly), then the fewest pairs of radix passes, then the
+    // smallest n1
+    int64_t n1 = 0, d0 = 0;
+    int best_odd = 2, best_groups = 1 << 30;
     for (int64_t d = 1; d <= n; ++d) {
-        if (n % d) continue;
-        if (n / d <= kN2Max) {
+        if (n % d || n / d > kN2Max) continue;
+        if (d0 == 0) d0 = d;
+        if (4 * d > 5 * d0) break;
+        std::vector<int> r;
+        if (!make_radix_list(n / d, r)) break; // not 7-smooth: reported below
+        const int odd = (int)((n / d) & 1), groups = ((int)r.size() + 1) / 2;
+        if (odd < best_odd || (odd == best_odd && groups < best_groups)) {
+            best_odd = odd;
+            best_groups = groups;
             n1 = d;
-            break;
         }
+    }
+    if (n1 == 0) {
+        why = "clip length has a prime factor other than 2, 3, 5, 7";
+        return false;
     }
     const int64_t n2 = n / n1;
     std::vector<int> tmp;
@@ -226,16 +260,14 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
         why = "too many radix passes";
         return false;
     }
-    // quadrant rule used by the row kernel: T[m + q n2/4] = (-i)^q T[m]; keep it only if it is exact
-    p.rows_quad = (n2 % 4 == 0) ? 1 : 0;
-    for (int64_t m = 0; p.rows_quad && m < n2; ++m) {
-        const int64_t nq = n2 / 4, q = m / nq;
-        const HostCf e = p.tw_n2[(size_t)(m - q * nq)];
-        float re = (q & 1) ? e.i : e.r, im = (q & 1) ? e.r : e.i;
-        if (q == 2 || q == 3) re = -re;
-        if (q == 1 || q == 2) im = -im;
-        const HostCf want = p.tw_n2[(size_t)m];
-        if (std::memcmp(&re, &want.r, 4) != 0 || std::memcmp(&im, &want.i, 4) != 0) p.rows_quad = 0;
+    // per-butterfly twiddle tables of the fused groups (values copied from T_n2)
+    {
+        int64_t len = n2;
+        for (const auto &g : p.groups) {
+            p.rows_gtw_off.push_back((int)p.rows_gtw.size());
+            append_group_twiddles(p.tw_n2, n2, len, g.first, g.second, p.rows_gtw);
+            len /= g.first * g.second;
+        }
     }
     p.tw_big.resize((size_t)n1 * p.h);
     for (int64_t a = 0; a < n1; ++a)

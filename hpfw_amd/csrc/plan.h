@@ -28,7 +28,8 @@ struct HostPlan {
     int m = 0, c = 0, n_frames = 0, n_hp = 0;
     std::vector<int> radix;                 // passes of the length-n2 FFT
     std::vector<std::pair<int, int>> groups; // the same passes, fused in pairs (second = 1: single pass)
-    int rows_quad = 0;                      // 4 | n2: T_n2 follows exactly from its first quarter
+    std::vector<HostCf> rows_gtw;           // per-butterfly twiddles of every group, [entry][butterfly]
+    std::vector<int> rows_gtw_off;          // start of each group's table in rows_gtw
     std::vector<HostCf> tw_n2, tw_n1, tw_big;
     std::vector<int> pos_n2;
     int start[121], lg[121], psize[121];
@@ -45,5 +46,7 @@ void twiddle_d(int64_t m, int64_t n, double &re, double &im);
 // mixed-radix digit reversal of the DIF pass list
 int64_t digit_pos(int64_t k, int64_t n, const std::vector<int> &radix);
 bool make_radix_list(int64_t n, std::vector<int> &radix);
+void append_group_twiddles(const std::vector<HostCf> &tw, int64_t n, int64_t len, int r1, int r2,
+                           std::vector<HostCf> &out);
 
 } // namespace hpfw

@@ -296,7 +296,7 @@ static int make_rows_radix_list(int64_t n, int32_t *radix)
 /* ------------------------------------------------------------------------------------------ */
 /* plan                                                                                        */
 /* ------------------------------------------------------------------------------------------ */
-#define N2_MAX 15360 /* complex f32 elements one in-core FFT may hold (120 KiB) */
+#define N2_MAX 6826 /* complex f32 elements of one in-core FFT: with half of its twiddle table, two fit a CU's LDS */
 #define SAMPLE_RATE 44100.0
 #define MIN_FREQ 130.81  /* cqt.h:60 */
 #define MAX_FREQ 4186.01 /* cqt.h:61 */
@@ -460,11 +460,27 @@ hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n)
     if (n < 2) return NULL;
     hpfw_oracle_plan *p = (hpfw_oracle_plan *)calloc(1, sizeof(*p));
     p->info.n_samples = n;
-    /* N = n1 * n2: n1 = smallest divisor with n / n1 <= N2_MAX */
-    int64_t n1 = 0;
+    /* N = n1 * n2 with n2 <= N2_MAX: d0 = the smallest divisor that fits; among the divisors in
+     * [d0, 5 d0 / 4] prefer an even n2 (its twiddle table halves exactly), then the fewest pairs of
+     * radix passes, then the smallest n1 */
+    int64_t n1 = 0, best_odd = 2, best_groups = 1 << 30, d0 = 0;
     for (int64_t d = 1; d <= n; ++d) {
-        if (n % d) continue;
-        if (n / d <= N2_MAX) { n1 = d; break; }
+        if (n % d || n / d > N2_MAX) continue;
+        if (d0 == 0) d0 = d;
+        if (4 * d > 5 * d0) break;
+        int32_t tmp_r[HPFW_O_MAXRADIX];
+        int nr = make_radix_list(n / d, tmp_r);
+        if (nr < 0) break; /* not 7-smooth: rejected below */
+        int64_t odd = (n / d) & 1, groups = (nr + 1) / 2;
+        if (odd < best_odd || (odd == best_odd && groups < best_groups)) {
+            best_odd = odd;
+            best_groups = groups;
+            n1 = d;
+        }
+    }
+    if (n1 == 0) {
+        free(p);
+        return NULL;
     }
     int64_t n2 = n / n1;
     p->info.n1 = n1;
@@ -563,8 +579,8 @@ void hpfw_oracle_spectrum(const hpfw_oracle_plan *p, const int16_t *pcm, float *
             cf y = yp[a * h + k2];
             ar = fmaf(d.r, y.r, ar);
             ar = fmaf(-d.i, y.i, ar);
-            ai = fmaf(d.r, y.i, ai);
             ai = fmaf(d.i, y.r, ai);
+            ai = fmaf(d.r, y.i, ai);
         }
         x_ri[2 * (k - p->info.kmin)] = ar;
         x_ri[2 * (k - p->info.kmin) + 1] = conj ? -ai : ai;

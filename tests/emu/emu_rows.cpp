@@ -30,7 +30,7 @@ struct Checked {
 int main(int argc, char **argv)
 {
     const long n = argc > 1 ? std::atol(argv[1]) : 44100 * 3;
-    const int nthreads = argc > 2 ? std::atoi(argv[2]) : 768;
+    const int nthreads = argc > 2 ? std::atoi(argv[2]) : 384;
     hpfw::HostPlan hp;
     std::string why;
     if (!hpfw::build_plan(n, hp, why)) {
@@ -49,17 +49,18 @@ int main(int argc, char **argv)
     a.n1 = hp.n1;
     a.n2 = hp.n2;
     a.h = hp.h;
-    a.quad = hp.rows_quad;
+    for (size_t g = 0; g < hp.groups.size(); ++g) a.groups.tw_off[g] = hp.rows_gtw_off[g];
+    a.hpad = (hp.h + 31) / 32 * 32;
     a.groups.n = (int)hp.groups.size();
     for (size_t g = 0; g < hp.groups.size(); ++g) {
         a.groups.r1[g] = hp.groups[g].first;
         a.groups.r2[g] = hp.groups[g].second;
     }
-    a.tw_n2 = reinterpret_cast<const cf *>(hp.tw_n2.data());
+    a.gtw = reinterpret_cast<const cf *>(hp.rows_gtw.data());
     a.tw_big = reinterpret_cast<const cf *>(hp.tw_big.data());
     a.pos_n2 = hp.pos_n2.data();
-    std::vector<cf> yp((size_t)hp.n1 * hp.h);
-    const size_t lds_n = (size_t)hp.n2 + (hp.rows_quad ? hp.n2 / 4 : 0);
+    std::vector<float> yp((size_t)2 * hp.n1 * a.hpad, NAN);
+    const size_t lds_n = (size_t)hp.n2;
     for (int a0 = 0; a0 < hp.n1; a0 += 2) {
         std::vector<hpfw::i16x2> pairs(hp.n2);
         for (int t = 0; t < hp.n2; ++t) {
@@ -68,8 +69,13 @@ int main(int argc, char **argv)
         }
         std::vector<cf> lds_mem(lds_n, cf{NAN, NAN});
         Checked<cf> lds{lds_mem.data(), lds_mem.size()};
-        hpfw::rows_body(lds, a, nthreads, pairs.data(), a0, yp.data() + (size_t)a0 * hp.h,
-                        (a0 + 1 < hp.n1) ? yp.data() + (size_t)(a0 + 1) * hp.h : nullptr);
+        float *ya = yp.data() + (size_t)2 * a0 * a.hpad;
+        float *yb = (a0 + 1 < hp.n1) ? yp.data() + (size_t)2 * (a0 + 1) * a.hpad : nullptr;
+        // alternate between the compile-time group sequence (when it applies) and the run-time one
+        if (hpfw::Groups6300::matches(a.groups, 0, a.groups.n) && (a0 & 2) == 0)
+            hpfw::rows_body<hpfw::Groups6300>(lds, a, nthreads, pairs.data(), a0, ya, yb);
+        else
+            hpfw::rows_body<hpfw::RuntimeGroups>(lds, a, nthreads, pairs.data(), a0, ya, yb);
     }
     // S6: X[n2 k1 + k2] = sum_a T_n1[a k1] Y'[a][k2]
     const long nk = hp.kmax - hp.kmin;
@@ -85,11 +91,11 @@ int main(int argc, char **argv)
         float ar = 0.f, ai = 0.f;
         for (long aa = 0; aa < hp.n1; ++aa) {
             const hpfw::HostCf d = hp.tw_n1[(size_t)((aa * k1) % hp.n1)];
-            const cf y = yp[(size_t)(aa * hp.h + k2)];
+            const cf y = {yp[(size_t)(2 * aa) * a.hpad + k2], yp[(size_t)(2 * aa + 1) * a.hpad + k2]};
             ar = __builtin_fmaf(d.r, y.r, ar);
             ar = __builtin_fmaf(-d.i, y.i, ar);
-            ai = __builtin_fmaf(d.r, y.i, ai);
             ai = __builtin_fmaf(d.i, y.r, ai);
+            ai = __builtin_fmaf(d.r, y.i, ai);
         }
         got[2 * (k - hp.kmin)] = ar;
         got[2 * (k - hp.kmin) + 1] = conj ? -ai : ai;
@@ -102,7 +108,7 @@ int main(int argc, char **argv)
             if (bad < 5) std::fprintf(stderr, "bin %ld: emu %.9g oracle %.9g\n", i / 2 + hp.kmin, got[i], ref[i]);
             ++bad;
         }
-    std::printf("n=%ld n1=%d n2=%d groups=%d quad=%d values=%ld mismatches=%ld\n", n, hp.n1, hp.n2, a.groups.n, a.quad,
+    std::printf("n=%ld n1=%d n2=%d groups=%d gtw=%d values=%ld mismatches=%ld\n", n, hp.n1, hp.n2, a.groups.n, (int)hp.rows_gtw.size(),
                 2 * nk, bad);
     hpfw_oracle_plan_destroy(op);
     return bad ? 1 : 0;
