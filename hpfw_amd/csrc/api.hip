@@ -227,7 +227,9 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         cd.n_bands = (int)bc.bands.size();
         cd.radix = to_radix(bc.radix);
         if ((rc = upload(bc.tw, reinterpret_cast<const hpfw::HostCf **>(&cd.tw), dp->owned))) return rc;
-        if ((rc = upload(bc.oct, reinterpret_cast<const hpfw::HostCf **>(&cd.oct), dp->owned))) return rc;
+        if ((rc = upload(bc.gtw, reinterpret_cast<const hpfw::HostCf **>(&cd.gtw.tab), dp->owned))) return rc;
+        for (int g = 0; g < 4; ++g) cd.gtw.off[g] = bc.goff[g];
+        cd.gtw.mid_off = bc.mid_off;
         if ((rc = upload(bc.vrev, reinterpret_cast<const hpfw::HostCf **>(&cd.vrev), dp->owned))) return rc;
         if ((rc = upload(bc.bands, &cd.band, dp->owned))) return rc;
         dp->cls.push_back(cd);

@@ -2,10 +2,10 @@
 //
 // The arithmetic is the specification's sequence of radix-4 (and one radix-2) passes; here two
 // consecutive passes are fused in registers (16 points per thread, one LDS round trip instead of
-// two), the twiddles T_N[m] are rebuilt from a first-octant table kept in LDS (sign flips and
-// swaps only, which is how the specification defines the table, so the values are identical), and
-// the data sit in a padded image (one spare slot per 16) so that the stride-16 accesses of the
-// innermost pass do not collide on LDS banks.  None of this changes a single rounding.
+// two), the twiddles of a fused group come from a per-butterfly table in global memory (built by
+// the host from T_N, entry e of butterfly b at [e][b]: coalesced, L2 resident, no index
+// arithmetic), and the data sit in a padded image (one spare slot per 16) so that the stride-16
+// accesses of the innermost pass do not collide on LDS banks.  None of this changes a rounding.
 #pragma once
 #include "device_math.h"
 
@@ -16,25 +16,17 @@ HPFW_DEVICE int pad16(int i) { return i + (i >> 4); }
 template <int LOGN>
 struct Pow2 {
     static constexpr int N = 1 << LOGN;
-    static constexpr int NOCT = N / 8;              // octant table: NOCT + 1 entries (cos, sin)
-    static constexpr int DATA = N + N / 16;         // padded data slots
-    static constexpr int LDS_CF = DATA + NOCT + 1;  // complex slots a workgroup needs
+    static constexpr int DATA = N + N / 16; // padded data slots (complex)
+};
 
-    // T_N[m] = e^{-2 pi i m / N} from oct[t] = (cos, sin)(2 pi t / N), t = 0..N/8
-    template <class Lds>
-    HPFW_DEVICE_STATIC cf tw(const Lds &lds, int m)
-    {
-        const int o = m >> (LOGN - 3);
-        const int mm = m & (NOCT - 1);
-        const int t = (o & 1) ? NOCT - mm : mm;
-        const cf e = lds[DATA + t];
-        const bool swp = ((o + 1) & 2) != 0;
-        float c = swp ? e.i : e.r;
-        float s = swp ? e.r : e.i;
-        if ((o + 2) & 4) c = -c;
-        if (o & 4) s = -s;
-        return {c, -s};
-    }
+constexpr int kCqMaxGroups = 4;
+
+// where each fused group's twiddles start in the class table (complex elements); entry layout as
+// in plan.cpp append_group_twiddles: q2 (R1-1) + (s-1) for stage 1, (R1-1) R2 + (s2-1) for stage 2
+struct CqTwiddles {
+    const cf *tab;
+    int off[kCqMaxGroups]; // outer groups, outermost first
+    int mid_off;           // innermost group: one butterfly's entries (they do not depend on b)
 };
 
 // ---- one fused group of the forward DIF: radix R1 at sub-length LEN, then radix R2 (or 1) ----
@@ -42,16 +34,16 @@ struct Pow2 {
 // LEN == N): a radix-R1 butterfly whose inputs 1..R1-1 are zero returns its input 0 on every
 // output, so those loads and adds are skipped and the zero padding is never read.
 template <int LOGN, int LOGLEN, int R1, int R2, bool PRUNE, class Lds>
-HPFW_DEVICE void dif_group(Lds &lds, int tid, int nthreads, int nz)
+HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nthreads, int nz)
 {
     using P = Pow2<LOGN>;
     constexpr int LEN = 1 << LOGLEN;
     constexpr int M1 = LEN / R1, M2 = M1 / R2;
-    constexpr int TS1 = P::N / LEN, TS2 = P::N / M1;
     constexpr int NB = P::N / (R1 * R2);
     for (int b = tid; b < NB; b += nthreads) {
         const int blk = b / M2, j0 = b % M2;
         const int base = blk * LEN + j0;
+        const cf *__restrict__ tb = gt + b;
         cf e[R1][R2];
 #pragma unroll
         for (int q2 = 0; q2 < R2; ++q2) {
@@ -69,7 +61,7 @@ HPFW_DEVICE void dif_group(Lds &lds, int tid, int nthreads, int nz)
             }
             e[0][q2] = u[0];
 #pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], P::tw(lds, TS1 * j * s));
+            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tb[(q2 * (R1 - 1) + (s - 1)) * NB]);
         }
 #pragma unroll
         for (int s = 0; s < R1; ++s) {
@@ -81,7 +73,7 @@ HPFW_DEVICE void dif_group(Lds &lds, int tid, int nthreads, int nz)
                 lds[pad16(base + s * M1)] = v[0];
 #pragma unroll
                 for (int s2 = 1; s2 < R2; ++s2)
-                    lds[pad16(base + s * M1 + s2 * M2)] = c_mul(v[s2], P::tw(lds, TS2 * j0 * s2));
+                    lds[pad16(base + s * M1 + s2 * M2)] = c_mul(v[s2], tb[((R1 - 1) * R2 + (s2 - 1)) * NB]);
             } else {
                 lds[pad16(base + s * M1)] = e[s][0];
             }
@@ -101,18 +93,19 @@ HPFW_DEVICE void idft(cf *u)
 }
 
 // ---- one fused group of the inverse DIT: radix R2 (or 1) at sub-length LEN / R1, then R1 ----
-// Outputs with index >= keep are not stored (only the first C samples of the last group are used).
+// Same table as the forward group (the kernel conjugates).  Outputs with index >= keep are not
+// stored (only the first C samples of the last group are used).
 template <int LOGN, int LOGLEN, int R1, int R2, class Lds>
-HPFW_DEVICE void idit_group(Lds &lds, int tid, int nthreads, int keep)
+HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nthreads, int keep)
 {
     using P = Pow2<LOGN>;
     constexpr int LEN = 1 << LOGLEN;
     constexpr int M1 = LEN / R1, M2 = M1 / R2;
-    constexpr int TS1 = P::N / LEN, TS2 = P::N / M1;
     constexpr int NB = P::N / (R1 * R2);
     for (int b = tid; b < NB; b += nthreads) {
         const int blk = b / M2, j0 = b % M2;
         const int base = blk * LEN + j0;
+        const cf *__restrict__ tb = gt + b;
         cf o[R1][R2];
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
@@ -120,7 +113,7 @@ HPFW_DEVICE void idit_group(Lds &lds, int tid, int nthreads, int keep)
             v[0] = lds[pad16(base + q * M1)];
 #pragma unroll
             for (int q2 = 1; q2 < R2; ++q2)
-                v[q2] = c_mulc(lds[pad16(base + q * M1 + q2 * M2)], P::tw(lds, TS2 * j0 * q2));
+                v[q2] = c_mulc(lds[pad16(base + q * M1 + q2 * M2)], tb[((R1 - 1) * R2 + (q2 - 1)) * NB]);
             if constexpr (R2 > 1) idft<R2>(v);
 #pragma unroll
             for (int s2 = 0; s2 < R2; ++s2) o[q][s2] = v[s2];
@@ -131,7 +124,7 @@ HPFW_DEVICE void idit_group(Lds &lds, int tid, int nthreads, int keep)
             cf u[R1];
             u[0] = o[0][s2];
 #pragma unroll
-            for (int q = 1; q < R1; ++q) u[q] = c_mulc(o[q][s2], P::tw(lds, TS1 * j * q));
+            for (int q = 1; q < R1; ++q) u[q] = c_mulc(o[q][s2], tb[(s2 * (R1 - 1) + (q - 1)) * NB]);
             idft<R1>(u);
 #pragma unroll
             for (int s = 0; s < R1; ++s) {
@@ -145,14 +138,14 @@ HPFW_DEVICE void idit_group(Lds &lds, int tid, int nthreads, int keep)
 // ---- the innermost group of both transforms in one register pass:
 // last DIF group (R1, R2 at LEN), pointwise product with V (digit-reversed positions = the LDS
 // positions), first inverse DIT group (R2, then R1) -- the same LEN points in both directions.
+// mt: the group's stage-1 entries (q2 (R1-1) + (s-1)), the same for every butterfly.
 template <int LOGN, int LOGLEN, int R1, int R2, class Lds>
-HPFW_DEVICE void mid_group(Lds &lds, int tid, int nthreads, const cf *__restrict__ vrev)
+HPFW_DEVICE void mid_group(Lds &lds, const cf *__restrict__ mt, int tid, int nthreads, const cf *__restrict__ vrev)
 {
     using P = Pow2<LOGN>;
     constexpr int LEN = 1 << LOGLEN;
     static_assert(LEN == R1 * R2, "the innermost group spans whole sub-transforms");
     constexpr int M1 = LEN / R1, M2 = 1;
-    constexpr int TS1 = P::N / LEN;
     constexpr int NB = P::N / LEN;
     for (int b = tid; b < NB; b += nthreads) {
         const int base = b * LEN;
@@ -166,7 +159,7 @@ HPFW_DEVICE void mid_group(Lds &lds, int tid, int nthreads, const cf *__restrict
             Dft<R1>::run(u);
             e[0][q2] = u[0];
 #pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], P::tw(lds, TS1 * q2 * s));
+            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], mt[q2 * (R1 - 1) + (s - 1)]);
         }
 #pragma unroll
         for (int s = 0; s < R1; ++s) {
@@ -192,7 +185,7 @@ HPFW_DEVICE void mid_group(Lds &lds, int tid, int nthreads, const cf *__restrict
             cf u[R1];
             u[0] = e[0][s2];
 #pragma unroll
-            for (int q = 1; q < R1; ++q) u[q] = c_mulc(e[q][s2], P::tw(lds, TS1 * s2 * q));
+            for (int q = 1; q < R1; ++q) u[q] = c_mulc(e[q][s2], mt[s2 * (R1 - 1) + (q - 1)]);
             idft<R1>(u);
 #pragma unroll
             for (int s = 0; s < R1; ++s) lds[pad16(base + s2 + s * M1)] = u[s];
@@ -203,6 +196,7 @@ HPFW_DEVICE void mid_group(Lds &lds, int tid, int nthreads, const cf *__restrict
 // ---- drivers: groups of the pass list [4 x (LOGN/2), 2 x (LOGN%2)] ----
 // LOGLEN = log2 of the sub-transform length still to be done.  The innermost group is handled by
 // mid_group; the outer ones by dif_group on the way in and idit_group on the way out.
+// (plan.cpp walks the same list to lay out the twiddle tables.)
 template <int LOGLEN>
 struct GroupOf { // radices of the next fused group when 2^LOGLEN remains
     static constexpr int R1 = (LOGLEN >= 2) ? 4 : 2;
@@ -210,48 +204,52 @@ struct GroupOf { // radices of the next fused group when 2^LOGLEN remains
     static constexpr int BITS = (R1 == 4 ? 2 : 1) + (R2 == 4 ? 2 : (R2 == 2 ? 1 : 0));
 };
 
-template <int LOGN, int LOGLEN, bool FIRST, class Lds>
-HPFW_DEVICE void cq_transform(Lds &lds, int tid, int nthreads, int nz, int keep, const cf *__restrict__ vrev)
+template <int LOGN, int LOGLEN, int G, class Lds>
+HPFW_DEVICE void cq_transform(Lds &lds, const CqTwiddles &tw, int nthreads, int nz, int keep,
+                              const cf *__restrict__ vrev)
 {
-    using G = GroupOf<LOGLEN>;
-    constexpr int REST = LOGLEN - G::BITS;
+    using GO = GroupOf<LOGLEN>;
+    constexpr int REST = LOGLEN - GO::BITS;
+    constexpr bool FIRST = (G == 0);
     if constexpr (REST == 0) {
-        HPFW_FOR_THREADS(t, nthreads) { (void)tid; mid_group<LOGN, LOGLEN, G::R1, G::R2>(lds, t, nthreads, vrev); }
+        const cf *mt = tw.tab + tw.mid_off;
+        HPFW_FOR_THREADS(t, nthreads) { mid_group<LOGN, LOGLEN, GO::R1, GO::R2>(lds, mt, t, nthreads, vrev); }
         HPFW_BARRIER();
     } else {
-        if (FIRST && nz <= (1 << LOGLEN) / G::R1) {
-            HPFW_FOR_THREADS(t, nthreads) { dif_group<LOGN, LOGLEN, G::R1, G::R2, true>(lds, t, nthreads, nz); }
+        static_assert(G < kCqMaxGroups, "too many fused groups");
+        const cf *gt = tw.tab + tw.off[G];
+        if (FIRST && nz <= (1 << LOGLEN) / GO::R1) {
+            HPFW_FOR_THREADS(t, nthreads) { dif_group<LOGN, LOGLEN, GO::R1, GO::R2, true>(lds, gt, t, nthreads, nz); }
         } else {
-            HPFW_FOR_THREADS(t, nthreads) { dif_group<LOGN, LOGLEN, G::R1, G::R2, false>(lds, t, nthreads, nz); }
+            HPFW_FOR_THREADS(t, nthreads) { dif_group<LOGN, LOGLEN, GO::R1, GO::R2, false>(lds, gt, t, nthreads, nz); }
         }
         HPFW_BARRIER();
-        cq_transform<LOGN, REST, false>(lds, tid, nthreads, nz, keep, vrev);
+        cq_transform<LOGN, REST, G + 1>(lds, tw, nthreads, nz, keep, vrev);
         HPFW_FOR_THREADS(t, nthreads)
         {
-            idit_group<LOGN, LOGLEN, G::R1, G::R2>(lds, t, nthreads, FIRST ? keep : (1 << LOGN));
+            idit_group<LOGN, LOGLEN, GO::R1, GO::R2>(lds, gt, t, nthreads, FIRST ? keep : (1 << LOGN));
         }
         HPFW_BARRIER();
     }
 }
 
 // ---- the whole band: window*chirp, forward FFT, times V, inverse FFT, magnitudes ----
-// lds: Pow2<LOGP>::LDS_CF complex slots.  Returns this thread's maximum magnitude through red[].
+// lds: Pow2<LOGP>::DATA complex slots; red: one float per thread (this thread's largest magnitude).
 template <int LOGP, class Lds, class Red>
 HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const cf *__restrict__ xs, const cf *__restrict__ g,
-                              int lg, const cf *__restrict__ oct, const cf *__restrict__ vrev, int c,
+                              int lg, const CqTwiddles &tw, const cf *__restrict__ vrev, int c,
                               float *__restrict__ out_mag)
 {
     using P = Pow2<LOGP>;
     const bool prune = lg <= P::N / 4;
     HPFW_FOR_THREADS(tid, nthreads)
     {
-        for (int i = tid; i <= P::NOCT; i += nthreads) lds[P::DATA + i] = oct[i];
         for (int i = tid; i < lg; i += nthreads) lds[pad16(i)] = c_mul(xs[i], g[i]);
         if (!prune)
             for (int i = lg + tid; i < P::N; i += nthreads) lds[pad16(i)] = {0.0f, 0.0f};
     }
     HPFW_BARRIER();
-    cq_transform<LOGP, LOGP, true>(lds, 0, nthreads, lg, c, vrev);
+    cq_transform<LOGP, LOGP, 0>(lds, tw, nthreads, lg, c, vrev);
     HPFW_FOR_THREADS(tid, nthreads)
     {
         float mx = 0.0f;

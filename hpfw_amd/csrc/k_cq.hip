@@ -7,7 +7,6 @@
 // (Bluestein) transform of power-of-two length P_j >= Lg_j + C - 1 held entirely in LDS
 // (DESIGN.md S7): a = X[s_j + i] G_j[i]; A = FFT_P(a); B = A . V_P; b = IFFT_P(B); |b[c]|.
 #include "kernels.h"
-#include "fft_lds.h"
 
 namespace hpfw {
 
@@ -35,12 +34,12 @@ __global__ __launch_bounds__(cq_threads(LOGP)) void cq_kernel(CqPlanDev cp, CqCl
 {
     using P = Pow2<LOGP>;
     cf *lds = reinterpret_cast<cf *>(smem_raw);
-    float *red = reinterpret_cast<float *>(lds + P::DATA); // reuses the twiddle slots after the last pass
+    float *red = reinterpret_cast<float *>(lds + P::DATA); // one float per thread behind the data
     const int j = cc.band[blockIdx.x];
     const int clip = blockIdx.y;
     const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[j] - cp.kmin);
     float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
-    cq_band_body<LOGP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.oct, cc.vrev, cp.c, out);
+    cq_band_body<LOGP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out);
     const float mx = wave_max(red[threadIdx.x]);
     if ((threadIdx.x & 63) == 0) atomicMax(&magmax[clip], __float_as_uint(mx)); // mag >= 0: bit order = value order
 }
@@ -126,7 +125,7 @@ static void launch_cq_t(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x
         attr_set = true;
     }
     dim3 grid(cc.n_bands, n_clips);
-    hipLaunchKernelGGL(cq_kernel<LOGP>, grid, dim3(cq_threads(LOGP)), (size_t)Pow2<LOGP>::LDS_CF * sizeof(cf), s, cp,
+    hipLaunchKernelGGL(cq_kernel<LOGP>, grid, dim3(cq_threads(LOGP)), (size_t)Pow2<LOGP>::DATA * sizeof(cf) + cq_threads(LOGP) * sizeof(float), s, cp,
                        cc, d_x, d_mag, d_magmax);
 }
 

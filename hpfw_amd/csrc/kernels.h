@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "device_math.h"
+#include "fft_lds.h"
 #include "fft_rows.h"
 
 namespace hpfw {
@@ -30,7 +31,7 @@ struct CqClassDev {
     int n_bands;        // bands in this class
     RadixList radix;
     const cf *tw;       // T_p   [p]
-    const cf *oct;      // first octant (cos, sin)(2 pi t / p), t = 0..p/8
+    CqTwiddles gtw;     // per-butterfly twiddle tables of the fused groups
     const cf *vrev;     // DFT_p(chirp) at digit-reversed positions [p]
     const int *band;    // band index j                 [n_bands]
 };

@@ -294,25 +294,33 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
             bc.p = (int)ps;
             make_radix_list(ps, bc.radix);
             bc.tw = twiddle_table(ps);
-            // first-octant table the kernels keep in LDS; T_p must follow from it exactly
-            bc.oct.resize((size_t)(ps / 8 + 1));
-            for (int64_t t = 0; t <= ps / 8; ++t) {
-                const double alpha = M_PI * (double)(8 * t) / (double)(4 * ps);
-                bc.oct[(size_t)t] = {(float)std::cos(alpha), (float)std::sin(alpha)};
-            }
-            for (int64_t mm = 0; mm < ps; ++mm) {
-                const int o = (int)(mm / (ps / 8));
-                const int64_t r = mm % (ps / 8);
-                const HostCf e = bc.oct[(size_t)((o & 1) ? ps / 8 - r : r)];
-                const bool swp = ((o + 1) & 2) != 0;
-                float c = swp ? e.i : e.r, s = swp ? e.r : e.i;
-                if ((o + 2) & 4) c = -c;
-                if (o & 4) s = -s;
-                const HostCf want = bc.tw[(size_t)mm];
-                const float ni = -s;
-                if (std::memcmp(&c, &want.r, 4) != 0 || std::memcmp(&ni, &want.i, 4) != 0) {
-                    why = "internal: octant twiddle table does not reproduce T_p";
-                    return false;
+            // per-butterfly twiddle tables of the fused groups, in the order the kernel walks them
+            // (fft_lds.h GroupOf): pairs of radix-4 passes, then (4,2) / (4) / (2); the innermost
+            // group's entries do not depend on the butterfly and are stored once
+            {
+                int loglen = 0;
+                while ((1 << loglen) < ps) ++loglen;
+                int g = 0;
+                for (;;) {
+                    const int r1 = loglen >= 2 ? 4 : 2;
+                    const int r2 = loglen >= 4 ? 4 : (loglen == 3 ? 2 : 1);
+                    const int bits = (r1 == 4 ? 2 : 1) + (r2 == 4 ? 2 : (r2 == 2 ? 1 : 0));
+                    const int64_t len = (int64_t)1 << loglen;
+                    if (loglen - bits == 0) {
+                        std::vector<HostCf> tmp;
+                        append_group_twiddles(bc.tw, ps, len, r1, r2, tmp);
+                        const int64_t nb = ps / (r1 * r2);
+                        bc.mid_off = (int)bc.gtw.size();
+                        for (int e = 0; e < (r1 - 1) * r2; ++e) bc.gtw.push_back(tmp[(size_t)e * nb]);
+                        break;
+                    }
+                    if (g >= 4) {
+                        why = "internal: too many fused groups";
+                        return false;
+                    }
+                    bc.goff[g++] = (int)bc.gtw.size();
+                    append_group_twiddles(bc.tw, ps, len, r1, r2, bc.gtw);
+                    loglen -= bits;
                 }
             }
             std::vector<double> re((size_t)ps, 0.0), im((size_t)ps, 0.0);

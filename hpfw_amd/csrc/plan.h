@@ -16,7 +16,9 @@ struct BluesteinClass {
     int p = 0;
     std::vector<int> radix;
     std::vector<HostCf> tw;    // T_p
-    std::vector<HostCf> oct;   // (cos, sin)(2 pi t / p), t = 0..p/8: first octant, T_p follows by symmetry
+    std::vector<HostCf> gtw;   // per-butterfly twiddles of the fused groups, [entry][butterfly] per group
+    int goff[4] = {0, 0, 0, 0}; // start of each outer group's table in gtw
+    int mid_off = 0;           // start of the innermost group's entries
     std::vector<HostCf> vrev;  // DFT_p(chirp) at digit-reversed positions
     std::vector<int> bands;    // bands using this size
 };

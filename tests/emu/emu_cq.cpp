@@ -36,7 +36,7 @@ static void run_band(const hpfw::HostPlan &hp, const hpfw::BluesteinClass &bc, i
     int nt = P::N / 16;
     if (nt < 64) nt = 64;
     if (nt > 1024) nt = 1024;
-    std::vector<cf> lds_mem(P::LDS_CF);
+    std::vector<cf> lds_mem(P::DATA);
     // poison so that a read of never-written LDS shows up as NaN
     for (auto &v : lds_mem) v = {__builtin_nanf(""), __builtin_nanf("")};
     Checked<cf> lds{lds_mem.data(), lds_mem.size()};
@@ -44,8 +44,12 @@ static void run_band(const hpfw::HostPlan &hp, const hpfw::BluesteinClass &bc, i
     Checked<float> red{red_mem.data(), red_mem.size()};
     const cf *xs = x + (hp.start[j] - hp.kmin);
     const cf *g = reinterpret_cast<const cf *>(hp.g.data()) + hp.g_off[j];
-    hpfw::cq_band_body<LOGP>(lds, red, nt, xs, g, hp.lg[j], reinterpret_cast<const cf *>(bc.oct.data()),
-                             reinterpret_cast<const cf *>(bc.vrev.data()), hp.c, mag + (size_t)j * hp.c);
+    hpfw::CqTwiddles tw;
+    tw.tab = reinterpret_cast<const cf *>(bc.gtw.data());
+    for (int k = 0; k < 4; ++k) tw.off[k] = bc.goff[k];
+    tw.mid_off = bc.mid_off;
+    hpfw::cq_band_body<LOGP>(lds, red, nt, xs, g, hp.lg[j], tw, reinterpret_cast<const cf *>(bc.vrev.data()), hp.c,
+                             mag + (size_t)j * hp.c);
 }
 
 int main(int argc, char **argv)
