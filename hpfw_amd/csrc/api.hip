@@ -88,7 +88,7 @@ struct hpfw_gpu {
     bool has_filters = false;
     float *d_fpack = nullptr;
     std::map<int64_t, std::unique_ptr<DevPlan>> plans;
-    int batch = 256; // clips per pass: ~2.4 GB of workspace at 30 s; fills the 256 CUs several times over
+    int batch = 1024; // clips per pass: ~10 GB of workspace at 30 s; every launch fills the 256 CUs many times over
     // extraction workspace
     size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
     void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // yp, x, mag, proj, magmax, pairs
@@ -182,6 +182,9 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     ra.n2 = p.n2;
     ra.h = p.h;
     ra.hpad = (p.h + 31) / 32 * 32;
+    // The pcm_pairs pre-pass (coalesced stream) measured faster than reading the aligned 4-byte pair
+    // words in place (6.4 vs 7.1 ms per 1000 clips); HPFW_ROWS_INPLACE=1 selects the latter (n1 even).
+    ra.pair_stride = (p.n1 % 2 == 0 && std::getenv("HPFW_ROWS_INPLACE")) ? p.n1 / 2 : 1;
     ra.groups.n = (int)p.groups.size();
     for (size_t g = 0; g < p.groups.size(); ++g) {
         ra.groups.r1[g] = p.groups[g].first;
@@ -206,6 +209,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     ca.k1lo = p.k1lo;
     ca.k1n = p.k1hi - p.k1lo + 1;
     ca.n_tiles = (2 * ca.k1n + 15) / 16;
+    ca.debug_same_a = std::getenv("HPFW_DEBUG_COLS_SAME_A") ? 1 : 0;
     {
         std::vector<float> apack((size_t)p.n1 * ca.n_tiles * 64);
         hpfw::pack_cols_coefficients(p.n1, ca.k1lo, ca.k1n, reinterpret_cast<const float *>(p.tw_n1.data()),
@@ -266,8 +270,12 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
     HIP_TRY(hipMemsetAsync(mm, 0, (size_t)nb * 4, s));
     {
         Timed t(h, K_ROWS, s);
-        hpfw::launch_pcm_pairs(p.n, p.n1, p.n2, d_pcm, nb, (hpfw::i16x2 *)h->ws[5], s);
-        hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, yp, s);
+        if (dp->rows.pair_stride == 1) {
+            hpfw::launch_pcm_pairs(p.n, p.n1, p.n2, d_pcm, nb, (hpfw::i16x2 *)h->ws[5], s);
+            hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, yp, s);
+        } else {
+            hpfw::launch_fwd_rows(dp->rows, reinterpret_cast<const hpfw::i16x2 *>(d_pcm), nb, yp, s);
+        }
     }
     if ((rc = check_launch("fwd_rows"))) return rc;
     {
@@ -388,7 +396,7 @@ int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out)
 int hpfw_gpu_set_batch(hpfw_gpu *h, int clips)
 {
     if (!h || clips < 0 || clips > 4096) return fail(HPFW_E_INVALID, "batch out of range");
-    h->batch = clips == 0 ? 256 : clips;
+    h->batch = clips == 0 ? 1024 : clips;
     return 0;
 }
 
@@ -462,8 +470,13 @@ int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        hpfw::launch_pcm_pairs(dp->hp.n, dp->hp.n1, dp->hp.n2, d_pcm + c0 * n_samples, nb, (hpfw::i16x2 *)h->ws[5], s);
-        hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, (float *)h->ws[0], s);
+        if (dp->rows.pair_stride == 1) {
+            hpfw::launch_pcm_pairs(dp->hp.n, dp->hp.n1, dp->hp.n2, d_pcm + c0 * n_samples, nb, (hpfw::i16x2 *)h->ws[5], s);
+            hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, (float *)h->ws[0], s);
+        } else {
+            hpfw::launch_fwd_rows(dp->rows, reinterpret_cast<const hpfw::i16x2 *>(d_pcm + c0 * n_samples), nb,
+                                  (float *)h->ws[0], s);
+        }
         if ((rc = check_launch("fwd_rows"))) return rc;
         hpfw::launch_fwd_cols(dp->cols, (const float *)h->ws[0], nb, (hpfw::cf *)d_x + c0 * nk, s);
         if ((rc = check_launch("fwd_cols"))) return rc;

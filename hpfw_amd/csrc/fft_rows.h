@@ -27,6 +27,8 @@ struct RowGroups {
 struct RowsArgs {
     int n1, n2, h;            // N = n1 * n2, h = n2 / 2 + 1
     int hpad;                 // row stride (floats) of the planar output, a multiple of 32
+    int pair_stride;          // distance between consecutive time steps of a pair stream, in pairs:
+                              // 1 after the pcm_pairs pre-pass, n1 / 2 when read in place (n1 even)
     RowGroups groups;
     const cf *gtw;            // per-butterfly twiddles of every group (see group_twiddle_count)
     const cf *tw_big;         // T_N[a * k2]  [n1][h]
@@ -179,7 +181,7 @@ HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x
 #pragma unroll
             for (int e = 0; e < kLd; ++e) {
                 const int t = t0 + e * nthreads;
-                p[e] = pairs[t < n2 ? t : 0];
+                p[e] = pairs[(int64_t)(t < n2 ? t : 0) * a.pair_stride];
             }
 #pragma unroll
             for (int e = 0; e < kLd; ++e) {

@@ -53,16 +53,16 @@ constexpr int kFwdThreads = 384;
 
 template <class Groups>
 __global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, const i16x2 *__restrict__ pairs,
+                                                                  int64_t clip_pitch, int pair_pitch,
                                                                   float *__restrict__ yp)
 {
     cf *lds = reinterpret_cast<cf *>(smem_raw);
     const int p = blockIdx.x;
     const int clip = blockIdx.y;
-    const int np = (a.n1 + 1) / 2;
     const int a0 = 2 * p;
     float *ya = yp + ((int64_t)clip * 2 * a.n1 + 2 * a0) * a.hpad;
     float *yb = (a0 + 1 < a.n1) ? ya + 2 * (int64_t)a.hpad : nullptr;
-    rows_body<Groups>(lds, a, (int)blockDim.x, pairs + ((int64_t)clip * np + p) * a.n2, a0, ya, yb);
+    rows_body<Groups>(lds, a, (int)blockDim.x, pairs + clip * clip_pitch + (int64_t)p * pair_pitch, a0, ya, yb);
 }
 
 // ---- column DFT on the matrix cores --------------------------------------------------------
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, co
 //   cr <  K1 : k1 = k1lo + cr           -> X[n2 k1 + k2]
 //   cr >= K1 : k1' = n1 - 1 - k1        -> X[n2 k1 + (n2 - k2)] = conj(.)      (X[k] = conj X[N - k])
 // One wave = one tile of 32 columns x NT row tiles of 32 (16 complex rows each); no LDS, no barriers.
-constexpr int kColsStep = 8; // MFMA k-steps (residues) per register block
+constexpr int kColsStep = 16; // MFMA k-steps (residues) per register block
 
 template <int NT>
 __global__ __launch_bounds__(256) void fwd_cols_kernel(ColsArgs ca, int tile0, const float *__restrict__ yp,
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void fwd_cols_kernel(ColsArgs ca, int tile0, c
     const int hb = lane >> 5, j = lane & 31;
     const float *bp = yp + (int64_t)clip * 2 * ca.n1 * ca.hpad + (int64_t)hb * ca.hpad + ctile * 32 + j;
     const float *ap = ca.apack + (size_t)tile0 * 64 + lane; // [a][tile][lane]
-    const size_t astep = (size_t)ca.n_tiles * 64;
+    const size_t astep = ca.debug_same_a ? 0 : (size_t)ca.n_tiles * 64;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
@@ -157,15 +157,21 @@ static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, 
         attr_set = true;
     }
     dim3 grid((a.n1 + 1) / 2, n_clips);
-    hipLaunchKernelGGL(fwd_rows_kernel<Groups>, grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, d_pairs, d_yp);
+    // pre-passed stream: [clip][pair][n2]; in place: pair p of time step t at pcm word t n1/2 + p
+    const int64_t clip_pitch = a.pair_stride == 1 ? (int64_t)((a.n1 + 1) / 2) * a.n2 : (int64_t)a.n1 * a.n2 / 2;
+    const int pair_pitch = a.pair_stride == 1 ? a.n2 : 1;
+    hipLaunchKernelGGL(fwd_rows_kernel<Groups>, grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, d_pairs,
+                       clip_pitch, pair_pitch, d_yp);
 }
 
-void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, float *d_yp, hipStream_t s)
+// d_src: the pcm_pairs output when a.pair_stride == 1, otherwise the PCM itself (n1 even: every
+// residue pair is an aligned 4-byte word of the [n2][n1] sample matrix)
+void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_src, int n_clips, float *d_yp, hipStream_t s)
 {
     if (Groups6300::matches(a.groups, 0, a.groups.n))
-        launch_rows_t<Groups6300>(a, d_pairs, n_clips, d_yp, s);
+        launch_rows_t<Groups6300>(a, d_src, n_clips, d_yp, s);
     else
-        launch_rows_t<RuntimeGroups>(a, d_pairs, n_clips, d_yp, s);
+        launch_rows_t<RuntimeGroups>(a, d_src, n_clips, d_yp, s);
 }
 
 void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s)

@@ -15,7 +15,11 @@ from collections import defaultdict
 
 
 def short(name):
-    return name.split("(")[0].replace("hpfw::", "")
+    name = name.replace("void ", "")
+    head = name.split("(")[0]
+    if "<" in head:  # templated kernels: keep the first template argument (size class / group list)
+        head = head.split("<")[0] + "<" + name.split("<", 1)[1].split(">")[0].split(",")[0].strip() + ">"
+    return head.replace("hpfw::", "")
 
 
 def main():
@@ -26,7 +30,7 @@ def main():
     rows = []
     if stats:
         for r in csv.DictReader(open(stats[0])):
-            if r["Name"].startswith("hpfw::"):
+            if "hpfw::" in r["Name"]:
                 rows.append([short(r["Name"]), r["Calls"], r["TotalDurationNs"], f'{float(r["AverageNs"]):.0f}',
                              r["MinNs"], r["MaxNs"], r["Percentage"]])
         with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -40,7 +44,7 @@ def main():
             continue
         acc = defaultdict(lambda: [0.0, 0])
         for r in csv.DictReader(open(files[0])):
-            if r["Kernel_Name"].startswith("hpfw::") and r["Counter_Name"] == counter:
+            if "hpfw::" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 a = acc[short(r["Kernel_Name"])]
                 a[0] += float(r["Counter_Value"])
                 a[1] += 1

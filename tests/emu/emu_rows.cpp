@@ -51,6 +51,7 @@ int main(int argc, char **argv)
     a.h = hp.h;
     for (size_t g = 0; g < hp.groups.size(); ++g) a.groups.tw_off[g] = hp.rows_gtw_off[g];
     a.hpad = (hp.h + 31) / 32 * 32;
+    a.pair_stride = 1;
     a.groups.n = (int)hp.groups.size();
     for (size_t g = 0; g < hp.groups.size(); ++g) {
         a.groups.r1[g] = hp.groups[g].first;
