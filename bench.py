@@ -77,11 +77,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # HPFW_BENCH_REHEARSE_ONE_GPU=1: every rank on cuda:0 with gloo and CPU-side collectives -- only to
+    # rehearse the N > 1 code path on a one-GPU box; the driver's runs use one GPU per rank and RCCL.
+    rehearse = bool(os.environ.get("HPFW_BENCH_REHEARSE_ONE_GPU")) and world > 1
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as tdist
-        tdist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            tdist.init_process_group("gloo")
+        else:
+            tdist.init_process_group("nccl", device_id=device)
 
     def barrier():
         if world > 1:
@@ -90,11 +97,11 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=device)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else device)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         return float(t.item())
 
-    gpu = hpfw_amd.Gpu(local_rank)
+    gpu = hpfw_amd.Gpu(dev_index)
     filt = synth.make_filters()
     gpu.set_filters(filt)
     if args.batch:
@@ -141,7 +148,8 @@ def main():
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_path):
         try:
-            traffic = json.load(open(tr_path)).get("project_mfma_hbm_bytes_per_launch")
+            per_clip = json.load(open(tr_path)).get("project_mfma_hbm_bytes_per_clip")
+            traffic = per_clip * clips_per_launch if per_clip is not None else None   # PMC bytes, per launch
         except Exception:
             traffic = None
     roofline = {"kernel": "project_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
@@ -186,7 +194,7 @@ def main():
     search = None
     if not args.no_search:
         search = bench_search(torch, tdist if world > 1 else None, gpu, hdist, synth, args, rank, world, device,
-                              stream, barrier, max_over_ranks)
+                              stream, barrier, max_over_ranks, rehearse)
 
     if rank == 0:
         line = {
@@ -209,7 +217,8 @@ def main():
         tdist.destroy_process_group()
 
 
-def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, stream, barrier, max_over_ranks):
+def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, stream, barrier, max_over_ranks,
+                 rehearse=False):
     """configs[2] per GPU (configs[3] layout when world > 1): index shard resident in HBM, replicated
     queries, scan + per-shard top-k on every rank, one all-gather of Q x k x 16 B, identical merge."""
     import hpfw_amd
@@ -239,12 +248,16 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
     gpu.index_add_dev(db.data_ptr(), np.arange(0, (n_local + 1) * n_hp, n_hp, dtype=np.int64), stream)
     q_off = np.arange(0, (nq + 1) * kq, kq, dtype=np.int64)
     hits = torch.empty((nq, args.topk, 4), dtype=torch.int32, device=device)
-    gathered = torch.empty((world, nq, args.topk, 4), dtype=torch.int32, device=device) if world > 1 else None
+    gathered = torch.empty((world, nq, args.topk, 4), dtype=torch.int32,
+                           device="cpu" if rehearse else device) if world > 1 else None
 
     def one():
         gpu.search_topk_dev(q.data_ptr(), q_off, args.topk, hits.data_ptr(), stream)
-        if world > 1:
-            tdist.all_gather_into_tensor(gathered, hits)
+        if world > 1 and rehearse:
+            parts = [gathered[i] for i in range(world)]
+            tdist.all_gather(parts, hits.cpu())
+        elif world > 1:
+            tdist.all_gather_into_tensor(gathered, hits)      # RCCL over xGMI: Q x k x 16 B per rank
 
     one()
     torch.cuda.synchronize()

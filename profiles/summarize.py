@@ -5,7 +5,7 @@
   profiles/traffic.json             HBM bytes per launch of the dominant kernel, read by bench.py
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB, and on gfx950 FETCH_SIZE
 reports half of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section).
-usage: python profiles/summarize.py r01 [gpurun_out/prof]"""
+usage: python profiles/summarize.py r01 [gpurun_out/prof] [clips_per_launch=1000]"""
 import csv
 import glob
 import json
@@ -25,6 +25,7 @@ def short(name):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
+    clips = float(sys.argv[3]) if len(sys.argv) > 3 else 1000.0   # clips per back-end launch in the profiled run
     here = os.path.dirname(os.path.abspath(__file__))
     stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
     rows = []
@@ -60,8 +61,9 @@ def main():
         json.dump(pmc, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
         pk = pmc.get("project_kernel", {})
         if "hbm_bytes_per_launch" in pk:
-            json.dump({"project_mfma_hbm_bytes_per_launch": pk["hbm_bytes_per_launch"], "source": f"{tag}_pmc.json",
-                       "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024"},
+            json.dump({"project_mfma_hbm_bytes_per_clip": pk["hbm_bytes_per_launch"] / clips,
+                       "clips_per_launch_profiled": clips, "source": f"{tag}_pmc.json",
+                       "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / clips"},
                       open(os.path.join(here, "traffic.json"), "w"), indent=1)
     print(open(os.path.join(here, f"{tag}_kernel_stats.csv")).read() if rows else "no trace")
     print(json.dumps(pmc, indent=1, sort_keys=True))
