@@ -22,6 +22,9 @@ EXPORTS = (
     "hpfw_gpu_set_filters", "hpfw_gpu_geometry", "hpfw_gpu_extract_pcm16",
     "hpfw_gpu_extract_pcm16_host", "hpfw_gpu_set_batch", "hpfw_gpu_stage_spectrum",
     "hpfw_gpu_stage_cqmag", "hpfw_gpu_stage_db", "hpfw_gpu_stage_project", "hpfw_gpu_stage_pack",
+    "hpfw_gpu_cov_reset", "hpfw_gpu_cov_accumulate_pcm16", "hpfw_gpu_cov_accumulate_pcm16_host",
+    "hpfw_gpu_cov_accumulate_db", "hpfw_gpu_cov_get",
+    "hpfw_gpu_cov_set", "hpfw_gpu_learn_filters", "hpfw_gpu_host_top_eigenvectors",
     "hpfw_gpu_index_clear", "hpfw_gpu_index_add", "hpfw_gpu_index_add_device",
     "hpfw_gpu_index_size", "hpfw_gpu_index_set_clip_base", "hpfw_gpu_search_topk_device",
     "hpfw_gpu_search_topk", "hpfw_gpu_merge_topk", "hpfw_gpu_timer_start", "hpfw_gpu_timer_stop",
@@ -76,6 +79,14 @@ def lib():
     L.hpfw_gpu_stage_db.argtypes = [vp, vp, i64, i64, vp, vp]
     L.hpfw_gpu_stage_project.argtypes = [vp, vp, i64, i64, vp, vp]
     L.hpfw_gpu_stage_pack.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_cov_reset.argtypes = [vp]
+    L.hpfw_gpu_cov_accumulate_pcm16.argtypes = [vp, vp, i64, i64, vp]
+    L.hpfw_gpu_cov_accumulate_pcm16_host.argtypes = [vp, vp, i64, i64]
+    L.hpfw_gpu_cov_accumulate_db.argtypes = [vp, vp, i64, i64, vp]
+    L.hpfw_gpu_cov_get.argtypes = [vp, vp, ctypes.POINTER(i64)]
+    L.hpfw_gpu_cov_set.argtypes = [vp, vp, i64]
+    L.hpfw_gpu_learn_filters.argtypes = [vp, vp]
+    L.hpfw_gpu_host_top_eigenvectors.argtypes = [vp, i32, i32, vp, vp]
     L.hpfw_gpu_index_clear.argtypes = [vp]
     L.hpfw_gpu_index_add.argtypes = [vp, vp, vp, i64]
     L.hpfw_gpu_index_add_device.argtypes = [vp, vp, vp, i64, vp]
@@ -131,7 +142,11 @@ class Gpu:
             lib().hpfw_gpu_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:        # interpreter teardown: the module globals may already be gone
+            pass
 
     # ---- configuration -------------------------------------------------------------------
     def set_filters(self, filters_colmajor):
@@ -176,6 +191,41 @@ class Gpu:
 
     def stage_pack_dev(self, d_proj, n_clips, n_frames, d_hp, stream=0):
         check(lib().hpfw_gpu_stage_pack(self._h, d_proj, n_clips, n_frames, d_hp, stream))
+
+    # ---- filter learning ------------------------------------------------------------------
+    def cov_reset(self):
+        check(lib().hpfw_gpu_cov_reset(self._h))
+
+    def cov_accumulate_dev(self, d_pcm, n_samples, n_clips, stream=0):
+        check(lib().hpfw_gpu_cov_accumulate_pcm16(self._h, d_pcm, n_samples, n_clips, stream))
+
+    def cov_accumulate(self, pcm):
+        """pcm: int16 [n_clips][n_samples] on the host"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        check(lib().hpfw_gpu_cov_accumulate_pcm16_host(self._h, _hp(pcm), pcm.shape[1], pcm.shape[0]))
+
+    def cov_accumulate_db_dev(self, d_db, n_clips, c, stream=0):
+        check(lib().hpfw_gpu_cov_accumulate_db(self._h, d_db, n_clips, c, stream))
+
+    def cov_get(self):
+        """(accum_cov [2420][2420] float32, number of clips accumulated)"""
+        cov = np.zeros((2420, 2420), np.float32)
+        n = ctypes.c_int64(0)
+        check(lib().hpfw_gpu_cov_get(self._h, _hp(cov), ctypes.byref(n)))
+        return cov, int(n.value)
+
+    def cov_set(self, cov, n_files):
+        c = np.ascontiguousarray(cov, np.float32)
+        assert c.shape == (2420, 2420)
+        check(lib().hpfw_gpu_cov_set(self._h, _hp(c), int(n_files)))
+
+    def learn_filters(self):
+        """eigen-solve the accumulated covariance, install and return the filters (flat column-major)"""
+        f = np.zeros(64 * 2420, np.float32)
+        check(lib().hpfw_gpu_learn_filters(self._h, _hp(f)))
+        return f
 
     # ---- index + search ------------------------------------------------------------------
     def index_clear(self):

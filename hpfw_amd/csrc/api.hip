@@ -105,6 +105,14 @@ struct hpfw_gpu {
     size_t best_cap = 0;
     int64_t *d_q_off = nullptr;
     size_t q_off_cap = 0;
+    // filter learning: accum_cov of ParallelCollector (parallel_collector.h:76), upper tiles only
+    float *d_cov = nullptr;
+    float *d_mu = nullptr;
+    float *d_cov_part = nullptr;
+    size_t cov_part_cap = 0;
+    size_t mu_cap = 0;
+    int *d_cov_tiles = nullptr;
+    int64_t cov_files = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned timing_mask = 0;
@@ -352,6 +360,10 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     for (void *p : h->ws)
         if (p) (void)hipFree(p);
     if (h->d_fpack) (void)hipFree(h->d_fpack);
+    if (h->d_cov) (void)hipFree(h->d_cov);
+    if (h->d_mu) (void)hipFree(h->d_mu);
+    if (h->d_cov_part) (void)hipFree(h->d_cov_part);
+    if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
     if (h->d_db) (void)hipFree(h->d_db);
     if (h->d_db_off) (void)hipFree(h->d_db_off);
     if (h->d_best) (void)hipFree(h->d_best);
@@ -553,6 +565,143 @@ int hpfw_gpu_stage_pack(hpfw_gpu *h, const float *d_proj, int64_t n_clips, int64
         hpfw::launch_pack(d_proj + c0 * 64 * n_frames, nb, (int)n_frames, d_hp + c0 * (n_frames - hpfw::kLag), s);
     }
     return check_launch("delta_pack");
+}
+
+// ---- filter learning: preprocess() of the reference (parallel_collector.h:82-112) ---------------
+static int cov_prepare(hpfw_gpu *h, hipStream_t s)
+{
+    if (!h->d_cov) {
+        HIP_TRY(hipMalloc((void **)&h->d_cov, (size_t)hpfw::kFrame * hpfw::kFrame * 4));
+        HIP_TRY(hipMemsetAsync(h->d_cov, 0, (size_t)hpfw::kFrame * hpfw::kFrame * 4, s));
+        h->cov_files = 0;
+    }
+    if (!h->d_cov_tiles) {
+        std::vector<int> xy((size_t)2 * hpfw::cov_tile_count());
+        hpfw::cov_tile_list(xy.data());
+        HIP_TRY(hipMalloc((void **)&h->d_cov_tiles, xy.size() * 4));
+        HIP_TRY(hipMemcpy(h->d_cov_tiles, xy.data(), xy.size() * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int hpfw_gpu_cov_reset(hpfw_gpu *h)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->d_cov) HIP_TRY(hipMemset(h->d_cov, 0, (size_t)hpfw::kFrame * hpfw::kFrame * 4));
+    h->cov_files = 0;
+    return 0;
+}
+
+int hpfw_gpu_cov_accumulate_db(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c, void *stream)
+{
+    if (!h || !d_db || n_clips < 0 || c < hpfw::kCtx + 1) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = cov_prepare(h, s);
+    if (rc) return rc;
+    const int64_t chunk = 4096;
+    if ((rc = ensure((void **)&h->d_mu, &h->mu_cap, (size_t)std::min(chunk, std::max<int64_t>(n_clips, 1)) * hpfw::kFrame * 4)))
+        return rc;
+    if ((rc = ensure((void **)&h->d_cov_part, &h->cov_part_cap,
+                     hpfw::cov_part_bytes((int)std::min(chunk, std::max<int64_t>(n_clips, 1)), (int)c))))
+        return rc;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += chunk) {
+        const int nb = (int)std::min(chunk, n_clips - c0);
+        hpfw::launch_frame_mean(d_db + c0 * 121 * c, nb, (int)c, h->d_mu, s);
+        hpfw::launch_cov(d_db + c0 * 121 * c, h->d_mu, nb, (int)c, h->d_cov_tiles, h->d_cov_part, h->d_cov, s);
+        if ((rc = check_launch("covariance"))) return rc;
+    }
+    h->cov_files += n_clips;
+    return 0;
+}
+
+int hpfw_gpu_cov_accumulate_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,
+                                  void *stream)
+{
+    if (!h || !d_pcm || n_clips < 0) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    DevPlan *dp;
+    int rc = get_plan(h, n_samples, &dp);
+    if (rc) return rc;
+    if (dp->hp.n_frames < 2) return fail(HPFW_E_UNSUPPORTED, "clip too short for a covariance");
+    hipStream_t s = (hipStream_t)stream;
+    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
+    if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
+        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
+        if ((rc = run_front(h, dp, d_pcm + c0 * n_samples, nb, 0, s))) return rc;
+        if ((rc = hpfw_gpu_cov_accumulate_db(h, (const float *)h->ws[2], nb, dp->hp.c, stream))) return rc;
+    }
+    return 0;
+}
+
+int hpfw_gpu_cov_accumulate_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples, int64_t n_clips)
+{
+    if (!h || !pcm || n_clips < 0) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_clips == 0) return 0;
+    int16_t *d_pcm = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_pcm, (size_t)n_clips * n_samples * 2));
+    int rc = 0;
+    if (hipMemcpy(d_pcm, pcm, (size_t)n_clips * n_samples * 2, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (!rc) rc = hpfw_gpu_cov_accumulate_pcm16(h, d_pcm, n_samples, n_clips, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(HPFW_E_HIP, "kernel execution failed");
+    (void)hipFree(d_pcm);
+    return rc;
+}
+
+// full symmetric matrix, row-major 2420 x 2420 (= the column-major Eigen matrix of accum_cov.cereal)
+int hpfw_gpu_cov_get(hpfw_gpu *h, float *cov, int64_t *n_files)
+{
+    if (!h || !cov) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nn = (size_t)hpfw::kFrame * hpfw::kFrame;
+    if (!h->d_cov) {
+        std::memset(cov, 0, nn * 4);
+    } else {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(cov, h->d_cov, nn * 4, hipMemcpyDeviceToHost));
+        // the device holds tiles on or above the diagonal (128-wide); mirror them
+        for (int r = 0; r < hpfw::kFrame; ++r)
+            for (int c2 = 0; c2 < r; ++c2)
+                if (c2 / 128 < r / 128) cov[(size_t)r * hpfw::kFrame + c2] = cov[(size_t)c2 * hpfw::kFrame + r];
+    }
+    if (n_files) *n_files = h->cov_files;
+    return 0;
+}
+
+int hpfw_gpu_cov_set(hpfw_gpu *h, const float *cov, int64_t n_files)
+{
+    if (!h || !cov || n_files < 0) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = cov_prepare(h, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(h->d_cov, cov, (size_t)hpfw::kFrame * hpfw::kFrame * 4, hipMemcpyHostToDevice));
+    h->cov_files = n_files;
+    return 0;
+}
+
+// calc_filters (hashprint_handle.h:105-112): eigenvectors of the accumulated covariance by descending
+// eigenvalue, the first 64 as rows; they become the handle's filters.  filters_out (optional) receives
+// them in the reference's column-major layout.
+int hpfw_gpu_learn_filters(hpfw_gpu *h, float *filters_out)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    if (!h->d_cov || h->cov_files == 0) return fail(HPFW_E_INVALID, "no covariance accumulated");
+    std::vector<float> cov((size_t)hpfw::kFrame * hpfw::kFrame);
+    int rc = hpfw_gpu_cov_get(h, cov.data(), nullptr);
+    if (rc) return rc;
+    std::vector<float> rows((size_t)hpfw::kFilters * hpfw::kFrame);
+    if (hpfw::top_eigenvectors(cov.data(), hpfw::kFrame, hpfw::kFilters, rows.data(), nullptr) != 0)
+        return fail(HPFW_E_INVALID, "eigen-solve failed");
+    std::vector<float> colmajor((size_t)hpfw::kFilters * hpfw::kFrame);
+    for (int r = 0; r < hpfw::kFilters; ++r)
+        for (int k = 0; k < hpfw::kFrame; ++k) colmajor[(size_t)r + 64 * (size_t)k] = rows[(size_t)r * hpfw::kFrame + k];
+    if ((rc = hpfw_gpu_set_filters(h, colmajor.data()))) return rc;
+    if (filters_out) std::memcpy(filters_out, colmajor.data(), colmajor.size() * 4);
+    return 0;
 }
 
 // ---- index + search ----------------------------------------------------------------------------

@@ -175,7 +175,7 @@ HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x
     HPFW_FOR_THREADS(tid, nthreads)
     {
         // loads in batches of kLd so that their latencies overlap
-        constexpr int kLd = 6;
+        constexpr int kLd = 9;
         for (int t0 = tid; t0 < n2; t0 += kLd * nthreads) {
             i16x2 p[kLd];
 #pragma unroll
@@ -197,7 +197,7 @@ HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x
     const cf *__restrict__ twa = a.tw_big + (int64_t)a0 * a.h;
     const cf *__restrict__ twb = yb ? twa + a.h : twa;
     const int *__restrict__ pos = a.pos_n2;
-    constexpr int kEpi = 4;
+    constexpr int kEpi = 9;
     HPFW_FOR_THREADS(tid, nthreads)
     {
         for (int k0 = tid; k0 < a.h; k0 += kEpi * nthreads) {

@@ -144,6 +144,16 @@ void par_collector_load(hpfw_legacy_collector *c, const char *cache)
         c->filters.swap(f);
         (void)hpfw_gpu_set_filters(c->gpu, c->filters.data());
     }
+    // accum_cov.cereal (cache.h:34-36): int32 2420, int32 2420, 2420^2 floats (symmetric, so the
+    // column-major payload is also row-major); the reference keeps accumulating across runs
+    std::ifstream is(c->cache_dir + "accum_cov.cereal", std::ios::binary);
+    int32_t rows = 0, cols = 0;
+    if (is && is.read(reinterpret_cast<char *>(&rows), 4) && is.read(reinterpret_cast<char *>(&cols), 4) &&
+        rows == HPFW_FRAME_SIZE && cols == HPFW_FRAME_SIZE) {
+        std::vector<float> cov((size_t)rows * cols);
+        if (is.read(reinterpret_cast<char *>(cov.data()), (std::streamsize)cov.size() * 4))
+            (void)hpfw_gpu_cov_set(c->gpu, cov.data(), 1);
+    }
 }
 
 void par_collector_save(hpfw_legacy_collector *c, const char *cache)
@@ -156,6 +166,15 @@ void par_collector_save(hpfw_legacy_collector *c, const char *cache)
     std::error_code ec;
     std::filesystem::create_directories(c->cache_dir, ec);
     (void)save_filters_cereal(c->cache_dir + "filters.cereal", c->filters);
+    std::vector<float> cov((size_t)HPFW_FRAME_SIZE * HPFW_FRAME_SIZE);
+    int64_t n_files = 0;
+    if (hpfw_gpu_cov_get(c->gpu, cov.data(), &n_files) == 0 && n_files > 0) { // cache.h:34-36
+        std::ofstream os(c->cache_dir + "accum_cov.cereal", std::ios::binary);
+        const int32_t dim = HPFW_FRAME_SIZE;
+        os.write(reinterpret_cast<const char *>(&dim), 4);
+        os.write(reinterpret_cast<const char *>(&dim), 4);
+        os.write(reinterpret_cast<const char *>(cov.data()), (std::streamsize)cov.size() * 4);
+    }
 }
 
 uint64_t *par_collector_calc_hashprint(hpfw_legacy_collector *c, const char *filename, int *size)
@@ -192,6 +211,26 @@ FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const cha
 {
     if (got) *got = 0;
     if (!c || !filenames || n < 0 || !got) return nullptr;
+    // preprocess (parallel_collector.h:82-112): add every file's frame covariance to accum_cov, take the
+    // 64 leading eigenvectors as the new filters, save().  HPFW_PREPARE_KEEP_FILTERS=1 skips this step
+    // and keeps the filters that load() / a previous prepare() installed.
+    if (!(std::getenv("HPFW_PREPARE_KEEP_FILTERS") && !c->filters.empty())) {
+        int used = 0;
+        for (int i = 0; i < n; ++i) {
+            std::vector<int16_t> pcm;
+            std::string why;
+            if (!read_wav_pcm16_mono(filenames[i], pcm, why)) continue; // skipped, parallel_collector.h:101-103
+            if (hpfw_gpu_cov_accumulate_pcm16_host(c->gpu, pcm.data(), (int64_t)pcm.size(), 1) == 0) ++used;
+        }
+        if (used > 0) {
+            c->filters.assign((size_t)HPFW_FILTERS * HPFW_FRAME_SIZE, 0.0f);
+            if (hpfw_gpu_learn_filters(c->gpu, c->filters.data()) != 0) {
+                c->filters.clear();
+                return nullptr;
+            }
+            par_collector_save(c, nullptr);
+        }
+    }
     auto *res = new FilenameHashprintPair[(size_t)(n > 0 ? n : 1)];
     int w = 0;
     for (int i = 0; i < n; ++i) {

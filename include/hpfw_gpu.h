@@ -111,6 +111,26 @@ int hpfw_gpu_stage_project(hpfw_gpu *h, const float *d_db, int64_t n_clips, int6
 int hpfw_gpu_stage_pack(hpfw_gpu *h, const float *d_proj, int64_t n_clips, int64_t n_frames,
                         uint64_t *d_hp, void *stream);
 
+/* ---- filter learning: ParallelCollector::preprocess + calc_filters ------------------------
+ * (parallel_collector.h:82-112, hashprint_handle.h:96-112).  The handle owns accum_cov
+ * (2420 x 2420, parallel_collector.h:76): per clip, the covariance of its context frames (centred
+ * on the clip's own mean, / (n_frames - 1)) is added on the GPU (f32 MFMA); learn_filters takes the
+ * eigenvectors of the 64 largest eigenvalues on the host and installs them as the filters.
+ * Eigenvector signs are arbitrary in the reference; here the largest component is positive. */
+int hpfw_gpu_cov_reset(hpfw_gpu *h);
+int hpfw_gpu_cov_accumulate_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,
+                                  void *stream);
+int hpfw_gpu_cov_accumulate_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples, int64_t n_clips);
+/* stage entry point: from dB spectrograms d_db [n_clips][121][C] */
+int hpfw_gpu_cov_accumulate_db(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c, void *stream);
+/* host copies of accum_cov (full symmetric 2420 x 2420 floats; synchronises) and the file count */
+int hpfw_gpu_cov_get(hpfw_gpu *h, float *cov, int64_t *n_files);
+int hpfw_gpu_cov_set(hpfw_gpu *h, const float *cov, int64_t n_files);
+/* filters_colmajor_out may be NULL; layout as hpfw_gpu_set_filters */
+int hpfw_gpu_learn_filters(hpfw_gpu *h, float *filters_colmajor_out);
+/* host-only: unit eigenvectors of the m largest eigenvalues of a symmetric n x n float matrix */
+int hpfw_gpu_host_top_eigenvectors(const float *cov, int n, int m, float *out, double *evals);
+
 /* ---- index + search: MemoryStorage::build / find ----------------------------------------- */
 int hpfw_gpu_index_clear(hpfw_gpu *h);
 /* appends n_clips hashprints; clip i is hp[offsets[i] .. offsets[i+1]); host or device source */

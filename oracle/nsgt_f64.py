@@ -85,3 +85,22 @@ def pack(proj):
     bits = (d >= 0)
     w = (np.uint64(1) << np.arange(63, -1, -1, dtype=np.uint64))
     return (bits.astype(np.uint64) * w[:, None]).sum(axis=0, dtype=np.uint64)
+
+
+def frames(s_db):
+    """hashprint_handle.h:79-93: frames[b*20 + t, n] = S[b, n + t], float64 [2420][C-19]"""
+    s = np.asarray(s_db, np.float64)
+    nf = s.shape[1] - 19
+    out = np.zeros((BINS * 20, nf))
+    for b in range(BINS):
+        for t in range(20):
+            out[b * 20 + t] = s[b, t:t + nf]
+    return out
+
+
+def covariance(s_db):
+    """hashprint_handle.h:96-102 on frames^T: centre every component on its mean over the frames,
+    centred^T centred / (n_frames - 1); float64 [2420][2420]"""
+    x = frames(s_db)
+    xc = x - x.mean(axis=1, keepdims=True)
+    return xc @ xc.T / (x.shape[1] - 1)

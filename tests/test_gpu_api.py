@@ -48,7 +48,11 @@ def test_legacy_ffi_through_python_twin(wav_set, oracle, filters):
     with pytest.raises(hpfw_amd.HpfwError):            # no filters yet: an error, never garbage (D-9)
         pc.calc_hashprint(paths[0])
     pc.load(cache)
-    res = pc.prepare(paths + [str(d / "missing.wav")])  # a bad file is skipped, as parallel_collector.h:101-103
+    os.environ["HPFW_PREPARE_KEEP_FILTERS"] = "1"        # use the loaded fixture instead of re-learning
+    try:
+        res = pc.prepare(paths + [str(d / "missing.wav")])  # a bad file is skipped, as parallel_collector.h:101-103
+    finally:
+        del os.environ["HPFW_PREPARE_KEEP_FILTERS"]
     assert [name for _, name in res] == [f"track{i:02d}" for i in range(4)]
     plan = oracle.Plan(clips[0].size)
     for (hp, _), c in zip(res, clips):

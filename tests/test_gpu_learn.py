@@ -1,0 +1,97 @@
+"""GPU tests of the filter-learning path: frame covariance on f32 MFMA
+against a float64 numpy evaluation (tolerance: the reference's own result depends on MKL's
+summation order), the host eigen-solve, and extraction with the learned filters against the
+oracle (bit-exact: once the filters are fixed the path is the same as everywhere else)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import hpfw_amd  # noqa: E402
+from hpfw_amd import synth  # noqa: E402
+from oracle import nsgt_f64  # noqa: E402
+
+
+def test_covariance_against_float64(torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    g = hpfw_amd.Gpu(0)
+    total = np.zeros((2420, 2420))
+    for c, n_clips in ((150, 2), (300, 1), (277, 3)):       # odd frame counts and partial chunks included
+        s = rng.uniform(-80, 0, (n_clips, 121, c)).astype(np.float32)
+        s[:, ::7, :] *= 0.1
+        d_s = torch.from_numpy(s).cuda()
+        g.cov_accumulate_db_dev(d_s.data_ptr(), n_clips, c)
+        for x in s:
+            total += nsgt_f64.covariance(x)
+    cov, n_files = g.cov_get()
+    assert n_files == 6
+    assert np.array_equal(cov, cov.T)
+    assert np.abs(cov - total).max() / np.abs(total).max() < 2e-5
+    g.cov_reset()
+    cov0, n0 = g.cov_get()
+    assert n0 == 0 and not cov0.any()
+    g.close()
+
+
+def test_learn_filters_and_extract(torch_cuda, oracle):
+    clips = np.stack([synth.gen_clip(700 + i, 3.0) for i in range(6)])
+    g = hpfw_amd.Gpu(0)
+    with pytest.raises(hpfw_amd.HpfwError):
+        g.learn_filters()                                    # nothing accumulated yet
+    g.cov_accumulate(clips[:4])
+    g.cov_accumulate(clips[4:])
+    cov, n_files = g.cov_get()
+    assert n_files == 6
+    # float64 reference of the whole chain up to the covariance, from the oracle's dB spectrograms
+    plan = oracle.Plan(clips.shape[1])
+    ref = sum(nsgt_f64.covariance(oracle.db(plan.cqmag(plan.spectrum(c)))) for c in clips)
+    assert np.abs(cov - ref).max() / np.abs(ref).max() < 5e-5
+    filt = g.learn_filters()
+    rows = synth.filters_rows(filt)                          # [64][2420]
+    assert np.abs(rows @ rows.T - np.eye(64)).max() < 1e-5
+    w, v = np.linalg.eigh(cov.astype(np.float64))
+    w, v = w[::-1], v[:, ::-1]
+    ray = np.einsum("rk,kl,rl->r", rows, cov.astype(np.float64), rows)
+    assert np.abs(ray - w[:64]).max() / w[0] < 1e-5          # Rayleigh quotients = leading eigenvalues
+    gaps = (w[:64] - w[1:65]) / w[0]
+    sep = gaps > 1e-4                                        # well separated: the vector itself is determined
+    dots = np.abs(np.sum(rows * v[:, :64].T, axis=1))
+    assert dots[sep].min() > 0.999
+    assert (rows[np.arange(64), np.abs(rows).argmax(axis=1)] > 0).all()   # sign convention
+    hp = g.extract(clips)
+    want = np.stack([plan.extract(filt, c) for c in clips])
+    assert np.array_equal(hp, want)
+    # the covariance can be saved and restored: same filters
+    g2 = hpfw_amd.Gpu(0)
+    g2.cov_set(cov, n_files)
+    assert np.array_equal(g2.learn_filters(), filt)
+    g.close()
+    g2.close()
+
+
+def test_legacy_prepare_learns_and_persists(torch_cuda, oracle, tmp_path):
+    clips = [synth.gen_clip(720 + i, 3.0) for i in range(5)]
+    paths = []
+    for i, c in enumerate(clips):
+        p = str(tmp_path / f"song{i}.wav")
+        synth.write_wav(p, c)
+        paths.append(p)
+    cache = str(tmp_path / "cache") + "/"
+    pc = hpfw_amd.ParallelCollector()
+    pc.load(cache)                                           # nothing there yet: silent (cache.h:77-79)
+    res = pc.prepare(paths)                                  # preprocess: covariance -> filters -> save
+    assert [n for _, n in res] == [f"song{i}" for i in range(5)]
+    raw = open(os.path.join(cache, "filters.cereal"), "rb").read()
+    assert raw[:8] == np.array([64, 2420], np.int32).tobytes()
+    filt = np.frombuffer(raw[8:], np.float32)
+    plan = oracle.Plan(clips[0].size)
+    for (hp, _), c in zip(res, clips):
+        assert np.array_equal(hp, plan.extract(filt, c))
+    rawc = open(os.path.join(cache, "accum_cov.cereal"), "rb").read()
+    assert rawc[:8] == np.array([2420, 2420], np.int32).tobytes() and len(rawc) == 8 + 4 * 2420 * 2420
+    pc2 = hpfw_amd.ParallelCollector()                       # a new process would do exactly this
+    pc2.load(cache)
+    assert np.array_equal(pc2.calc_hashprint(paths[2]), res[2][0])

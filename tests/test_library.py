@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b((?:hpfw_gpu|par_collector)_\w+|prepare_result_free|calc_hashprint_result_free)\s*\(",
                               header))
-    assert len(declared) >= 34
+    assert len(declared) >= 42
     L = hpfw_amd.lib()
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
@@ -63,6 +63,29 @@ def test_merge_topk_host():
     m = hpfw_amd.merge_topk(h, 3)
     assert [tuple(int(v) for v in x)[:3] for x in m[0]] == [(4, 20, 9), (5, 0, 1), (5, 10, 1)]
     assert tuple(int(v) for v in m[1, 0])[:3] == (7, 12, 3) and m[1, 1]["clip"] == 0xFFFFFFFF
+
+
+def test_host_eigen_solver_against_numpy():
+    """calc_filters' eigen-solve (hashprint_handle.h:105-112) on the host: leading eigenpairs of a
+    covariance-like matrix against numpy.linalg.eigh"""
+    import ctypes
+    rng = np.random.default_rng(4)
+    n, m = 300, 24
+    x = rng.standard_normal((n, 900)) * np.linspace(4, 0.2, n)[:, None]
+    x = np.linalg.qr(rng.standard_normal((n, n)))[0] @ x
+    a = (x @ x.T / 900).astype(np.float32)
+    out = np.zeros((m, n), np.float32)
+    ev = np.zeros(m)
+    rc = hpfw_amd.lib().hpfw_gpu_host_top_eigenvectors(a.ctypes.data_as(ctypes.c_void_p), n, m,
+                                                       out.ctypes.data_as(ctypes.c_void_p),
+                                                       ev.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    w, v = np.linalg.eigh(a.astype(np.float64))
+    w, v = w[::-1], v[:, ::-1]
+    assert np.abs(ev - w[:m]).max() / w[0] < 1e-12
+    assert np.abs(out @ out.T - np.eye(m)).max() < 1e-5
+    assert np.abs(np.sum(out * v[:, :m].T, axis=1)).min() > 0.99999
+    assert (out[np.arange(m), np.abs(out).argmax(axis=1)] > 0).all()
 
 
 def test_missing_library_is_an_error(monkeypatch):
