@@ -45,3 +45,32 @@ def _all_gather_list(out, t, group):
     import torch.distributed as dist
     parts = [out[i] for i in range(out.shape[0])]
     dist.all_gather(parts, t, group=group)
+
+
+def learn_filters_sharded(gpu, group=None, device=None):
+    """Filter learning over ranks (reference parallel_collector.h:82-112 accumulates one accum_cov
+    over all files): every rank has accumulated the covariance of its own shard of clips on `gpu`;
+    the matrices and the file counts are summed with one all-reduce (23 MB), rank 0 solves for the
+    64 leading eigenvectors and broadcasts them, and every rank installs the same filters.
+    Returns the filters (flat, column-major [64][2420])."""
+    import torch
+    import torch.distributed as dist
+    cov, n_files = gpu.cov_get()
+    t = torch.from_numpy(cov)
+    cnt = torch.tensor([n_files], dtype=torch.int64)
+    if device is not None:
+        t, cnt = t.to(device), cnt.to(device)
+    dist.all_reduce(t, group=group)
+    dist.all_reduce(cnt, group=group)
+    total = t.cpu().numpy()
+    total = np.triu(total) + np.triu(total, 1).T          # exactly symmetric whatever the reduction order
+    gpu.cov_set(total, int(cnt.item()))
+    f = torch.zeros(64 * 2420, dtype=torch.float32)
+    if dist.get_rank(group) == 0:
+        f = torch.from_numpy(gpu.learn_filters())
+    if device is not None:
+        f = f.to(device)
+    dist.broadcast(f, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    filt = f.cpu().numpy()
+    gpu.set_filters(filt)
+    return filt

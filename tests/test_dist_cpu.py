@@ -62,6 +62,75 @@ def test_sharded_search_equals_single_rank():
         assert np.array_equal(merged, want)
 
 
+class _HostLearner:
+    """Stands in for hpfw_amd.Gpu in the build container: holds a covariance on the host and solves
+    with the product's own host eigen-solver (hpfw_gpu_host_top_eigenvectors needs no GPU)."""
+
+    def __init__(self, cov, n_files):
+        self.cov, self.n, self.filters = cov, n_files, None
+
+    def cov_get(self):
+        return self.cov.copy(), self.n
+
+    def cov_set(self, cov, n_files):
+        self.cov, self.n = np.array(cov, np.float32), n_files
+
+    def learn_filters(self):
+        import ctypes
+        import hpfw_amd
+        nn = self.cov.shape[0]
+        rows = np.zeros((64, nn), np.float32)
+        rc = hpfw_amd.lib().hpfw_gpu_host_top_eigenvectors(self.cov.ctypes.data_as(ctypes.c_void_p), nn, 64,
+                                                           rows.ctypes.data_as(ctypes.c_void_p), None)
+        assert rc == 0
+        return np.ascontiguousarray(rows.T).ravel()          # column-major [64][nn]
+
+    def set_filters(self, f):
+        self.filters = np.array(f)
+
+
+def _shard_cov(rank):
+    rng = np.random.default_rng(100 + rank)
+    x = rng.standard_normal((2420, 400)).astype(np.float32) * np.linspace(3, 0.1, 2420, dtype=np.float32)[:, None]
+    return (x @ x.T / 399).astype(np.float32)
+
+
+def _learn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from hpfw_amd import dist as hdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = _HostLearner(_shard_cov(rank), 3 + rank)
+    f = hdist.learn_filters_sharded(g)
+    q.put((rank, f.tobytes(), g.filters.tobytes(), g.n, g.cov.tobytes()))
+    dist.destroy_process_group()
+
+
+def test_sharded_filter_learning():
+    """covariances of the shards are summed, rank 0 solves, every rank ends with the same filters"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_learn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == got[0][2] == got[1][2]
+    assert got[0][3] == got[1][3] == 7
+    total = np.frombuffer(got[0][4], np.float32).reshape(2420, 2420)
+    want = _shard_cov(0) + _shard_cov(1)
+    assert np.abs(total - want).max() <= 1e-6 * np.abs(want).max()
+    rows = np.frombuffer(got[0][1], np.float32).reshape(2420, 64).T
+    w = np.linalg.eigvalsh(want.astype(np.float64))[::-1]
+    ray = np.einsum("rk,kl,rl->r", rows, want.astype(np.float64), rows)
+    assert np.abs(ray - w[:64]).max() / w[0] < 1e-5
+
+
 def test_shard_range_covers_everything():
     from hpfw_amd.dist import shard_range
     for n in (0, 1, 7, 8, 100000, 12345):
