@@ -28,6 +28,7 @@ EXPORTS = (
     "hpfw_gpu_index_clear", "hpfw_gpu_index_add", "hpfw_gpu_index_add_device",
     "hpfw_gpu_index_size", "hpfw_gpu_index_set_clip_base", "hpfw_gpu_search_topk_device",
     "hpfw_gpu_search_topk", "hpfw_gpu_merge_topk", "hpfw_gpu_timer_start", "hpfw_gpu_timer_stop",
+    "hpfw_gpu_index_get", "hpfw_gpu_extract_db_host",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_save", "par_collector_load",
@@ -98,6 +99,8 @@ def lib():
     L.hpfw_gpu_merge_topk.argtypes = [vp, i32, i64, i32, vp]
     L.hpfw_gpu_timer_start.argtypes = [vp, vp]
     L.hpfw_gpu_timer_stop.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.hpfw_gpu_index_get.argtypes = [vp, vp, vp, ctypes.c_int64]
+    L.hpfw_gpu_extract_db_host.argtypes = [vp, vp, i32, i32, vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.hpfw_gpu_set_kernel_timing.argtypes = [vp, i32]
     L.hpfw_gpu_get_kernel_timing.argtypes = [vp, vp, vp, vp, ctypes.POINTER(i32)]
     L.hpfw_gpu_plan_checksum.argtypes = [i64, vp]
@@ -239,6 +242,24 @@ class Gpu:
     def index_add_dev(self, d_hp, offsets, stream=0):
         off = np.ascontiguousarray(offsets, np.int64)
         check(lib().hpfw_gpu_index_add_device(self._h, d_hp, _hp(off), off.size - 1, stream))
+
+    def index_get(self):
+        """(hashprints uint64 [total], offsets int64 [n_clips + 1]) copied back from HBM"""
+        off = np.zeros(self.index_size() + 1, np.int64)
+        check(lib().hpfw_gpu_index_get(self._h, _hp(off), None, 0))
+        hp = np.zeros(int(off[-1]), np.uint64)
+        check(lib().hpfw_gpu_index_get(self._h, _hp(off), _hp(hp), hp.size))
+        return hp, off
+
+    def extract_db(self, s_colmajor):
+        """hashprints of a cached dB spectrogram: s_colmajor float32 [cols][121] (Eigen column-major
+        [121 x cols] as cache/spectros/<stem> holds it)"""
+        s = np.ascontiguousarray(s_colmajor, np.float32)
+        cols, rows = s.shape
+        n = ctypes.c_int64(0)
+        hp = np.zeros(max(cols - 99, 0), np.uint64)
+        check(lib().hpfw_gpu_extract_db_host(self._h, _hp(s), rows, cols, _hp(hp), hp.size, ctypes.byref(n)))
+        return hp[:n.value]
 
     def index_size(self):
         return int(lib().hpfw_gpu_index_size(self._h))

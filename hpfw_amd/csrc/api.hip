@@ -567,6 +567,40 @@ int hpfw_gpu_stage_pack(hpfw_gpu *h, const float *d_proj, int64_t n_clips, int64
     return check_launch("delta_pack");
 }
 
+// Hashprints of one cached dB spectrogram (collect_fingerprints over cache.get_spectros(),
+// parallel_collector.h:114-137; file layout utils.h:77-106: Eigen column-major [rows = 121][cols]).
+// The caller passes the matrix as stored; it is transposed to the bin-major device layout here.
+int hpfw_gpu_extract_db_host(hpfw_gpu *h, const float *s_colmajor, int32_t rows, int32_t cols, uint64_t *hp,
+                             int64_t hp_cap, int64_t *n_hp)
+{
+    if (!h || !s_colmajor || !n_hp) return fail(HPFW_E_INVALID, "null argument");
+    if (rows != hpfw::kBins) return fail(HPFW_E_INVALID, "a spectrogram has 121 rows");
+    if (!h->has_filters) return fail(HPFW_E_NOFILTERS, "no filters set");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t nf = (int64_t)cols - (hpfw::kCtx - 1), nh = nf - hpfw::kLag;
+    *n_hp = nh > 0 ? nh : 0;
+    if (nh <= 0) return 0; // too short: no hashprints (hashprint_handle.h:118: empty fingerprint)
+    if (!hp || hp_cap < nh) return fail(HPFW_E_INVALID, "hashprint buffer too small");
+    std::vector<float> binmajor((size_t)rows * cols);
+    for (int32_t c = 0; c < cols; ++c)
+        for (int32_t b = 0; b < rows; ++b) binmajor[(size_t)b * cols + c] = s_colmajor[(size_t)c * rows + b];
+    float *d_s = nullptr, *d_p = nullptr;
+    uint64_t *d_h = nullptr;
+    int rc = 0;
+    if (hipMalloc((void **)&d_s, binmajor.size() * 4) != hipSuccess || hipMalloc((void **)&d_p, (size_t)64 * nf * 4) != hipSuccess ||
+        hipMalloc((void **)&d_h, (size_t)nh * 8) != hipSuccess)
+        rc = fail(HPFW_E_HIP, "out of device memory");
+    if (!rc && hipMemcpy(d_s, binmajor.data(), binmajor.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (!rc) rc = hpfw_gpu_stage_project(h, d_s, 1, cols, d_p, nullptr);
+    if (!rc) rc = hpfw_gpu_stage_pack(h, d_p, 1, nf, d_h, nullptr);
+    if (!rc && hipMemcpy(hp, d_h, (size_t)nh * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(HPFW_E_HIP, "D2H copy failed");
+    if (d_s) (void)hipFree(d_s);
+    if (d_p) (void)hipFree(d_p);
+    if (d_h) (void)hipFree(d_h);
+    return rc;
+}
+
 // ---- filter learning: preprocess() of the reference (parallel_collector.h:82-112) ---------------
 static int cov_prepare(hpfw_gpu *h, hipStream_t s)
 {
@@ -755,6 +789,23 @@ int hpfw_gpu_index_add_device(hpfw_gpu *h, const uint64_t *d_hp, const int64_t *
 }
 
 int64_t hpfw_gpu_index_size(hpfw_gpu *h) { return h ? (int64_t)h->db_off.size() - 1 : 0; }
+
+// the index back on the host (MemoryStorage::save, storage.h:67-75, dumps the whole db):
+// offsets [n_clips + 1] always; hp [offsets[n_clips]] when hp != NULL and hp_cap is large enough
+int hpfw_gpu_index_get(hpfw_gpu *h, int64_t *offsets, uint64_t *hp, int64_t hp_cap)
+{
+    if (!h || !offsets) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::memcpy(offsets, h->db_off.data(), h->db_off.size() * sizeof(int64_t));
+    if (!hp) return 0;
+    const int64_t total = h->db_off.back();
+    if (hp_cap < total) return fail(HPFW_E_INVALID, "hashprint buffer too small for the index");
+    if (total) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(hp, h->d_db, (size_t)total * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
 
 int hpfw_gpu_index_set_clip_base(hpfw_gpu *h, uint32_t base)
 {

@@ -7,9 +7,10 @@
 // Same public surface: Hashprint, FilenameFingerprintPair, prepare(), calc_hashprint(), save(),
 // load().  Differences, all deliberate:
 //   - audio files must be PCM16 WAV at 44.1 kHz (decode/resample are outside the accelerated path);
-//   - filters are not learned here: load() must find <cache>/filters.cereal (the reference's own
-//     file, utils.h:84-90) or set_filters() must be called; otherwise prepare()/calc_hashprint()
-//     throw instead of projecting with uninitialised filters (reference defect D-9);
+//   - prepare() learns the filters as the reference's preprocess() does (covariance of the frames
+//     of every file, 64 leading eigenvectors; parallel_collector.h:82-112) unless the environment
+//     variable HPFW_PREPARE_KEEP_FILTERS is set and filters were loaded; calc_hashprint() before any
+//     filters exist throws instead of projecting with uninitialised filters (reference defect D-9);
 //   - prepare() returns results in input order (the reference's order is racy, :129).
 #pragma once
 

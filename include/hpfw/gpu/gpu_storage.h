@@ -7,7 +7,9 @@
 #pragma once
 
 #include <cstdint>
+#include <fstream>
 #include <limits>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -73,14 +75,67 @@ public:
 
     size_t size() const { return names_.size(); }
 
+    /// storage.h:67-75: the cereal BinaryOutputArchive image of std::vector<FilenameFingerprintPair>
+    /// (parallel_collector.h:26-35): u64 count, then per entry u64 length + bytes of the filename and
+    /// u64 length + that many u64 hashprints.  A dump written by the reference loads here and vice versa.
+    auto save(const std::optional<std::string> &filename) const -> std::string
+    {
+        const auto dump_name = filename.value_or("db/dump.cereal");
+        std::vector<int64_t> off(names_.size() + 1, 0);
+        check(hpfw_gpu_index_get(h_, off.data(), nullptr, 0));
+        std::vector<uint64_t> all((size_t)off.back());
+        check(hpfw_gpu_index_get(h_, off.data(), all.empty() ? &dummy_ : all.data(), (int64_t)all.size()));
+        std::ofstream os(dump_name, std::ios::binary);
+        if (!os) throw std::runtime_error("hpfw::db::GpuStorage: cannot write " + dump_name);
+        put(os, (uint64_t)names_.size());
+        for (size_t i = 0; i < names_.size(); ++i) {
+            put(os, (uint64_t)names_[i].size());
+            os.write(names_[i].data(), (std::streamsize)names_[i].size());
+            const uint64_t n = (uint64_t)(off[i + 1] - off[i]);
+            put(os, n);
+            os.write(reinterpret_cast<const char *>(all.data() + off[i]), (std::streamsize)(n * 8));
+        }
+        if (!os) throw std::runtime_error("hpfw::db::GpuStorage: write failed: " + dump_name);
+        return dump_name;
+    }
+
+    /// storage.h:78-86
+    auto load(const std::string &dump_name) -> GpuStorage &
+    {
+        std::ifstream is(dump_name, std::ios::binary);
+        if (!is) throw std::runtime_error("hpfw::db::GpuStorage: cannot read " + dump_name);
+        struct Pair {
+            std::string filename;
+            std::vector<uint64_t> fingerprint;
+        };
+        std::vector<Pair> db((size_t)get(is, dump_name));
+        for (Pair &p : db) {
+            p.filename.resize((size_t)get(is, dump_name));
+            is.read(p.filename.data(), (std::streamsize)p.filename.size());
+            p.fingerprint.resize((size_t)get(is, dump_name));
+            is.read(reinterpret_cast<char *>(p.fingerprint.data()), (std::streamsize)(p.fingerprint.size() * 8));
+            if (!is) throw std::runtime_error("hpfw::db::GpuStorage: truncated dump " + dump_name);
+        }
+        build(db);
+        return *this;
+    }
+
 private:
+    static void put(std::ostream &os, uint64_t v) { os.write(reinterpret_cast<const char *>(&v), 8); }
+    static uint64_t get(std::istream &is, const std::string &name)
+    {
+        uint64_t v = 0;
+        is.read(reinterpret_cast<char *>(&v), 8);
+        if (!is || v > (uint64_t(1) << 40)) throw std::runtime_error("hpfw::db::GpuStorage: malformed dump " + name);
+        return v;
+    }
     static void check(int rc)
     {
         if (rc != 0) throw std::runtime_error(std::string("hpfw::db::GpuStorage: ") + hpfw_gpu_last_error());
     }
     hpfw_gpu *h_ = nullptr;
     std::vector<std::string> names_;
-    uint64_t dummy_ = 0;
+    mutable uint64_t dummy_ = 0;
 };
 
 } // namespace hpfw::db

@@ -131,6 +131,13 @@ int hpfw_gpu_learn_filters(hpfw_gpu *h, float *filters_colmajor_out);
 /* host-only: unit eigenvectors of the m largest eigenvalues of a symmetric n x n float matrix */
 int hpfw_gpu_host_top_eigenvectors(const float *cov, int n, int m, float *out, double *evals);
 
+/* Hashprints of one cached dB spectrogram, as collect_fingerprints computes them from
+ * cache/spectros/<stem> (parallel_collector.h:114-137).  s_colmajor is the matrix as the cereal file
+ * holds it (utils.h:77-106: int32 rows = 121, int32 cols, column-major floats).  *n_hp = cols - 99
+ * (0 when the spectrogram is too short); hp receives them when hp_cap >= *n_hp. */
+int hpfw_gpu_extract_db_host(hpfw_gpu *h, const float *s_colmajor, int32_t rows, int32_t cols,
+                             uint64_t *hp, int64_t hp_cap, int64_t *n_hp);
+
 /* ---- index + search: MemoryStorage::build / find ----------------------------------------- */
 int hpfw_gpu_index_clear(hpfw_gpu *h);
 /* appends n_clips hashprints; clip i is hp[offsets[i] .. offsets[i+1]); host or device source */
@@ -138,6 +145,9 @@ int hpfw_gpu_index_add(hpfw_gpu *h, const uint64_t *hp, const int64_t *offsets, 
 int hpfw_gpu_index_add_device(hpfw_gpu *h, const uint64_t *d_hp, const int64_t *offsets,
                               int64_t n_clips, void *stream);
 int64_t hpfw_gpu_index_size(hpfw_gpu *h); /* number of clips */
+/* The index back on the host -- what MemoryStorage::save dumps (storage.h:67-75).  offsets
+ * [n_clips + 1] is always written; hp [offsets[n_clips]] when hp != NULL (hp_cap = its capacity). */
+int hpfw_gpu_index_get(hpfw_gpu *h, int64_t *offsets, uint64_t *hp, int64_t hp_cap);
 /* added to every reported clip id (rank's first global clip id when the index is sharded) */
 int hpfw_gpu_index_set_clip_base(hpfw_gpu *h, uint32_t clip_base);
 

@@ -104,6 +104,53 @@ def test_cpp_live_song_identification(wav_set, filters, tmp_path):
         assert lines[2 * k] == f"=> Finding {qp}"
         name, cnt, off = lines[2 * k + 1][3:].split()
         assert name == f"track{ci:02d}" and int(cnt) > 0 and abs(int(off) - start / hop) <= 2
+    # index() learned its own filters and the destructor saved them (live_song_id.h:23-29)
+    learned = np.frombuffer(open(str(work / "cache" / "filters.cereal"), "rb").read()[8:], np.float32)
+    assert learned.size == 64 * 2420 and not np.array_equal(learned, np.asarray(filters, np.float32).ravel())
+    # f2: the database in MemoryStorage's cereal format (storage.h:67-86), written and read back
+    dump = str(work / "dump.cereal")
+    r2 = subprocess.run([exe, "--index"] + paths + ["--dump", dump], cwd=str(work), capture_output=True, text=True,
+                        timeout=300, env=dict(os.environ, HPFW_PREPARE_KEEP_FILTERS="1"))
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    raw = open(dump, "rb").read()
+    pos, entries = 8, []
+    assert int(np.frombuffer(raw[:8], np.uint64)[0]) == 4
+    for _ in range(4):
+        n = int(np.frombuffer(raw[pos:pos + 8], np.uint64)[0])
+        name = raw[pos + 8:pos + 8 + n].decode()
+        pos += 8 + n
+        n = int(np.frombuffer(raw[pos:pos + 8], np.uint64)[0])
+        entries.append((name, np.frombuffer(raw[pos + 8:pos + 8 + 8 * n], np.uint64)))
+        pos += 8 + 8 * n
+    assert pos == len(raw) and [e[0] for e in entries] == [f"track{i:02d}" for i in range(4)]
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(learned)
+    assert all(np.array_equal(e[1], hp) for e, hp in zip(entries, g.extract(np.stack(clips))))
+    g.close()
+    r3 = subprocess.run([exe, "--db", dump, "--search"] + [q[0] for q in qpaths], cwd=str(work),
+                        capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    assert [ln for ln in r3.stdout.splitlines() if ln.startswith("=> ")] == lines
+
+
+def test_index_readback_and_cached_spectrogram(torch_cuda, oracle, filters):
+    g = hpfw_amd.Gpu(0)
+    db = synth.random_hashprints(5, 300)
+    off = np.array([0, 300, 420, 420, 1000, 1500], np.int64)               # ragged, one empty clip
+    g.index_add(db.ravel(), off)
+    hp, off2 = g.index_get()
+    assert np.array_equal(hp, db.ravel()) and np.array_equal(off2, off)
+    # hashprints from a dB spectrogram as cache/spectros/<stem> holds it (column-major [121][C])
+    g.set_filters(filters)
+    rng = np.random.default_rng(8)
+    for c in (100, 137, 404):
+        s = rng.uniform(-80, 0, (121, c)).astype(np.float32)
+        got = g.extract_db(np.ascontiguousarray(s.T))
+        assert np.array_equal(got, oracle.pack(oracle.project(filters, s)))
+    assert g.extract_db(np.zeros((99, 121), np.float32)).size == 0          # too short: no hashprints
+    with pytest.raises(hpfw_amd.HpfwError):
+        g.extract_db(np.zeros((200, 120), np.float32))                         # not a 121-bin spectrogram
+    g.close()
 
 
 def test_c_abi_error_codes(torch_cuda):
