@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n
 
 // one workgroup = one residue pair of one clip; the body (fft_rows.h) is shared with tests/emu.
 // 384 threads x <= 168 VGPRs and <= 80 KB of LDS: two workgroups per CU.
-constexpr int kFwdThreads = 384;
+constexpr int kFwdThreads = 512;
 
 template <class Groups>
 __global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, const i16x2 *__restrict__ pairs,
@@ -57,8 +57,11 @@ __global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, co
                                                                   float *__restrict__ yp)
 {
     cf *lds = reinterpret_cast<cf *>(smem_raw);
-    const int p = blockIdx.x;
-    const int clip = blockIdx.y;
+    // clip is the fast grid index: workgroups resident at the same time then share one residue
+    // pair, so its two rows of the T_N[a k2] table (50 KB of the 5.3 MB) stay in L2 instead of the
+    // whole table cycling through it once per clip
+    const int p = blockIdx.y;
+    const int clip = blockIdx.x;
     const int a0 = 2 * p;
     float *ya = yp + ((int64_t)clip * 2 * a.n1 + 2 * a0) * a.hpad;
     float *yb = (a0 + 1 < a.n1) ? ya + 2 * (int64_t)a.hpad : nullptr;
@@ -73,48 +76,67 @@ __global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, co
 // One wave = one tile of 32 columns x NT row tiles of 32 (16 complex rows each); no LDS, no barriers.
 constexpr int kColsStep = 16; // MFMA k-steps (residues) per register block
 
+// Operands come through buffer loads: lane part of the address in one VGPR that never changes, the
+// residue step in an SGPR, the row-tile step in the instruction's immediate -- no vector address
+// arithmetic between the MFMAs -- and a residue past n1 (the padded tail of the last block) is
+// out of range of the descriptor and reads as 0.
+__device__ __forceinline__ float cols_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 template <int NT>
-__global__ __launch_bounds__(256) void fwd_cols_kernel(ColsArgs ca, int tile0, const float *__restrict__ yp,
-                                                       cf *__restrict__ x)
+__global__ __launch_bounds__(256, 2) void fwd_cols_kernel(ColsArgs ca, int tile0, const float *__restrict__ yp,
+                                                          cf *__restrict__ x)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ctile = blockIdx.x * 4 + wave;
     const int clip = blockIdx.y;
     if (ctile * 32 >= ca.h) return;
     const int hb = lane >> 5, j = lane & 31;
-    const float *bp = yp + (int64_t)clip * 2 * ca.n1 * ca.hpad + (int64_t)hb * ca.hpad + ctile * 32 + j;
-    const float *ap = ca.apack + (size_t)tile0 * 64 + lane; // [a][tile][lane]
-    const size_t astep = ca.debug_same_a ? 0 : (size_t)ca.n_tiles * 64;
+    const int64_t clip_floats = (int64_t)2 * ca.n1 * ca.hpad;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(yp + clip * clip_floats), (short)0, (int)(clip_floats * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(ca.apack), (short)0, ca.n1 * ca.n_tiles * 256, 0x00020000); // [a][tile][lane]
+    const int vb = (hb * ca.hpad + ctile * 32 + j) * 4;
+    const int va = (tile0 * 64 + lane) * 4;
+    const int sb = 2 * ca.hpad * 4;                          // bytes per residue in Y' (Re row, Im row)
+    const int sa = ca.debug_same_a ? 0 : ca.n_tiles * 256;   // bytes per residue in the coefficient image
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
-    float a_cur[kColsStep][NT], b_cur[kColsStep], a_nxt[kColsStep][NT], b_nxt[kColsStep];
+    float a0[kColsStep][NT], b0[kColsStep], a1[kColsStep][NT], b1[kColsStep];
     const int nblocks = (ca.n1 + kColsStep - 1) / kColsStep;
-    auto load = [&](int blk, float (&av)[kColsStep][NT], float (&bv)[kColsStep]) {
+#pragma unroll
+    for (int s = 0; s < kColsStep; ++s) {
+        b0[s] = cols_ld(rb, vb, s * sb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a0[s][t] = cols_ld(ra, va + t * 256, s * sa);
+    }
+    // two register sets in turn: the loads of the next block are issued between the MFMAs of this one
+#pragma unroll 1
+    for (int blk = 0; blk < nblocks; blk += 2) {
+        const int r1 = (blk + 1) * kColsStep, r2 = (blk + 2) * kColsStep;
 #pragma unroll
         for (int s = 0; s < kColsStep; ++s) {
-            int a = blk * kColsStep + s;
-            const bool ok = a < ca.n1;
-            a = ok ? a : ca.n1 - 1; // the tail re-reads the last residue with zero coefficients
-            bv[s] = bp[(int64_t)2 * a * ca.hpad];
+            b1[s] = cols_ld(rb, vb, (r1 + s) * sb);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) av[s][t] = ok ? ap[a * astep + (size_t)t * 64] : 0.0f;
-        }
-    };
-    load(0, a_cur, b_cur);
-#pragma unroll 1
-    for (int blk = 0; blk < nblocks; ++blk) {
-        if (blk + 1 < nblocks) load(blk + 1, a_nxt, b_nxt);
-#pragma unroll
-        for (int s = 0; s < kColsStep; ++s)
+            for (int t = 0; t < NT; ++t) a1[s][t] = cols_ld(ra, va + t * 256, (r1 + s) * sa);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s][t], b_cur[s], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s][t], b0[s], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); // keep the loads up here: the scheduler would sink them to save registers
+        }
 #pragma unroll
         for (int s = 0; s < kColsStep; ++s) {
-            b_cur[s] = b_nxt[s];
+            b0[s] = cols_ld(rb, vb, (r2 + s) * sb);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a_cur[s][t] = a_nxt[s][t];
+            for (int t = 0; t < NT; ++t) a0[s][t] = cols_ld(ra, va + t * 256, (r2 + s) * sa);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][t], b1[s], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // D layout: column = lane & 31; registers (2q, 2q+1) of a tile are rows 2p, 2p+1 with
@@ -156,7 +178,7 @@ static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    dim3 grid((a.n1 + 1) / 2, n_clips);
+    dim3 grid(n_clips, (a.n1 + 1) / 2);
     // pre-passed stream: [clip][pair][n2]; in place: pair p of time step t at pcm word t n1/2 + p
     const int64_t clip_pitch = a.pair_stride == 1 ? (int64_t)((a.n1 + 1) / 2) * a.n2 : (int64_t)a.n1 * a.n2 / 2;
     const int pair_pitch = a.pair_stride == 1 ? a.n2 : 1;
