@@ -91,7 +91,7 @@ struct hpfw_gpu {
     int batch = 1024; // clips per pass: ~10 GB of workspace at 30 s; every launch fills the 256 CUs many times over
     // extraction workspace
     size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
-    void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // yp, x, mag, proj, magmax, pairs
+    void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // yp, x, mag, proj, wave maxima [clip][121][16], pairs
     // index
     uint64_t *d_db = nullptr;
     size_t db_cap = 0;
@@ -108,6 +108,8 @@ struct hpfw_gpu {
     // filter learning: accum_cov of ParallelCollector (parallel_collector.h:76), upper tiles only
     float *d_cov = nullptr;
     float *d_mu = nullptr;
+    float *d_clipmax = nullptr; // per-clip maximum magnitude (reference level of the dB conversion)
+    size_t clipmax_cap = 0;
     float *d_cov_part = nullptr;
     size_t cov_part_cap = 0;
     size_t mu_cap = 0;
@@ -257,12 +259,12 @@ int ensure_ws(hpfw_gpu *h, const hpfw::HostPlan &p, int nb, int ns)
 {
     const size_t need[6] = {(size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4, (size_t)nb * (p.kmax - p.kmin) * 8,
                             (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4,
-                            (size_t)ns * 4, (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4};
+                            (size_t)ns * 121 * hpfw::kCqMaxWaves * 4, (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4};
     for (int i = 0; i < 6; ++i) {
         int rc = ensure(&h->ws[i], &h->ws_bytes[i], need[i]);
         if (rc) return rc;
     }
-    return 0;
+    return ensure((void **)&h->d_clipmax, &h->clipmax_cap, (size_t)ns * 4);
 }
 
 // front end for nb clips: PCM -> dB spectrogram, written at clip slot `slot` of the S workspace
@@ -273,9 +275,8 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
     float *yp = (float *)h->ws[0];
     cf *x = (cf *)h->ws[1];
     float *mag = (float *)h->ws[2] + (size_t)slot * 121 * p.c;
-    unsigned *mm = (unsigned *)h->ws[4] + slot;
+    float *mm = (float *)h->ws[4] + (size_t)slot * 121 * hpfw::kCqMaxWaves; // this pass's wave maxima
     int rc;
-    HIP_TRY(hipMemsetAsync(mm, 0, (size_t)nb * 4, s));
     {
         Timed t(h, K_ROWS, s);
         if (dp->rows.pair_stride == 1) {
@@ -298,7 +299,7 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
     if ((rc = check_launch("cq_chirpz"))) return rc;
     {
         Timed t(h, K_DB, s);
-        hpfw::launch_db(mag, mm, nb, (int64_t)121 * p.c, mag, s);
+        hpfw::launch_db(mag, mm, h->d_clipmax + slot, nb, (int64_t)121 * p.c, mag, s);
     }
     return check_launch("db");
 }
@@ -362,6 +363,7 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->d_fpack) (void)hipFree(h->d_fpack);
     if (h->d_cov) (void)hipFree(h->d_cov);
     if (h->d_mu) (void)hipFree(h->d_mu);
+    if (h->d_clipmax) (void)hipFree(h->d_clipmax);
     if (h->d_cov_part) (void)hipFree(h->d_cov_part);
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
     if (h->d_db) (void)hipFree(h->d_db);
@@ -510,10 +512,9 @@ int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        HIP_TRY(hipMemsetAsync(h->ws[4], 0, (size_t)nb * 4, s));
         for (const hpfw::CqClassDev &cd : dp->cls)
             hpfw::launch_cq_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb,
-                                  d_mag + c0 * 121 * dp->hp.c, (unsigned *)h->ws[4], s);
+                                  d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], s);
         if ((rc = check_launch("cq_chirpz"))) return rc;
     }
     return 0;
@@ -527,12 +528,12 @@ int hpfw_gpu_stage_db(hpfw_gpu *h, const float *d_mag, int64_t n_clips, int64_t 
     int rc;
     const int64_t per = 121 * c;
     const int nbmax = 1024;
-    if ((rc = ensure(&h->ws[4], &h->ws_bytes[4], (size_t)nbmax * 4))) return rc;
+    if ((rc = ensure(&h->ws[4], &h->ws_bytes[4], (size_t)nbmax * 121 * hpfw::kCqMaxWaves * 4))) return rc;
+    if ((rc = ensure((void **)&h->d_clipmax, &h->clipmax_cap, (size_t)nbmax * 4))) return rc;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        HIP_TRY(hipMemsetAsync(h->ws[4], 0, (size_t)nb * 4, s));
-        hpfw::launch_magmax(d_mag + c0 * per, nb, per, (unsigned *)h->ws[4], s);
-        hpfw::launch_db(d_mag + c0 * per, (unsigned *)h->ws[4], nb, per, d_db + c0 * per, s);
+        hpfw::launch_magmax(d_mag + c0 * per, nb, (int)c, (float *)h->ws[4], s);
+        hpfw::launch_db(d_mag + c0 * per, (const float *)h->ws[4], h->d_clipmax, nb, per, d_db + c0 * per, s);
         if ((rc = check_launch("db"))) return rc;
     }
     return 0;

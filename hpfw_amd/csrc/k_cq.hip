@@ -30,7 +30,7 @@ constexpr int cq_threads(int logp)
 template <int LOGP>
 __global__ __launch_bounds__(cq_threads(LOGP)) void cq_kernel(CqPlanDev cp, CqClassDev cc,
                                                               const cf *__restrict__ x, float *__restrict__ mag,
-                                                              unsigned *__restrict__ magmax)
+                                                              float *__restrict__ wavemax)
 {
     using P = Pow2<LOGP>;
     cf *lds = reinterpret_cast<cf *>(smem_raw);
@@ -40,21 +40,39 @@ __global__ __launch_bounds__(cq_threads(LOGP)) void cq_kernel(CqPlanDev cp, CqCl
     const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[j] - cp.kmin);
     float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
     cq_band_body<LOGP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out);
+    // wave maximum -> wavemax[clip][band][wave]: plain stores (clipmax_kernel reduces them); one
+    // atomicMax per wave on a per-clip word cost 0.4 ms per 1000 clips in contention
     const float mx = wave_max(red[threadIdx.x]);
-    if ((threadIdx.x & 63) == 0) atomicMax(&magmax[clip], __float_as_uint(mx)); // mag >= 0: bit order = value order
+    float *slot = wavemax + ((int64_t)clip * kBins + j) * kCqMaxWaves;
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = mx;
+    if (threadIdx.x < kCqMaxWaves && threadIdx.x >= (blockDim.x >> 6)) slot[threadIdx.x] = 0.0f; // slots of absent waves
 }
 
-// per-clip maximum for the stage entry point that starts from given magnitudes
-__global__ __launch_bounds__(256) void magmax_kernel(const float *__restrict__ mag, int64_t per_clip,
-                                                     unsigned *__restrict__ magmax)
+// band maxima for the stage entry point that starts from given magnitudes: one workgroup per (band, clip)
+__global__ __launch_bounds__(256) void magmax_kernel(const float *__restrict__ mag, int c, float *__restrict__ wavemax)
 {
-    const int clip = blockIdx.y;
-    const float *m = mag + (int64_t)clip * per_clip;
+    const int band = blockIdx.x, clip = blockIdx.y;
+    const float *m = mag + ((int64_t)clip * kBins + band) * c;
     float mx = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_clip; i += (int64_t)gridDim.x * 256)
-        mx = fmaxf(mx, m[i]);
+    for (int i = threadIdx.x; i < c; i += 256) mx = fmaxf(mx, m[i]);
     mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) atomicMax(&magmax[clip], __float_as_uint(mx));
+    float *slot = wavemax + ((int64_t)clip * kBins + band) * kCqMaxWaves;
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = mx;
+    if (threadIdx.x < kCqMaxWaves && threadIdx.x >= 4) slot[threadIdx.x] = 0.0f;
+}
+
+// clipmax[clip] = max over the clip's wave maxima
+__global__ __launch_bounds__(256) void clipmax_kernel(const float *__restrict__ wavemax, float *__restrict__ clipmax)
+{
+    __shared__ float part[4];
+    const int clip = blockIdx.x;
+    const float *w = wavemax + (int64_t)clip * kBins * kCqMaxWaves;
+    float mx = 0.0f;
+    for (int i = threadIdx.x; i < kBins * kCqMaxWaves; i += 256) mx = fmaxf(mx, w[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) clipmax[clip] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
 }
 
 // log10 in double by a fixed sequence of IEEE operations
@@ -94,13 +112,13 @@ __device__ __forceinline__ float db_term(float pw)
 }
 
 // mag and db may be the same buffer (each element is read, then written, by one thread)
-__global__ __launch_bounds__(256) void db_kernel(const float *mag, const unsigned *__restrict__ magmax,
+__global__ __launch_bounds__(256) void db_kernel(const float *mag, const float *__restrict__ clipmax,
                                                  int64_t per_clip, float *db)
 {
     __shared__ float ref_s;
     const int clip = blockIdx.y;
     if (threadIdx.x == 0) {
-        const float mm = __uint_as_float(magmax[clip]);
+        const float mm = clipmax[clip];
         ref_s = db_term(mm * mm);
     }
     __syncthreads();
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(256) void db_kernel(const float *mag, const unsigne
 
 template <int LOGP>
 static void launch_cq_t(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
-                        unsigned *d_magmax, hipStream_t s)
+                        float *d_wavemax, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -126,38 +144,37 @@ static void launch_cq_t(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x
     }
     dim3 grid(cc.n_bands, n_clips);
     hipLaunchKernelGGL(cq_kernel<LOGP>, grid, dim3(cq_threads(LOGP)), (size_t)Pow2<LOGP>::DATA * sizeof(cf) + cq_threads(LOGP) * sizeof(float), s, cp,
-                       cc, d_x, d_mag, d_magmax);
+                       cc, d_x, d_mag, d_wavemax);
 }
 
 void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
-                     unsigned *d_magmax, hipStream_t s)
+                     float *d_wavemax, hipStream_t s)
 {
     switch (cc.p) {
-    case 64: launch_cq_t<6>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
-    case 128: launch_cq_t<7>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
-    case 256: launch_cq_t<8>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
-    case 512: launch_cq_t<9>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
-    case 1024: launch_cq_t<10>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
-    case 2048: launch_cq_t<11>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
-    case 4096: launch_cq_t<12>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
-    case 8192: launch_cq_t<13>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break;
-    default: launch_cq_t<14>(cp, cc, d_x, n_clips, d_mag, d_magmax, s); break; // 16384: the plan admits nothing larger
+    case 64: launch_cq_t<6>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
+    case 128: launch_cq_t<7>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
+    case 256: launch_cq_t<8>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
+    case 512: launch_cq_t<9>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
+    case 1024: launch_cq_t<10>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
+    case 2048: launch_cq_t<11>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
+    case 4096: launch_cq_t<12>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
+    case 8192: launch_cq_t<13>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
+    default: launch_cq_t<14>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break; // 16384: the plan admits nothing larger
     }
 }
 
-void launch_magmax(const float *d_mag, int n_clips, int64_t per_clip, unsigned *d_magmax, hipStream_t s)
+void launch_magmax(const float *d_mag, int n_clips, int c, float *d_wavemax, hipStream_t s)
 {
-    int bx = (int)((per_clip + 256 * 8 - 1) / (256 * 8));
-    if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(magmax_kernel, dim3(bx, n_clips), dim3(256), 0, s, d_mag, per_clip, d_magmax);
+    hipLaunchKernelGGL(magmax_kernel, dim3(kBins, n_clips), dim3(256), 0, s, d_mag, c, d_wavemax);
 }
 
-void launch_db(const float *d_mag, const unsigned *d_magmax, int n_clips, int64_t per_clip, float *d_db,
-               hipStream_t s)
+void launch_db(const float *d_mag, const float *d_wavemax, float *d_clipmax, int n_clips, int64_t per_clip,
+               float *d_db, hipStream_t s)
 {
+    hipLaunchKernelGGL(clipmax_kernel, dim3(n_clips), dim3(256), 0, s, d_wavemax, d_clipmax);
     int bx = (int)((per_clip + 256 * 4 - 1) / (256 * 4));
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(db_kernel, dim3(bx, n_clips), dim3(256), 0, s, d_mag, d_magmax, per_clip, d_db);
+    hipLaunchKernelGGL(db_kernel, dim3(bx, n_clips), dim3(256), 0, s, d_mag, d_clipmax, per_clip, d_db);
 }
 
 } // namespace hpfw

@@ -54,14 +54,16 @@ size_t fwd_rows_lds_bytes(const RowsArgs &a);
 // length-n1 DFT across residues on f32 MFMA: planar yp [n_clips][2 n1][hpad] -> x [n_clips][kmax-kmin]
 void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s);
 void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, int n_tiles, float *apack);
-// band chirp-z transforms: x -> mag [n_clips][121][c]; also atomically maxes d_magmax[clip] (bits)
+// band chirp-z transforms: x -> mag [n_clips][121][c]; also the maxima each wave saw,
+// d_wavemax [n_clips][121][kCqMaxWaves] (slots of absent waves are written as 0)
+constexpr int kCqMaxWaves = 16;
 void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips,
-                     float *d_mag, unsigned *d_magmax, hipStream_t s);
-// per-clip maximum of mag when the chirp-z stage did not run (stage entry point): d_magmax[clip]
-void launch_magmax(const float *d_mag, int n_clips, int64_t per_clip, unsigned *d_magmax, hipStream_t s);
-// amplitude_to_db given the per-clip maximum
-void launch_db(const float *d_mag, const unsigned *d_magmax, int n_clips, int64_t per_clip, float *d_db,
-               hipStream_t s);
+                     float *d_mag, float *d_wavemax, hipStream_t s);
+// the same maxima when the chirp-z stage did not run (stage entry point)
+void launch_magmax(const float *d_mag, int n_clips, int c, float *d_wavemax, hipStream_t s);
+// amplitude_to_db: d_clipmax [n_clips] receives the per-clip maximum of d_wavemax first
+void launch_db(const float *d_mag, const float *d_wavemax, float *d_clipmax, int n_clips, int64_t per_clip,
+               float *d_db, hipStream_t s);
 // filters * frames on f32 MFMA: s_db [n_clips][121][c] -> proj [n_clips][64][c-19]
 // d_fpack: filters repacked by pack_filters_for_mfma()
 void launch_project(const float *d_fpack, const float *d_db, int n_clips, int c, float *d_proj,
