@@ -204,6 +204,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     if ((rc = upload(p.rows_gtw, reinterpret_cast<const hpfw::HostCf **>(&ra.gtw), dp->owned))) return rc;
     if ((rc = upload(p.tw_big, reinterpret_cast<const hpfw::HostCf **>(&ra.tw_big), dp->owned))) return rc;
     if ((rc = upload(p.pos_n2, &ra.pos_n2, dp->owned))) return rc;
+    if ((rc = upload(p.kb_last, &ra.kb_last, dp->owned))) return rc;
     if (hpfw::fwd_rows_lds_bytes(ra) > 160 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
     if (std::getenv("HPFW_DEBUG_ROWS_NOGROUPS")) ra.groups.n = 0; // timing ablations only (wrong results)
     if (std::getenv("HPFW_DEBUG_ROWS_NOEPI")) ra.h = 0;

@@ -33,13 +33,14 @@ struct RowsArgs {
     const cf *gtw;            // per-butterfly twiddles of every group (see group_twiddle_count)
     const cf *tw_big;         // T_N[a * k2]  [n1][h]
     const int *pos_n2;        // digit-reversed position of output k2
+    const int *kb_last;       // output k2 = kb_last[b] + (n2 / len) f of the last group's block b (see rows_last_*)
 };
 
 // entries per butterfly of a fused (R1, R2) group: stage 1 has (R1 - 1) R2, stage 2 has R2 - 1;
 // entry q2 (R1 - 1) + (s - 1) = T_n[ts1 (j0 + q2 m2) s], entry (R1 - 1) R2 + (s2 - 1) = T_n[ts2 j0 s2]
 constexpr int group_twiddle_count(int r1, int r2) { return (r1 - 1) * r2 + (r2 - 1); }
 
-// one fused group of the forward DIF at sub-length len: radix R1, then radix R2 (or 1)
+// one fused group of the forward DIF at sub-length len: radix R1, then radix R2 (or 1), in place
 template <int R1, int R2, class Lds>
 HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int len, int tid, int nthreads)
 {
@@ -83,6 +84,108 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
     }
 }
 
+// The group before the last, one butterfly per thread, in two halves around a barrier (its stores
+// are not in place): the same butterfly as rows_group into registers, out[s R2 + s2]; then element
+// j0 of the next group's block b' = blk R1 R2 + s R2 + s2 (in place: position b' m2 + j0) goes to
+// j0 (n / m2) + b'.  The last group, whose thread b owns block b, then reads with its lanes on
+// consecutive addresses instead of m2 complex apart (8-way bank conflicts for m2 = 20).
+template <int R1, int R2, class Lds>
+HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int len, int tid, cf *out)
+{
+    const int n = a.n2;
+    const int m1 = len / R1, m2 = m1 / R2;
+    const int nb = n / (R1 * R2);
+    if (tid >= nb) return;
+    const int blk = tid / m2, j0 = tid - blk * m2;
+    const int base = blk * len + j0;
+    const cf *__restrict__ tb = gt + tid;
+    cf e[R1][R2];
+#pragma unroll
+    for (int q2 = 0; q2 < R2; ++q2) {
+        cf u[R1];
+#pragma unroll
+        for (int q = 0; q < R1; ++q) u[q] = lds[base + q2 * m2 + q * m1];
+        Dft<R1>::run(u);
+        e[0][q2] = u[0];
+#pragma unroll
+        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tb[(q2 * (R1 - 1) + (s - 1)) * nb]);
+    }
+#pragma unroll
+    for (int s = 0; s < R1; ++s) {
+        if constexpr (R2 > 1) {
+            cf v[R2];
+#pragma unroll
+            for (int q2 = 0; q2 < R2; ++q2) v[q2] = e[s][q2];
+            Dft<R2>::run(v);
+            out[s * R2] = v[0];
+#pragma unroll
+            for (int s2 = 1; s2 < R2; ++s2) out[s * R2 + s2] = c_mul(v[s2], tb[((R1 - 1) * R2 + (s2 - 1)) * nb]);
+        } else {
+            out[s] = e[s][0];
+        }
+    }
+}
+
+template <int R1, int R2, class Lds>
+HPFW_DEVICE void rows_pre_store(Lds &lds, const RowsArgs &a, int len, int tid, const cf *out)
+{
+    const int n = a.n2;
+    const int m2 = len / (R1 * R2);
+    const int nb = n / (R1 * R2);
+    if (tid >= nb) return;
+    const int blk = tid / m2, j0 = tid - blk * m2;
+    const int o0 = j0 * (n / m2) + blk * (R1 * R2);
+#pragma unroll
+    for (int t = 0; t < R1 * R2; ++t) lds[o0 + t] = out[t];
+}
+
+// The last group (len = R1 R2: thread b owns block b) when the data are transposed, in two halves
+// around a barrier: compute from element e of block b at e nb + b into registers; then store output
+// f = s + R1 s2 of the block -- frequency k2 = kb_last[b] + nb f -- at lds[k2]: natural order, so the
+// Hermitian split reads lds[k2] and lds[n2 - k2] on consecutive lanes and needs no position table.
+template <int R1, int R2, class Lds>
+HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int tid, cf *out)
+{
+    const int nb = a.n2 / (R1 * R2);
+    if (tid >= nb) return;
+    const cf *__restrict__ tb = gt + tid;
+    cf e[R1][R2];
+#pragma unroll
+    for (int q2 = 0; q2 < R2; ++q2) {
+        cf u[R1];
+#pragma unroll
+        for (int q = 0; q < R1; ++q) u[q] = lds[(q2 + q * R2) * nb + tid];
+        Dft<R1>::run(u);
+        e[0][q2] = u[0];
+#pragma unroll
+        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tb[(q2 * (R1 - 1) + (s - 1)) * nb]);
+    }
+#pragma unroll
+    for (int s = 0; s < R1; ++s) {
+        if constexpr (R2 > 1) {
+            cf v[R2];
+#pragma unroll
+            for (int q2 = 0; q2 < R2; ++q2) v[q2] = e[s][q2];
+            Dft<R2>::run(v);
+            out[s] = v[0];
+#pragma unroll
+            for (int s2 = 1; s2 < R2; ++s2) out[s + R1 * s2] = c_mul(v[s2], tb[((R1 - 1) * R2 + (s2 - 1)) * nb]);
+        } else {
+            out[s] = e[s][0];
+        }
+    }
+}
+
+template <int R1, int R2, class Lds>
+HPFW_DEVICE void rows_last_store(Lds &lds, const RowsArgs &a, int tid, const cf *out)
+{
+    const int nb = a.n2 / (R1 * R2);
+    if (tid >= nb) return;
+    const int k0 = a.kb_last[tid];
+#pragma unroll
+    for (int f = 0; f < R1 * R2; ++f) lds[k0 + f * nb] = out[f];
+}
+
 template <int R1, class Lds>
 HPFW_DEVICE void rows_group_r2(Lds &lds, const RowsArgs &a, const cf *gt, int len, int r2, int tid, int nthreads)
 {
@@ -103,6 +206,7 @@ HPFW_DEVICE void rows_group_r2(Lds &lds, const RowsArgs &a, const cf *gt, int le
 
 // The group sequence either comes from the plan at run time (any 7-smooth n2) ...
 struct RuntimeGroups {
+    static constexpr bool kNatural = false; // outputs stay at their digit-reversed positions
     template <class Lds>
     HPFW_DEVICE_STATIC void run(Lds &lds, const RowsArgs &a, int nthreads)
     {
@@ -133,24 +237,59 @@ struct StaticGroups;
 
 template <>
 struct StaticGroups<> {
-    template <class Lds>
-    HPFW_DEVICE_STATIC void run_from(Lds &, const RowsArgs &, int, int, int) {}
+    static constexpr int kProduct = 1;
     static bool matches(const RowGroups &, int g, int n) { return g == n; }
 };
 
+// Needs at least two groups and one thread per butterfly of the last two (kMinThreads); those two
+// use the transposed layout and leave the outputs in natural order.
 template <int R1, int R2, int... Rest>
 struct StaticGroups<R1, R2, Rest...> {
+    static constexpr bool kNatural = true;
+    static constexpr int kProduct = R1 * R2 * StaticGroups<Rest...>::kProduct;
+    // butterflies of the two-phase groups: n2 / (R1 R2) with n2 the product of ALL radices, so only
+    // the complete list knows it; StaticGroups<...>::min_threads(n2) is used by the launcher
+    static int min_threads(int n2)
+    {
+        if constexpr (sizeof...(Rest) == 0 || sizeof...(Rest) == 2) {
+            const int here = n2 / (R1 * R2);
+            if constexpr (sizeof...(Rest) == 2) {
+                const int rest = StaticGroups<Rest...>::min_threads(n2);
+                return here > rest ? here : rest;
+            } else {
+                return here;
+            }
+        } else {
+            return StaticGroups<Rest...>::min_threads(n2);
+        }
+    }
     template <class Lds>
     HPFW_DEVICE_STATIC void run_from(Lds &lds, const RowsArgs &a, int nthreads, int len, int g)
     {
         const cf *gt = a.gtw + a.groups.tw_off[g];
-        HPFW_FOR_THREADS(tid, nthreads) { rows_group<R1, R2>(lds, a, gt, len, tid, nthreads); }
-        HPFW_BARRIER();
-        StaticGroups<Rest...>::run_from(lds, a, nthreads, len / (R1 * R2), g + 1);
+        if constexpr (sizeof...(Rest) == 0) {
+            HPFW_CARRY(cf, outv, R1 * R2, nthreads);
+            HPFW_FOR_THREADS(tid, nthreads) { rows_last_compute<R1, R2>(lds, a, gt, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
+            HPFW_BARRIER();
+            HPFW_FOR_THREADS(tid, nthreads) { rows_last_store<R1, R2>(lds, a, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
+            HPFW_BARRIER();
+        } else if constexpr (sizeof...(Rest) == 2) {
+            HPFW_CARRY(cf, outv, R1 * R2, nthreads);
+            HPFW_FOR_THREADS(tid, nthreads) { rows_pre_compute<R1, R2>(lds, a, gt, len, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
+            HPFW_BARRIER();
+            HPFW_FOR_THREADS(tid, nthreads) { rows_pre_store<R1, R2>(lds, a, len, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
+            HPFW_BARRIER();
+            StaticGroups<Rest...>::run_from(lds, a, nthreads, len / (R1 * R2), g + 1);
+        } else {
+            HPFW_FOR_THREADS(tid, nthreads) { rows_group<R1, R2>(lds, a, gt, len, tid, nthreads); }
+            HPFW_BARRIER();
+            StaticGroups<Rest...>::run_from(lds, a, nthreads, len / (R1 * R2), g + 1);
+        }
     }
     template <class Lds>
     HPFW_DEVICE_STATIC void run(Lds &lds, const RowsArgs &a, int nthreads)
     {
+        static_assert(sizeof...(Rest) >= 2, "the transposed layout needs a group before the last");
         run_from(lds, a, nthreads, a.n2, 0);
     }
     static bool matches(const RowGroups &g, int i, int n)
@@ -197,6 +336,7 @@ HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x
     const cf *__restrict__ twa = a.tw_big + (int64_t)a0 * a.h;
     const cf *__restrict__ twb = yb ? twa + a.h : twa;
     const int *__restrict__ pos = a.pos_n2;
+    constexpr bool kNat = Groups::kNatural;
     constexpr int kEpi = 9;
     HPFW_FOR_THREADS(tid, nthreads)
     {
@@ -207,8 +347,8 @@ HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x
             for (int e = 0; e < kEpi; ++e) {
                 const int k2 = k0 + e * nthreads;
                 const int kk = k2 < a.h ? k2 : 0;
-                pk[e] = pos[kk];
-                pm[e] = pos[kk == 0 ? 0 : n2 - kk];
+                pk[e] = kNat ? kk : pos[kk];
+                pm[e] = kNat ? (kk == 0 ? 0 : n2 - kk) : pos[kk == 0 ? 0 : n2 - kk];
                 wa[e] = twa[kk];
                 wb[e] = twb[kk];
             }

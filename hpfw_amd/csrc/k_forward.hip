@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n
 }
 
 // one workgroup = one residue pair of one clip; the body (fft_rows.h) is shared with tests/emu.
-// 384 threads x <= 168 VGPRs and <= 80 KB of LDS: two workgroups per CU.
+// 512 threads x 128 VGPRs and 50 KB of LDS: two workgroups per CU, every pass one butterfly per thread.
 constexpr int kFwdThreads = 512;
 
 template <class Groups>
@@ -190,7 +190,8 @@ static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, 
 // residue pair is an aligned 4-byte word of the [n2][n1] sample matrix)
 void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_src, int n_clips, float *d_yp, hipStream_t s)
 {
-    if (Groups6300::matches(a.groups, 0, a.groups.n))
+    // the compile-time sequence runs its last two groups one butterfly per thread
+    if (Groups6300::matches(a.groups, 0, a.groups.n) && Groups6300::min_threads(a.n2) <= kFwdThreads)
         launch_rows_t<Groups6300>(a, d_src, n_clips, d_yp, s);
     else
         launch_rows_t<RuntimeGroups>(a, d_src, n_clips, d_yp, s);

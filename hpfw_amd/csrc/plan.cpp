@@ -274,6 +274,22 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
         for (int64_t k2 = 0; k2 < p.h; ++k2) p.tw_big[(size_t)(a * p.h + k2)] = twiddle_f(a * k2, n);
     p.pos_n2.resize((size_t)n2);
     for (int64_t k = 0; k < n2; ++k) p.pos_n2[(size_t)k] = (int)digit_pos(k, n2, p.radix);
+    // the last fused group (R1, R2) works on blocks of len = R1 R2 consecutive positions; block b holds
+    // the outputs k2 = kb + nb f, f = s + R1 s2 at position len b + s R2 + s2 (nb = n2 / len)
+    {
+        const int r1 = p.groups.back().first, r2 = p.groups.back().second, len = r1 * r2;
+        const int nb = (int)(n2 / len);
+        p.kb_last.assign((size_t)nb, -1);
+        for (int k = 0; k < nb; ++k) p.kb_last[(size_t)(p.pos_n2[(size_t)k] / len)] = k;
+        for (int b = 0; b < nb; ++b)
+            for (int s = 0; s < r1; ++s)
+                for (int s2 = 0; s2 < r2; ++s2)
+                    if (p.kb_last[(size_t)b] < 0 ||
+                        p.pos_n2[(size_t)(p.kb_last[(size_t)b] + nb * (s + r1 * s2))] != len * b + s * r2 + s2) {
+                        why = "internal: last-group output map";
+                        return false;
+                    }
+    }
     // ---- chirp-z classes ----
     p.g_off.assign(kBins, 0);
     int64_t goff = 0;

@@ -34,6 +34,7 @@ struct HostPlan {
     std::vector<int> rows_gtw_off;          // start of each group's table in rows_gtw
     std::vector<HostCf> tw_n2, tw_n1, tw_big;
     std::vector<int> pos_n2;
+    std::vector<int> kb_last;               // last group's block b holds outputs kb_last[b] + (n2 / len) f
     int start[121], lg[121], psize[121];
     std::vector<int64_t> g_off;             // [121]
     std::vector<HostCf> g;                  // window * chirp / (M P), concatenated

@@ -16,12 +16,18 @@
 #define HPFW_DEVICE_STATIC static inline
 #define HPFW_FOR_THREADS(tid, nt) for (int tid = 0; tid < (nt); ++tid)
 #define HPFW_BARRIER() ((void)0)
+// registers a thread keeps across a barrier: one array per emulated thread
+#include <vector>
+#define HPFW_CARRY(type, name, count, nt) std::vector<type> name##_store((size_t)(count) * (size_t)(nt))
+#define HPFW_CARRY_AT(name, count, tid) (name##_store.data() + (size_t)(count) * (size_t)(tid))
 #else
 #include <hip/hip_runtime.h>
 #define HPFW_DEVICE __device__ __forceinline__
 #define HPFW_DEVICE_STATIC static __device__ __forceinline__
 #define HPFW_FOR_THREADS(tid, nt) for (int tid = threadIdx.x, hpfw_once_ = 1; hpfw_once_; hpfw_once_ = 0)
 #define HPFW_BARRIER() __syncthreads()
+#define HPFW_CARRY(type, name, count, nt) type name##_store[count]
+#define HPFW_CARRY_AT(name, count, tid) (name##_store)
 #endif
 
 #define HPFW_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))

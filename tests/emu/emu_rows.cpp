@@ -60,6 +60,7 @@ int main(int argc, char **argv)
     a.gtw = reinterpret_cast<const cf *>(hp.rows_gtw.data());
     a.tw_big = reinterpret_cast<const cf *>(hp.tw_big.data());
     a.pos_n2 = hp.pos_n2.data();
+    a.kb_last = hp.kb_last.data();
     std::vector<float> yp((size_t)2 * hp.n1 * a.hpad, NAN);
     const size_t lds_n = (size_t)hp.n2;
     for (int a0 = 0; a0 < hp.n1; a0 += 2) {
