@@ -28,7 +28,7 @@ EXPORTS = (
     "hpfw_gpu_index_clear", "hpfw_gpu_index_add", "hpfw_gpu_index_add_device",
     "hpfw_gpu_index_size", "hpfw_gpu_index_set_clip_base", "hpfw_gpu_search_topk_device",
     "hpfw_gpu_search_topk", "hpfw_gpu_merge_topk", "hpfw_gpu_timer_start", "hpfw_gpu_timer_stop",
-    "hpfw_gpu_index_get", "hpfw_gpu_extract_db_host",
+    "hpfw_gpu_index_get", "hpfw_gpu_extract_db_host", "hpfw_gpu_stage_spectrogram",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_save", "par_collector_load",
@@ -99,6 +99,7 @@ def lib():
     L.hpfw_gpu_merge_topk.argtypes = [vp, i32, i64, i32, vp]
     L.hpfw_gpu_timer_start.argtypes = [vp, vp]
     L.hpfw_gpu_timer_stop.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
+    L.hpfw_gpu_stage_spectrogram.argtypes = [vp, vp, i64, i64, vp, vp]
     L.hpfw_gpu_index_get.argtypes = [vp, vp, vp, ctypes.c_int64]
     L.hpfw_gpu_extract_db_host.argtypes = [vp, vp, i32, i32, vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.hpfw_gpu_set_kernel_timing.argtypes = [vp, i32]
@@ -194,6 +195,9 @@ class Gpu:
 
     def stage_pack_dev(self, d_proj, n_clips, n_frames, d_hp, stream=0):
         check(lib().hpfw_gpu_stage_pack(self._h, d_proj, n_clips, n_frames, d_hp, stream))
+
+    def stage_spectrogram_dev(self, d_pcm, n_samples, n_clips, d_db, stream=0):
+        check(lib().hpfw_gpu_stage_spectrogram(self._h, d_pcm, n_samples, n_clips, d_db, stream))
 
     # ---- filter learning ------------------------------------------------------------------
     def cov_reset(self):

@@ -268,8 +268,10 @@ int ensure_ws(hpfw_gpu *h, const hpfw::HostPlan &p, int nb, int ns)
     return ensure((void **)&h->d_clipmax, &h->clipmax_cap, (size_t)ns * 4);
 }
 
-// front end for nb clips: PCM -> dB spectrogram, written at clip slot `slot` of the S workspace
-int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, hipStream_t s)
+// front end for nb clips: PCM -> dB terms t (and their per-clip maximum in d_clipmax) at clip slot
+// `slot` of the S workspace; finish_db: also turn them into the dB spectrogram S = max(t - t_max, -80)
+// in place (the projection does that itself while staging, the covariance wants S)
+int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, bool finish_db, hipStream_t s)
 {
     using hpfw::cf;
     const hpfw::HostPlan &p = dp->hp;
@@ -295,12 +297,13 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
     if ((rc = check_launch("fwd_cols"))) return rc;
     for (const hpfw::CqClassDev &cd : dp->cls) {
         Timed t(h, K_CQ, s);
-        hpfw::launch_cq_class(dp->cq, cd, x, nb, mag, mm, s);
+        hpfw::launch_cq_class(dp->cq, cd, x, nb, mag, mm, true, s);
     }
     if ((rc = check_launch("cq_chirpz"))) return rc;
     {
         Timed t(h, K_DB, s);
-        hpfw::launch_db(mag, mm, h->d_clipmax + slot, nb, (int64_t)121 * p.c, mag, s);
+        hpfw::launch_clipmax(mm, h->d_clipmax + slot, nb, s);
+        if (finish_db) hpfw::launch_db_finish(mag, h->d_clipmax + slot, nb, (int64_t)121 * p.c, s);
     }
     return check_launch("db");
 }
@@ -314,7 +317,7 @@ int run_back(hpfw_gpu *h, DevPlan *dp, int ns, uint64_t *d_hp, hipStream_t s)
     int rc;
     {
         Timed t(h, K_PROJECT, s);
-        hpfw::launch_project(h->d_fpack, sdb, ns, p.c, proj, s);
+        hpfw::launch_project(h->d_fpack, sdb, h->d_clipmax, ns, p.c, proj, s);
     }
     if ((rc = check_launch("project"))) return rc;
     {
@@ -433,7 +436,7 @@ int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
         const int ns = (int)std::min<int64_t>(nsmax, n_clips - s0);
         for (int c0 = 0; c0 < ns; c0 += nbmax) {
             const int nb = std::min(nbmax, ns - c0);
-            rc = run_front(h, dp, d_pcm + (s0 + c0) * n_samples, nb, c0, s);
+            rc = run_front(h, dp, d_pcm + (s0 + c0) * n_samples, nb, c0, false, s);
             if (rc) return rc;
         }
         rc = run_back(h, dp, ns, d_hp + s0 * dp->hp.n_hp, s);
@@ -515,7 +518,7 @@ int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
         for (const hpfw::CqClassDev &cd : dp->cls)
             hpfw::launch_cq_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb,
-                                  d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], s);
+                                  d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s);
         if ((rc = check_launch("cq_chirpz"))) return rc;
     }
     return 0;
@@ -551,7 +554,7 @@ int hpfw_gpu_stage_project(hpfw_gpu *h, const float *d_db, int64_t n_clips, int6
     for (int64_t c0 = 0; c0 < n_clips; c0 += 16384) {
         const int nb = (int)std::min<int64_t>(16384, n_clips - c0);
         Timed t(h, K_PROJECT, s);
-        hpfw::launch_project(h->d_fpack, d_db + c0 * 121 * c, nb, (int)c, d_proj + c0 * 64 * nf, s);
+        hpfw::launch_project(h->d_fpack, d_db + c0 * 121 * c, nullptr, nb, (int)c, d_proj + c0 * 64 * nf, s);
     }
     return check_launch("project");
 }
@@ -652,6 +655,26 @@ int hpfw_gpu_cov_accumulate_db(hpfw_gpu *h, const float *d_db, int64_t n_clips, 
     return 0;
 }
 
+int hpfw_gpu_stage_spectrogram(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips, float *d_db,
+                               void *stream)
+{
+    if (!h || !d_pcm || !d_db || n_clips < 0) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    DevPlan *dp;
+    int rc = get_plan(h, n_samples, &dp);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
+    if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
+    const size_t per = (size_t)121 * dp->hp.c;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
+        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
+        if ((rc = run_front(h, dp, d_pcm + c0 * n_samples, nb, 0, true, s))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_db + c0 * per, h->ws[2], (size_t)nb * per * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
 int hpfw_gpu_cov_accumulate_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,
                                   void *stream)
 {
@@ -666,7 +689,7 @@ int hpfw_gpu_cov_accumulate_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_s
     if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        if ((rc = run_front(h, dp, d_pcm + c0 * n_samples, nb, 0, s))) return rc;
+        if ((rc = run_front(h, dp, d_pcm + c0 * n_samples, nb, 0, true, s))) return rc;
         if ((rc = hpfw_gpu_cov_accumulate_db(h, (const float *)h->ws[2], nb, dp->hp.c, stream))) return rc;
     }
     return 0;

@@ -234,11 +234,13 @@ HPFW_DEVICE void cq_transform(Lds &lds, const CqTwiddles &tw, int nthreads, int 
 }
 
 // ---- the whole band: window*chirp, forward FFT, times V, inverse FFT, magnitudes ----
-// lds: Pow2<LOGP>::DATA complex slots; red: one float per thread (this thread's largest magnitude).
-template <int LOGP, class Lds, class Red>
+// lds: Pow2<LOGP>::DATA complex slots; red: one float per thread (the largest value it stored).
+// fin(m): what is stored for magnitude m -- m itself, or its dB term (monotone in m, so the
+// largest stored value belongs to the largest magnitude either way).
+template <int LOGP, class Lds, class Red, class Fin>
 HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const cf *__restrict__ xs, const cf *__restrict__ g,
                               int lg, const CqTwiddles &tw, const cf *__restrict__ vrev, int c,
-                              float *__restrict__ out_mag)
+                              float *__restrict__ out_mag, Fin fin)
 {
     using P = Pow2<LOGP>;
     const bool prune = lg <= P::N / 4;
@@ -252,10 +254,10 @@ HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const cf *__rest
     cq_transform<LOGP, LOGP, 0>(lds, tw, nthreads, lg, c, vrev);
     HPFW_FOR_THREADS(tid, nthreads)
     {
-        float mx = 0.0f;
+        float mx = fin(0.0f);
         for (int i = tid; i < c; i += nthreads) {
             const cf v = lds[pad16(i)];
-            const float m = __builtin_sqrtf(HPFW_FMAF(v.r, v.r, v.i * v.i));
+            const float m = fin(__builtin_sqrtf(HPFW_FMAF(v.r, v.r, v.i * v.i)));
             out_mag[i] = m;
             mx = m > mx ? m : mx;
         }

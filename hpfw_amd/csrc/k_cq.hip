@@ -25,56 +25,6 @@ constexpr int cq_threads(int logp)
     return t < 64 ? 64 : (t > 1024 ? 1024 : t);
 }
 
-// One workgroup = one band of one clip.  The body (fft_lds.h) is shared with the host-side SIMT
-// emulation of tests/emu; here HPFW_FOR_THREADS is the thread itself and HPFW_BARRIER a barrier.
-template <int LOGP>
-__global__ __launch_bounds__(cq_threads(LOGP)) void cq_kernel(CqPlanDev cp, CqClassDev cc,
-                                                              const cf *__restrict__ x, float *__restrict__ mag,
-                                                              float *__restrict__ wavemax)
-{
-    using P = Pow2<LOGP>;
-    cf *lds = reinterpret_cast<cf *>(smem_raw);
-    float *red = reinterpret_cast<float *>(lds + P::DATA); // one float per thread behind the data
-    const int j = cc.band[blockIdx.x];
-    const int clip = blockIdx.y;
-    const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[j] - cp.kmin);
-    float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
-    cq_band_body<LOGP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out);
-    // wave maximum -> wavemax[clip][band][wave]: plain stores (clipmax_kernel reduces them); one
-    // atomicMax per wave on a per-clip word cost 0.4 ms per 1000 clips in contention
-    const float mx = wave_max(red[threadIdx.x]);
-    float *slot = wavemax + ((int64_t)clip * kBins + j) * kCqMaxWaves;
-    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = mx;
-    if (threadIdx.x < kCqMaxWaves && threadIdx.x >= (blockDim.x >> 6)) slot[threadIdx.x] = 0.0f; // slots of absent waves
-}
-
-// band maxima for the stage entry point that starts from given magnitudes: one workgroup per (band, clip)
-__global__ __launch_bounds__(256) void magmax_kernel(const float *__restrict__ mag, int c, float *__restrict__ wavemax)
-{
-    const int band = blockIdx.x, clip = blockIdx.y;
-    const float *m = mag + ((int64_t)clip * kBins + band) * c;
-    float mx = 0.0f;
-    for (int i = threadIdx.x; i < c; i += 256) mx = fmaxf(mx, m[i]);
-    mx = wave_max(mx);
-    float *slot = wavemax + ((int64_t)clip * kBins + band) * kCqMaxWaves;
-    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = mx;
-    if (threadIdx.x < kCqMaxWaves && threadIdx.x >= 4) slot[threadIdx.x] = 0.0f;
-}
-
-// clipmax[clip] = max over the clip's wave maxima
-__global__ __launch_bounds__(256) void clipmax_kernel(const float *__restrict__ wavemax, float *__restrict__ clipmax)
-{
-    __shared__ float part[4];
-    const int clip = blockIdx.x;
-    const float *w = wavemax + (int64_t)clip * kBins * kCqMaxWaves;
-    float mx = 0.0f;
-    for (int i = threadIdx.x; i < kBins * kCqMaxWaves; i += 256) mx = fmaxf(mx, w[i]);
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) clipmax[clip] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-}
-
 // log10 in double by a fixed sequence of IEEE operations
 __device__ __forceinline__ double log10_spec(double x)
 {
@@ -111,6 +61,60 @@ __device__ __forceinline__ float db_term(float pw)
     return (float)(10.0 * log10_spec((double)xx));
 }
 
+// One workgroup = one band of one clip.  The body (fft_lds.h) is shared with the host-side SIMT
+// emulation of tests/emu; here HPFW_FOR_THREADS is the thread itself and HPFW_BARRIER a barrier.
+// DBT: store the dB term t(m^2) = (float)(10 log10(max(m^2, 1e-10))) of each magnitude instead of the
+// magnitude (extraction: the dB conversion then is S = max(t - t_max, -80) wherever S is read, and
+// no separate pass over the spectrogram is needed; the chirp-z has VALU slots to spare for it).
+template <int LOGP, bool DBT>
+__global__ __launch_bounds__(cq_threads(LOGP)) void cq_kernel(CqPlanDev cp, CqClassDev cc,
+                                                              const cf *__restrict__ x, float *__restrict__ mag,
+                                                              float *__restrict__ wavemax)
+{
+    using P = Pow2<LOGP>;
+    cf *lds = reinterpret_cast<cf *>(smem_raw);
+    float *red = reinterpret_cast<float *>(lds + P::DATA); // one float per thread behind the data
+    const int j = cc.band[blockIdx.x];
+    const int clip = blockIdx.y;
+    const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[j] - cp.kmin);
+    float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
+    cq_band_body<LOGP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
+                       [](float m) { return DBT ? db_term(m * m) : m; });
+    // wave maximum -> wavemax[clip][band][wave]: plain stores (clipmax_kernel reduces them); one
+    // atomicMax per wave on a per-clip word cost 0.4 ms per 1000 clips in contention
+    const float mx = wave_max(red[threadIdx.x]);
+    float *slot = wavemax + ((int64_t)clip * kBins + j) * kCqMaxWaves;
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = mx;
+    if (threadIdx.x < kCqMaxWaves && threadIdx.x >= (blockDim.x >> 6)) slot[threadIdx.x] = -INFINITY; // slots of absent waves
+}
+
+// band maxima for the stage entry point that starts from given magnitudes: one workgroup per (band, clip)
+__global__ __launch_bounds__(256) void magmax_kernel(const float *__restrict__ mag, int c, float *__restrict__ wavemax)
+{
+    const int band = blockIdx.x, clip = blockIdx.y;
+    const float *m = mag + ((int64_t)clip * kBins + band) * c;
+    float mx = 0.0f;
+    for (int i = threadIdx.x; i < c; i += 256) mx = fmaxf(mx, m[i]);
+    mx = wave_max(mx);
+    float *slot = wavemax + ((int64_t)clip * kBins + band) * kCqMaxWaves;
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = mx;
+    if (threadIdx.x < kCqMaxWaves && threadIdx.x >= 4) slot[threadIdx.x] = -INFINITY;
+}
+
+// clipmax[clip] = max over the clip's wave maxima
+__global__ __launch_bounds__(256) void clipmax_kernel(const float *__restrict__ wavemax, float *__restrict__ clipmax)
+{
+    __shared__ float part[4];
+    const int clip = blockIdx.x;
+    const float *w = wavemax + (int64_t)clip * kBins * kCqMaxWaves;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < kBins * kCqMaxWaves; i += 256) mx = fmaxf(mx, w[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) clipmax[clip] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+
 // mag and db may be the same buffer (each element is read, then written, by one thread)
 __global__ __launch_bounds__(256) void db_kernel(const float *mag, const float *__restrict__ clipmax,
                                                  int64_t per_clip, float *db)
@@ -132,40 +136,70 @@ __global__ __launch_bounds__(256) void db_kernel(const float *mag, const float *
     }
 }
 
+// S = max(t - t_max, -80) in place, for consumers that want the dB spectrogram itself
+// (the covariance of filter learning, the stage entry point)
+__global__ __launch_bounds__(256) void db_finish_kernel(float *t, const float *__restrict__ clipmax, int64_t per_clip)
+{
+    const int clip = blockIdx.y;
+    const float ref = clipmax[clip];
+    float *o = t + (int64_t)clip * per_clip;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_clip; i += (int64_t)gridDim.x * 256) {
+        const float l = o[i] - ref;
+        o[i] = l < -80.0f ? -80.0f : l;
+    }
+}
+
 template <int LOGP>
 static void launch_cq_t(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
-                        float *d_wavemax, hipStream_t s)
+                        float *d_wavemax, bool db_term_out, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<LOGP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<LOGP, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<LOGP, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(cc.n_bands, n_clips);
-    hipLaunchKernelGGL(cq_kernel<LOGP>, grid, dim3(cq_threads(LOGP)), (size_t)Pow2<LOGP>::DATA * sizeof(cf) + cq_threads(LOGP) * sizeof(float), s, cp,
-                       cc, d_x, d_mag, d_wavemax);
+    const size_t lds = (size_t)Pow2<LOGP>::DATA * sizeof(cf) + cq_threads(LOGP) * sizeof(float);
+    if (db_term_out)
+        hipLaunchKernelGGL((cq_kernel<LOGP, true>), grid, dim3(cq_threads(LOGP)), lds, s, cp, cc, d_x, d_mag, d_wavemax);
+    else
+        hipLaunchKernelGGL((cq_kernel<LOGP, false>), grid, dim3(cq_threads(LOGP)), lds, s, cp, cc, d_x, d_mag, d_wavemax);
 }
 
 void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
-                     float *d_wavemax, hipStream_t s)
+                     float *d_wavemax, bool db_term_out, hipStream_t s)
 {
     switch (cc.p) {
-    case 64: launch_cq_t<6>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
-    case 128: launch_cq_t<7>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
-    case 256: launch_cq_t<8>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
-    case 512: launch_cq_t<9>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
-    case 1024: launch_cq_t<10>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
-    case 2048: launch_cq_t<11>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
-    case 4096: launch_cq_t<12>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
-    case 8192: launch_cq_t<13>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break;
-    default: launch_cq_t<14>(cp, cc, d_x, n_clips, d_mag, d_wavemax, s); break; // 16384: the plan admits nothing larger
+    case 64: launch_cq_t<6>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 128: launch_cq_t<7>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 256: launch_cq_t<8>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 512: launch_cq_t<9>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 1024: launch_cq_t<10>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 2048: launch_cq_t<11>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 4096: launch_cq_t<12>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 8192: launch_cq_t<13>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    default: launch_cq_t<14>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break; // 16384: the plan admits nothing larger
     }
 }
 
 void launch_magmax(const float *d_mag, int n_clips, int c, float *d_wavemax, hipStream_t s)
 {
     hipLaunchKernelGGL(magmax_kernel, dim3(kBins, n_clips), dim3(256), 0, s, d_mag, c, d_wavemax);
+}
+
+void launch_clipmax(const float *d_wavemax, float *d_clipmax, int n_clips, hipStream_t s)
+{
+    hipLaunchKernelGGL(clipmax_kernel, dim3(n_clips), dim3(256), 0, s, d_wavemax, d_clipmax);
+}
+
+void launch_db_finish(float *d_t, const float *d_clipmax, int n_clips, int64_t per_clip, hipStream_t s)
+{
+    int bx = (int)((per_clip + 256 * 4 - 1) / (256 * 4));
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(db_finish_kernel, dim3(bx, n_clips), dim3(256), 0, s, d_t, d_clipmax, per_clip);
 }
 
 void launch_db(const float *d_mag, const float *d_wavemax, float *d_clipmax, int n_clips, int64_t per_clip,

@@ -29,8 +29,12 @@ constexpr int kPjTp = kCtx / 2;            // 10 MFMA k-steps (k, k+1) per bin
 // one's staging hides behind another's MFMAs).  The filter operand is streamed straight from L2 into
 // registers, one bin (10 k-steps, 80 B per lane) ahead of its use: fpack is laid out
 // [bin][lane][k-step][filter tile] so that a wave reads 5 KB contiguously per bin.
-__global__ __launch_bounds__(kPjThreads) void project_kernel(const float *__restrict__ fpack,
-                                                             const float *__restrict__ sdb, int c, int nf,
+// FROM_T: sdb holds the dB terms t written by the chirp-z kernel; the conversion
+// S = max(t - tmax[clip], -80) (convert.h:12-15) rides on the staging loads.
+template <bool FROM_T>
+__global__ __launch_bounds__(kPjThreads, 3) void project_kernel(const float *__restrict__ fpack,
+                                                             const float *__restrict__ sdb,
+                                                             const float *__restrict__ tmax, int c, int nf,
                                                              float *__restrict__ proj)
 {
     __shared__ float s_tile[kPjBinsPerChunk * kPjRow];
@@ -40,6 +44,7 @@ __global__ __launch_bounds__(kPjThreads) void project_kernel(const float *__rest
     const int clip = blockIdx.y;
     const int n0 = blockIdx.x * kPjTileN;
     const float *S = sdb + (int64_t)clip * kBins * c;
+    const float ref = FROM_T ? tmax[clip] : 0.0f;
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0}; // [filter tile][frame tile]
     const int nl = wave * 64 + (lane & 31);
     const float4 *ap = reinterpret_cast<const float4 *>(fpack) + lane * (kPjTp / 2);
@@ -69,7 +74,14 @@ __global__ __launch_bounds__(kPjThreads) void project_kernel(const float *__rest
         for (int j = 0; j < kStage; ++j) {
             const int i = tid + j * kPjThreads;
             const int b = i / kPjCols;
-            if (i < kPjBinsPerChunk * kPjCols) s_tile[b * kPjRow + (i - b * kPjCols)] = stage[j];
+            // the dB conversion waits until here so that the loads stay in flight behind the MFMAs
+            // (columns past the clip get a meaningless value: only frames >= nf, never stored, see them)
+            float v = stage[j];
+            if (FROM_T) {
+                const float l = v - ref;
+                v = l < -80.0f ? -80.0f : l;
+            }
+            if (i < kPjBinsPerChunk * kPjCols) s_tile[b * kPjRow + (i - b * kPjCols)] = v;
         }
         __syncthreads();
         if (chunk + 1 < kBins / kPjBinsPerChunk) stage_load(chunk + 1);
@@ -145,11 +157,15 @@ void pack_filters_for_mfma(const float *f, float *fpack)
                 }
 }
 
-void launch_project(const float *d_fpack, const float *d_db, int n_clips, int c, float *d_proj, hipStream_t s)
+void launch_project(const float *d_fpack, const float *d_db, const float *d_tmax, int n_clips, int c, float *d_proj,
+                    hipStream_t s)
 {
     const int nf = c - (kCtx - 1);
     dim3 grid((nf + kPjTileN - 1) / kPjTileN, n_clips);
-    hipLaunchKernelGGL(project_kernel, grid, dim3(kPjThreads), 0, s, d_fpack, d_db, c, nf, d_proj);
+    if (d_tmax)
+        hipLaunchKernelGGL(project_kernel<true>, grid, dim3(kPjThreads), 0, s, d_fpack, d_db, d_tmax, c, nf, d_proj);
+    else
+        hipLaunchKernelGGL(project_kernel<false>, grid, dim3(kPjThreads), 0, s, d_fpack, d_db, d_tmax, c, nf, d_proj);
 }
 
 void launch_pack(const float *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s)

@@ -57,17 +57,23 @@ void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, in
 // band chirp-z transforms: x -> mag [n_clips][121][c]; also the maxima each wave saw,
 // d_wavemax [n_clips][121][kCqMaxWaves] (slots of absent waves are written as 0)
 constexpr int kCqMaxWaves = 16;
+// db_term_out: store t(m^2) = (float)(10 log10(max(m^2, 1e-10))) instead of the magnitude m
 void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips,
-                     float *d_mag, float *d_wavemax, hipStream_t s);
+                     float *d_mag, float *d_wavemax, bool db_term_out, hipStream_t s);
+// d_clipmax [n_clips] = the largest of each clip's wave maxima
+void launch_clipmax(const float *d_wavemax, float *d_clipmax, int n_clips, hipStream_t s);
+// dB terms -> dB spectrogram in place: S = max(t - t_max, -80)
+void launch_db_finish(float *d_t, const float *d_clipmax, int n_clips, int64_t per_clip, hipStream_t s);
 // the same maxima when the chirp-z stage did not run (stage entry point)
 void launch_magmax(const float *d_mag, int n_clips, int c, float *d_wavemax, hipStream_t s);
 // amplitude_to_db: d_clipmax [n_clips] receives the per-clip maximum of d_wavemax first
 void launch_db(const float *d_mag, const float *d_wavemax, float *d_clipmax, int n_clips, int64_t per_clip,
                float *d_db, hipStream_t s);
 // filters * frames on f32 MFMA: s_db [n_clips][121][c] -> proj [n_clips][64][c-19]
-// d_fpack: filters repacked by pack_filters_for_mfma()
-void launch_project(const float *d_fpack, const float *d_db, int n_clips, int c, float *d_proj,
-                    hipStream_t s);
+// d_fpack: filters repacked by pack_filters_for_mfma().  d_tmax != NULL: s_db holds dB terms and
+// S = max(t - d_tmax[clip], -80) is applied while the slab is staged.
+void launch_project(const float *d_fpack, const float *d_db, const float *d_tmax, int n_clips, int c,
+                    float *d_proj, hipStream_t s);
 // delta over 80 frames, sign, bit pack: proj [n_clips][64][nf] -> hp [n_clips][nf-80]
 void launch_pack(const float *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s);
 

@@ -111,6 +111,12 @@ int hpfw_gpu_stage_project(hpfw_gpu *h, const float *d_db, int64_t n_clips, int6
 int hpfw_gpu_stage_pack(hpfw_gpu *h, const float *d_proj, int64_t n_clips, int64_t n_frames,
                         uint64_t *d_hp, void *stream);
 
+/* PCM -> dB spectrogram through the front end exactly as extraction runs it (the chirp-z kernel
+ * writes dB terms, the reference level is applied afterwards): d_db [n_clips][121][C]
+ *                                                              cqt.h:45-81 + convert.h:7-25 */
+int hpfw_gpu_stage_spectrogram(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
+                               int64_t n_clips, float *d_db, void *stream);
+
 /* ---- filter learning: ParallelCollector::preprocess + calc_filters ------------------------
  * (parallel_collector.h:82-112, hashprint_handle.h:96-112).  The handle owns accum_cov
  * (2420 x 2420, parallel_collector.h:76): per clip, the covariance of its context frames (centred

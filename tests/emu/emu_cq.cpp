@@ -49,7 +49,7 @@ static void run_band(const hpfw::HostPlan &hp, const hpfw::BluesteinClass &bc, i
     for (int k = 0; k < 4; ++k) tw.off[k] = bc.goff[k];
     tw.mid_off = bc.mid_off;
     hpfw::cq_band_body<LOGP>(lds, red, nt, xs, g, hp.lg[j], tw, reinterpret_cast<const cf *>(bc.vrev.data()), hp.c,
-                             mag + (size_t)j * hp.c);
+                             mag + (size_t)j * hp.c, [](float m) { return m; });
 }
 
 int main(int argc, char **argv)

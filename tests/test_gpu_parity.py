@@ -62,6 +62,12 @@ def test_stages_bit_exact(gpu, torch_cuda, oracle, filters, seconds):
     db_gpu = d_db.cpu().numpy()
     db_ref = np.stack([oracle.db(m) for m in mag_ref])
     assert bits_equal(db_gpu, db_ref), _report("db", db_gpu, db_ref)
+    # the same spectrogram as extraction's front end produces it (dB terms written by the chirp-z
+    # kernel, reference level applied afterwards)
+    d_db2 = torch.empty_like(d_mag)
+    gpu.stage_spectrogram_dev(d_pcm.data_ptr(), n, n_clips, d_db2.data_ptr())
+    torch.cuda.synchronize()
+    assert bits_equal(d_db2.cpu().numpy(), db_ref), _report("spectrogram", d_db2.cpu().numpy(), db_ref)
     # projection (f32 MFMA) against the fmaf chain
     d_proj = torch.empty((n_clips, 64, plan.n_frames), dtype=torch.float32, device="cuda")
     gpu.stage_project_dev(d_db.data_ptr(), n_clips, plan.c, d_proj.data_ptr())
