@@ -90,20 +90,28 @@ __global__ __launch_bounds__(kPjThreads, 3) void project_kernel(const float *__r
         for (int b = 0; b < kPjBinsPerChunk; ++b) {
             const int bin = chunk * kPjBinsPerChunk + b;
             const int nbin = bin + 1 < kBins ? bin + 1 : bin; // the last prefetch re-reads the last bin
+            // next bin's filter operand first, pinned here: left alone the scheduler sinks these loads
+            // to the end of the bin and the wave then waits out their L2 latency before every copy
 #pragma unroll
             for (int i = 0; i < kPjTp / 2; ++i) a_nxt[i] = ap[(size_t)nbin * 64 * (kPjTp / 2) + i];
             const float *srow = s_tile + b * kPjRow + nl + kh;
+            float b0 = srow[0], b1 = srow[32];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tp = 0; tp < kPjTp; ++tp) {
                 const float4 a4 = a_cur[tp >> 1];
                 const float a0 = (tp & 1) ? a4.z : a4.x; // filter tile 0
                 const float a1 = (tp & 1) ? a4.w : a4.y; // filter tile 1
-                const float b0 = srow[2 * tp];
-                const float b1 = srow[2 * tp + 32];
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+                const float c0 = b0, c1 = b1;
+                if (tp + 1 < kPjTp) { // the S operands of the next step are read while this one multiplies
+                    b0 = srow[2 * tp + 2];
+                    b1 = srow[2 * tp + 34];
+                }
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, acc11, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int i = 0; i < kPjTp / 2; ++i) a_cur[i] = a_nxt[i];
