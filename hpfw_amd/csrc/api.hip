@@ -108,6 +108,10 @@ struct hpfw_gpu {
     // filter learning: accum_cov of ParallelCollector (parallel_collector.h:76), upper tiles only
     float *d_cov = nullptr;
     float *d_mu = nullptr;
+    void *d_qa = nullptr;   // queries expanded to fp4 for the matrix-core scan
+    size_t qa_cap = 0;
+    int *d_gk = nullptr;    // longest query of each group of 32
+    size_t gk_cap = 0;
     float *d_clipmax = nullptr; // per-clip maximum magnitude (reference level of the dB conversion)
     size_t clipmax_cap = 0;
     float *d_cov_part = nullptr;
@@ -367,6 +371,8 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->d_fpack) (void)hipFree(h->d_fpack);
     if (h->d_cov) (void)hipFree(h->d_cov);
     if (h->d_mu) (void)hipFree(h->d_mu);
+    if (h->d_qa) (void)hipFree(h->d_qa);
+    if (h->d_gk) (void)hipFree(h->d_gk);
     if (h->d_clipmax) (void)hipFree(h->d_clipmax);
     if (h->d_cov_part) (void)hipFree(h->d_cov_part);
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
@@ -868,9 +874,20 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
     if ((rc = ensure((void **)&h->d_q_off, &h->q_off_cap, (size_t)(n_q + 1) * 8))) return rc;
     HIP_TRY(hipMemcpyAsync(h->d_q_off, q_off, (size_t)(n_q + 1) * 8, hipMemcpyHostToDevice, s));
     // queries are processed in groups so the (query, clip) table stays below 1 GiB
-    int64_t qgroup = std::max<int64_t>(8, ((int64_t)1 << 27) / n_clips / 8 * 8);
-    qgroup = std::min<int64_t>(qgroup, (n_q + 7) / 8 * 8);
+    int64_t qgroup = std::max<int64_t>(32, ((int64_t)1 << 27) / n_clips / 32 * 32);
+    qgroup = std::min<int64_t>(qgroup, (n_q + 31) / 32 * 32);
     if ((rc = ensure((void **)&h->d_best, &h->best_cap, (size_t)qgroup * n_clips * 8))) return rc;
+    // The scan runs on the matrix cores (k_search_mfma.hip) unless the window does not fit the LDS
+    // (queries of several thousand hashprints) or HPFW_SEARCH_POPC asks for the xor/popcount kernel.
+    const bool mfma = !std::getenv("HPFW_SEARCH_POPC") && hpfw::hamming_mfma_lds_bytes((int)k_max) <= 160 * 1024 && k_max > 0;
+    const int kt_pad = hpfw::hamming_mfma_kt_pad((int)k_max);
+    int64_t n_max = 0;
+    for (int64_t i = 0; i < n_clips; ++i) n_max = std::max(n_max, h->db_off[i + 1] - h->db_off[i]);
+    if (mfma) {
+        if ((rc = ensure((void **)&h->d_qa, &h->qa_cap, (size_t)(qgroup / 32) * kt_pad * 1024))) return rc;
+        if ((rc = ensure((void **)&h->d_gk, &h->gk_cap, (size_t)(qgroup / 32) * 4))) return rc;
+    }
+    std::vector<int> gk;
     for (int64_t g0 = 0; g0 < n_q; g0 += qgroup) {
         const int ng = (int)std::min<int64_t>(qgroup, n_q - g0);
         HIP_TRY(hipMemsetAsync(h->d_best, 0xff, (size_t)ng * n_clips * 8, s));
@@ -883,7 +900,16 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
         a.n_q = ng;
         a.k_max = (int)k_max;
         a.best = h->d_best;
-        {
+        if (mfma && n_max > 0) {
+            gk.assign((size_t)(ng + 31) / 32, 0);
+            for (int i = 0; i < ng; ++i)
+                gk[(size_t)i / 32] = std::max(gk[(size_t)i / 32], (int)(q_off[g0 + i + 1] - q_off[g0 + i]));
+            HIP_TRY(hipMemcpyAsync(h->d_gk, gk.data(), gk.size() * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s)); // gk is reused by the next group of queries
+            Timed t(h, K_SCAN, s);
+            hpfw::launch_expand_queries(d_q_hp, a.q_off, ng, kt_pad, h->d_qa, s);
+            hpfw::launch_hamming_mfma(a, h->d_qa, kt_pad, h->d_gk, (int)n_max, s);
+        } else {
             Timed t(h, K_SCAN, s);
             hpfw::launch_hamming_scan(a, s);
         }

@@ -1,0 +1,237 @@
+// k_search_mfma.hip -- a9 on the matrix cores: the sliding Hamming scan as an exact +-1 contraction.
+//
+// Same result as hamming_scan_kernel (k_search.hip; reference MemoryStorage::find,
+// include/hpfw/audioproblems/live-song-id/storage.h:27-64), bit for bit: with every hashprint bit b
+// written as the E2M1 (fp4) number 1 - 2b, sum_j <Q_j, R_{off+j}> = 64 k - 2 sum_j popcount(q[j] ^
+// r[off+j]); the products are +-1 and the f32 accumulator holds integers of magnitude <= 64 k < 2^24,
+// so v_mfma_scale_f32_32x32x64_f8f6f4 (both operands fp4, unit scales) computes it exactly
+// (tools/fp4_probe.hip checks the instruction against popcount).  One MFMA = 32 queries x 32 offsets x
+// one hashprint position (K = 64 bits): 1024 pairs in 32 cycles per SIMD, against 4 VALU lane-ops
+// per pair for xor/popcount -- the scan is issue-bound, not memory-bound, so this is where the time is.
+//
+// Layout of the contraction (no diagonal sums, no lane shuffles in the loop):
+//   M = 32 queries of a group, N = offsets, K = (position j, bit): the operand B of step j for offset
+//   column n is the reference hashprint off + j -- a window of the clip sliding through LDS, one
+//   ds_read_b128 per MFMA; the operand A of step j (the 32 queries' hashprint j) is read once per
+//   step and used by the wave's 4 offset tiles.  Workgroup = 8 waves = one query group x 1024
+//   offsets of one clip; queries shorter than the group's longest are zero-padded (fp4 0 adds
+//   nothing), windows past the end of the clip are zeros, and k = min(k, n) (storage.h:37-39) falls
+//   out of that: a query longer than the clip meets zeros beyond n.
+#include "kernels.h"
+
+namespace hpfw {
+
+extern __shared__ __align__(16) unsigned char smem_raw[];
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kSmThreads = 512;            // 8 waves
+constexpr int kSmTiles = 4;                // offset tiles of 32 per wave
+constexpr int kSmWaveOffs = 32 * kSmTiles; // 128
+constexpr int kSmWgOffs = kSmWaveOffs * (kSmThreads / 64); // 1024 offsets per workgroup
+constexpr int kSmChunk = 16;               // positions j per staged chunk of the A operand (16 KB)
+
+// 8 bits -> 8 E2M1 nibbles, bit i in nibble i: 0 -> +1.0 (0x2), 1 -> -1.0 (0xA)
+__device__ __forceinline__ uint32_t expand8(uint32_t x)
+{
+    uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return 0x22222222u | (t << 3);
+}
+
+__device__ __forceinline__ v4i expand32(uint32_t w)
+{
+    v4i r;
+    r.x = (int)expand8(w & 0xff);
+    r.y = (int)expand8((w >> 8) & 0xff);
+    r.z = (int)expand8((w >> 16) & 0xff);
+    r.w = (int)expand8(w >> 24);
+    return r;
+}
+
+// qa [n_groups][kt_pad][64 lanes][16 B]: lane (m, h) of step j holds bits [32 h, 32 h + 32) of
+// hashprint j of query 32 g + m, or zeros past the query's end / past the last query.
+__global__ __launch_bounds__(256) void expand_queries_kernel(const uint64_t *__restrict__ q,
+                                                             const int64_t *__restrict__ q_off, int n_q, int kt_pad,
+                                                             v4i *__restrict__ qa)
+{
+    const int g = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x; // (j, lane)
+    if (idx >= kt_pad * 64) return;
+    const int j = idx >> 6, lane = idx & 63, m = lane & 31, h = lane >> 5;
+    const int qi = g * 32 + m;
+    v4i v = {0, 0, 0, 0};
+    if (qi < n_q) {
+        const int64_t o = q_off[qi];
+        if (j < (int)(q_off[qi + 1] - o)) v = expand32((uint32_t)(q[o + j] >> (32 * h)));
+    }
+    qa[((int64_t)g * kt_pad + j) * 64 + lane] = v;
+}
+
+struct SearchMfmaArgs {
+    const uint64_t *db;
+    const int64_t *db_off;
+    int n_clips;
+    const int64_t *q_off; // [n_q + 1] (device), this launch's first query at q_off[0]
+    int n_q;
+    const v4i *qa;        // expanded queries of this launch
+    int kt_pad;           // rows of qa per group (multiple of kSmChunk)
+    const int *gk;        // longest query of each group
+    uint64_t *best;       // [n_q][n_clips], initialised to ~0
+    int chunks;           // workgroups (of 1024 offsets) per clip
+};
+
+__global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaArgs a)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_lane = lane & 31, h = lane >> 5;
+    const int clip = blockIdx.x / a.chunks, g = blockIdx.y;
+    const int64_t r0 = a.db_off[clip];
+    const int n = (int)(a.db_off[clip + 1] - r0);
+    const int kt = a.gk[g];
+    if (n <= 0 || kt <= 0) return;
+    const int o0 = (blockIdx.x - clip * a.chunks) * kSmWgOffs;
+    if (o0 >= n) return; // no offset of this chunk exists (off <= n - 1 at best)
+
+    const int win = kSmWgOffs + kt;                      // window slots (one spare)
+    v4i *ldsB = reinterpret_cast<v4i *>(smem_raw);       // [win][2]: halves h = 0, 1 of each hashprint
+    v4i *ldsA = ldsB + 2 * win;                          // [2][kSmChunk][64]
+    int *kq_s = reinterpret_cast<int *>(ldsA + 2 * kSmChunk * 64); // [32] effective k of the group's queries
+    unsigned *red = reinterpret_cast<unsigned *>(kq_s + 32);       // [8 waves][32 queries]
+
+    // the clip's hashprints o0 .. o0 + win - 1, expanded; zeros past the end of the clip
+    for (int i = tid; i < win; i += kSmThreads) {
+        const int gi = o0 + i;
+        v4i lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (gi < n) {
+            const uint64_t w = a.db[r0 + gi];
+            lo = expand32((uint32_t)w);
+            hi = expand32((uint32_t)(w >> 32));
+        }
+        ldsB[2 * i] = lo;
+        ldsB[2 * i + 1] = hi;
+    }
+    if (tid < 32) {
+        const int qi = g * 32 + tid;
+        int k = 0;
+        if (qi < a.n_q) k = (int)(a.q_off[qi + 1] - a.q_off[qi]);
+        kq_s[tid] = k < n ? k : n; // storage.h:37-39
+    }
+    // first chunk of the A operand
+    const v4i *qa = a.qa + (int64_t)g * a.kt_pad * 64;
+    const int n_chunks = (kt + kSmChunk - 1) / kSmChunk;
+    v4i st0 = qa[tid], st1 = qa[tid + kSmThreads]; // 16 steps x 64 lanes = 1024 entries: two per thread
+    ldsA[tid] = st0;
+    ldsA[tid + kSmThreads] = st1;
+    __syncthreads();
+
+    f32x16 acc[kSmTiles];
+#pragma unroll
+    for (int t = 0; t < kSmTiles; ++t) acc[t] = f32x16{0};
+    const int one = 0x7f7f7f7f; // E8M0 scale 2^0
+    const v4i *bp = ldsB + 2 * (wave * kSmWaveOffs + n_lane) + h;
+
+    for (int c = 0; c < n_chunks; ++c) {
+        const bool more = c + 1 < n_chunks;
+        if (more) { // next chunk of A into registers while this one multiplies
+            st0 = qa[(c + 1) * (kSmChunk * 64) + tid];
+            st1 = qa[(c + 1) * (kSmChunk * 64) + tid + kSmThreads];
+        }
+        const v4i *ap = ldsA + (c & 1) * (kSmChunk * 64) + lane;
+        const int jn = min(kSmChunk, kt - c * kSmChunk);
+        const v4i *bj = bp + 2 * (c * kSmChunk);
+        for (int j = 0; j < jn; ++j) {
+            const v4i a4 = ap[j * 64];
+            const v8i av = {a4.x, a4.y, a4.z, a4.w, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < kSmTiles; ++t) {
+                const v4i b4 = bj[2 * (j + 32 * t)];
+                const v8i bv = {b4.x, b4.y, b4.z, b4.w, 0, 0, 0, 0};
+                acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[t], 4, 4, 0, one, 0, one);
+            }
+        }
+        if (more) {
+            v4i *dst = ldsA + ((c + 1) & 1) * (kSmChunk * 64);
+            dst[tid] = st0;
+            dst[tid + kSmThreads] = st1;
+        }
+        __syncthreads();
+    }
+
+    // acc[t][reg]: query row m = (reg & 3) + 8 (reg >> 2) + 4 h, offset o0 + wave 128 + t 32 + n_lane.
+    // key = dist << 12 | offset inside the workgroup's 1024 (dist <= 64 k < 2^20): smaller distance, then
+    // smaller offset -- the first strict minimum of storage.h:50.
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int k = kq_s[m];
+        unsigned key = 0xffffffffu;
+#pragma unroll
+        for (int t = 0; t < kSmTiles; ++t) {
+            const int lo = wave * kSmWaveOffs + t * 32 + n_lane;
+            const int dist = (64 * k - (int)acc[t][reg]) >> 1;
+            const unsigned cand = ((unsigned)dist << 12) | (unsigned)lo;
+            if (k > 0 && o0 + lo <= n - k && cand < key) key = cand;
+        }
+#pragma unroll
+        for (int s = 16; s >= 1; s >>= 1) { // minimum over the 32 offset columns of this half-wave
+            const unsigned o = (unsigned)__shfl_xor((int)key, s);
+            key = o < key ? o : key;
+        }
+        if (n_lane == 0) red[wave * 32 + m] = key;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        unsigned key = red[tid];
+        for (int w = 1; w < kSmThreads / 64; ++w) key = red[w * 32 + tid] < key ? red[w * 32 + tid] : key;
+        const int qi = g * 32 + tid;
+        if (qi < a.n_q && key != 0xffffffffu) {
+            const unsigned long long full = ((unsigned long long)(key >> 12) << 32) | (unsigned)(o0 + (int)(key & 0xfff));
+            atomicMin(reinterpret_cast<unsigned long long *>(a.best) + (int64_t)qi * a.n_clips + clip, full);
+        }
+    }
+}
+
+size_t hamming_mfma_lds_bytes(int kt)
+{
+    return (size_t)2 * (kSmWgOffs + kt) * 16 + (size_t)2 * kSmChunk * 64 * 16 + 32 * 4 + (kSmThreads / 64) * 32 * 4;
+}
+
+int hamming_mfma_kt_pad(int k_max) { return (k_max + kSmChunk - 1) / kSmChunk * kSmChunk + kSmChunk; }
+
+void launch_expand_queries(const uint64_t *d_q, const int64_t *d_q_off, int n_q, int kt_pad, void *d_qa, hipStream_t s)
+{
+    const int n_groups = (n_q + 31) / 32;
+    dim3 grid((kt_pad * 64 + 255) / 256, n_groups);
+    hipLaunchKernelGGL(expand_queries_kernel, grid, dim3(256), 0, s, d_q, d_q_off, n_q, kt_pad,
+                       reinterpret_cast<v4i *>(d_qa));
+}
+
+void launch_hamming_mfma(const SearchArgs &a, const void *d_qa, int kt_pad, const int *d_gk, int n_max, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_mfma_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    SearchMfmaArgs m;
+    m.db = a.db;
+    m.db_off = a.db_off;
+    m.n_clips = a.n_clips;
+    m.q_off = a.q_off;
+    m.n_q = a.n_q;
+    m.qa = reinterpret_cast<const v4i *>(d_qa);
+    m.kt_pad = kt_pad;
+    m.gk = d_gk;
+    m.best = a.best;
+    const int n_groups = (a.n_q + 31) / 32;
+    m.chunks = (n_max + kSmWgOffs - 1) / kSmWgOffs;
+    dim3 grid((unsigned)m.chunks * (unsigned)a.n_clips, n_groups);
+    hipLaunchKernelGGL(hamming_mfma_kernel, grid, dim3(kSmThreads), hamming_mfma_lds_bytes(a.k_max), s, m);
+}
+
+} // namespace hpfw
