@@ -26,7 +26,9 @@ if ROOT not in sys.path:
 
 PROJECT_FLOP_PER_CLIP = 2.0 * 64 * 2420 * 2400       # filters [64x2420] . frames [2420x2400]
 MFMA_F32_PEAK_TFLOPS = 157.3                         # MI355X_MICROARCH.md: dense f32 MFMA peak
-VALU_PAIR_PEAK = 256 * 4 * 32 * 2.4e9 / 4            # 4 VALU lane-ops per 64-bit pair
+VALU_PAIR_PEAK = 256 * 4 * 32 * 2.4e9 / 4            # xor/popcount kernel: 4 VALU lane-ops per 64-bit pair
+MFMA_FP4_PEAK_PFLOPS = 10.07                         # MI355X_MICROARCH.md: dense FP4 MFMA (32x32x64 in 32 cycles/SIMD)
+FP4_PAIR_PEAK = MFMA_FP4_PEAK_PFLOPS * 1e15 / 2 / 64 # one pair = 64 multiply-adds of +-1
 
 
 def synth_clips_gpu(torch, n_clips, n_samples, seed, device, chunk=25):
@@ -290,9 +292,19 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
                         + (f", all-gather of per-shard top-k over {world} ranks (RCCL)" if world > 1 else ""),
             "ms_per_search": round(dt * 1e3 / reps, 3), "queries_per_s": round(nq * reps / dt, 1),
             "planted_queries_found": ok,
-            "scan_kernel": {"pairs_per_s": round(scan_rate, 1), "valu_peak_pairs_per_s": VALU_PAIR_PEAK,
-                            "frac_of_valu_peak": round(scan_rate / VALU_PAIR_PEAK, 4),
-                            "note": "integer VALU-issue bound (2 v_xor + 2 v_bcnt per pair); HBM is not binding"}}
+            "scan_kernel": _scan_roofline(scan_rate)}
+
+
+def _scan_roofline(scan_rate):
+    if os.environ.get("HPFW_SEARCH_POPC"):
+        return {"kernel": "hamming_scan_kernel (v_xor_b32 + v_bcnt_u32_b32)", "pairs_per_s": round(scan_rate, 1),
+                "bound": "valu", "peak_pairs_per_s": VALU_PAIR_PEAK, "frac": round(scan_rate / VALU_PAIR_PEAK, 4),
+                "note": "integer VALU-issue bound (2 v_xor + 2 v_bcnt per pair); HBM is not binding"}
+    return {"kernel": "hamming_mfma_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, fp4 +-1, exact)",
+            "pairs_per_s": round(scan_rate, 1), "bound": "mfma", "peak_pairs_per_s": round(FP4_PAIR_PEAK, 1),
+            "frac": round(scan_rate / FP4_PAIR_PEAK, 4),
+            "note": "one pair = a 64-term +-1 dot product; the xor/popcount formulation (HPFW_SEARCH_POPC=1) peaks at "
+                    f"{VALU_PAIR_PEAK:.3g} pairs/s on the VALU; HBM is not binding"}
 
 
 if __name__ == "__main__":

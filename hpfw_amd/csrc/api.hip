@@ -885,7 +885,7 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
     for (int64_t i = 0; i < n_clips; ++i) n_max = std::max(n_max, h->db_off[i + 1] - h->db_off[i]);
     if (mfma) {
         if ((rc = ensure((void **)&h->d_qa, &h->qa_cap, (size_t)(qgroup / 32) * kt_pad * 1024))) return rc;
-        if ((rc = ensure((void **)&h->d_gk, &h->gk_cap, (size_t)(qgroup / 32) * 4))) return rc;
+        if ((rc = ensure((void **)&h->d_gk, &h->gk_cap, (size_t)(qgroup / 32) * 8))) return rc;
     }
     std::vector<int> gk;
     for (int64_t g0 = 0; g0 < n_q; g0 += qgroup) {
@@ -901,14 +901,21 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
         a.k_max = (int)k_max;
         a.best = h->d_best;
         if (mfma && n_max > 0) {
-            gk.assign((size_t)(ng + 31) / 32, 0);
-            for (int i = 0; i < ng; ++i)
-                gk[(size_t)i / 32] = std::max(gk[(size_t)i / 32], (int)(q_off[g0 + i + 1] - q_off[g0 + i]));
+            gk.assign((size_t)(ng + 31) / 32 * 2, 0); // per group: longest query, shortest non-empty query
+            int kmin_all = 0;
+            for (int i = 0; i < ng; ++i) {
+                const int kq = (int)(q_off[g0 + i + 1] - q_off[g0 + i]);
+                int &mx = gk[(size_t)i / 32 * 2], &mn = gk[(size_t)i / 32 * 2 + 1];
+                mx = std::max(mx, kq);
+                if (kq > 0) mn = mn == 0 ? kq : std::min(mn, kq);
+                if (kq > 0) kmin_all = kmin_all == 0 ? kq : std::min(kmin_all, kq);
+            }
             HIP_TRY(hipMemcpyAsync(h->d_gk, gk.data(), gk.size() * 4, hipMemcpyHostToDevice, s));
             HIP_TRY(hipStreamSynchronize(s)); // gk is reused by the next group of queries
             Timed t(h, K_SCAN, s);
             hpfw::launch_expand_queries(d_q_hp, a.q_off, ng, kt_pad, h->d_qa, s);
-            hpfw::launch_hamming_mfma(a, h->d_qa, kt_pad, h->d_gk, (int)n_max, s);
+            // offsets exist up to n_max - (shortest query): that many chunks of workgroups per clip
+            hpfw::launch_hamming_mfma(a, h->d_qa, kt_pad, h->d_gk, (int)std::max<int64_t>(n_max - std::min<int64_t>(kmin_all, n_max) + 1, 1), s);
         } else {
             Timed t(h, K_SCAN, s);
             hpfw::launch_hamming_scan(a, s);

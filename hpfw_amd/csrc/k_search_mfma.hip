@@ -79,7 +79,7 @@ struct SearchMfmaArgs {
     int n_q;
     const v4i *qa;        // expanded queries of this launch
     int kt_pad;           // rows of qa per group (multiple of kSmChunk)
-    const int *gk;        // longest query of each group
+    const int *gk;        // [2 g]: longest query of group g; [2 g + 1]: its shortest non-empty one
     uint64_t *best;       // [n_q][n_clips], initialised to ~0
     int chunks;           // workgroups (of 1024 offsets) per clip
 };
@@ -91,13 +91,15 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
     const int clip = blockIdx.x / a.chunks, g = blockIdx.y;
     const int64_t r0 = a.db_off[clip];
     const int n = (int)(a.db_off[clip + 1] - r0);
-    const int kt = a.gk[g];
+    const int kt = a.gk[2 * g];
     if (n <= 0 || kt <= 0) return;
     const int o0 = (blockIdx.x - clip * a.chunks) * kSmWgOffs;
-    if (o0 >= n) return; // no offset of this chunk exists (off <= n - 1 at best)
+    const int kmin = min(a.gk[2 * g + 1], n);
+    if (o0 > n - kmin) return; // no query of the group has an offset in this chunk (off <= n - k)
 
     const int win = kSmWgOffs + kt;                      // window slots (one spare)
-    v4i *ldsB = reinterpret_cast<v4i *>(smem_raw);       // [win][2]: halves h = 0, 1 of each hashprint
+    v4i *ldsB = reinterpret_cast<v4i *>(smem_raw);       // [2][win]: plane h = bits [32 h, 32 h + 32) of each hashprint
+                                                         // (lanes of a half-wave read 16 B apart: no bank conflicts)
     v4i *ldsA = ldsB + 2 * win;                          // [2][kSmChunk][64]
     int *kq_s = reinterpret_cast<int *>(ldsA + 2 * kSmChunk * 64); // [32] effective k of the group's queries
     unsigned *red = reinterpret_cast<unsigned *>(kq_s + 32);       // [8 waves][32 queries]
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
             lo = expand32((uint32_t)w);
             hi = expand32((uint32_t)(w >> 32));
         }
-        ldsB[2 * i] = lo;
-        ldsB[2 * i + 1] = hi;
+        ldsB[i] = lo;
+        ldsB[win + i] = hi;
     }
     if (tid < 32) {
         const int qi = g * 32 + tid;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
 #pragma unroll
     for (int t = 0; t < kSmTiles; ++t) acc[t] = f32x16{0};
     const int one = 0x7f7f7f7f; // E8M0 scale 2^0
-    const v4i *bp = ldsB + 2 * (wave * kSmWaveOffs + n_lane) + h;
+    const v4i *bp = ldsB + h * win + wave * kSmWaveOffs + n_lane;
 
     for (int c = 0; c < n_chunks; ++c) {
         const bool more = c + 1 < n_chunks;
@@ -142,13 +144,13 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
         }
         const v4i *ap = ldsA + (c & 1) * (kSmChunk * 64) + lane;
         const int jn = min(kSmChunk, kt - c * kSmChunk);
-        const v4i *bj = bp + 2 * (c * kSmChunk);
+        const v4i *bj = bp + c * kSmChunk;
         for (int j = 0; j < jn; ++j) {
             const v4i a4 = ap[j * 64];
             const v8i av = {a4.x, a4.y, a4.z, a4.w, 0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < kSmTiles; ++t) {
-                const v4i b4 = bj[2 * (j + 32 * t)];
+                const v4i b4 = bj[j + 32 * t];
                 const v8i bv = {b4.x, b4.y, b4.z, b4.w, 0, 0, 0, 0};
                 acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[t], 4, 4, 0, one, 0, one);
             }

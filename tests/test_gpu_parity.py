@@ -129,7 +129,17 @@ def _ragged(rng, lens):
     return (np.concatenate(hp) if hp else np.zeros(0, np.uint64)), off
 
 
-def test_search_matches_oracle(gpu, oracle):
+@pytest.fixture(params=["mfma", "popcount"])
+def scan_path(request):
+    """both scan kernels: the fp4 matrix-core contraction (default) and the xor/popcount kernel"""
+    import os
+    if request.param == "popcount":
+        os.environ["HPFW_SEARCH_POPC"] = "1"
+    yield request.param
+    os.environ.pop("HPFW_SEARCH_POPC", None)
+
+
+def test_search_matches_oracle(gpu, oracle, scan_path):
     rng = np.random.default_rng(11)
     db_lens = [2320, 305, 40, 1000, 2320, 1, 700, 305, 2320, 64, 333, 2000, 5]
     db, db_off = _ragged(rng, db_lens)
@@ -158,7 +168,7 @@ def test_search_matches_oracle(gpu, oracle):
     assert got[1, 0]["clip"] == 4 and got[1, 0]["offset"] == 2015 and got[1, 0]["dist"] == 0
 
 
-def test_search_ties_and_duplicates(gpu, oracle):
+def test_search_ties_and_duplicates(gpu, oracle, scan_path):
     """identical clips and repeated content: first strict minimum in database order and the
     smallest offset win (storage.h:50,56)"""
     rng = np.random.default_rng(12)
@@ -180,7 +190,48 @@ def test_search_ties_and_duplicates(gpu, oracle):
     assert [int(x) for x in got[1]["clip"][:2]] == [3, 4]
 
 
-def test_search_empty_and_small_index(gpu, oracle):
+def test_search_many_ragged_queries(gpu, oracle, scan_path):
+    """several groups of 32 queries with mixed lengths (empty, 1, longer than some clips), clips from 1
+    to 3000 hashprints (more than one 1024-offset chunk): both kernels equal the oracle"""
+    rng = np.random.default_rng(14)
+    db_lens = [3000, 2320, 1, 2, 64, 1024, 1025, 1329, 2048, 2049, 31, 33, 500, 2320]
+    db, db_off = _ragged(rng, db_lens)
+    lens = [0, 1, 2, 31, 32, 33, 64, 305, 304, 700, 1500, 2400] + [int(x) for x in rng.integers(1, 420, 66)]
+    qs = []
+    for i, k in enumerate(lens):
+        c = i % len(db_lens)
+        if k and k <= db_lens[c] and i % 3:
+            o = int(rng.integers(0, db_lens[c] - k + 1))
+            seg = db[db_off[c] + o: db_off[c] + o + k].copy()
+            seg ^= np.uint64(1) << rng.integers(0, 64, size=k, dtype=np.uint64)
+        else:
+            seg = rng.integers(0, 2 ** 64, size=k, dtype=np.uint64)
+        qs.append(seg)
+    q_off = np.concatenate([[0], np.cumsum([x.size for x in qs])]).astype(np.int64)
+    q = np.concatenate(qs)
+    gpu.index_clear()
+    gpu.index_add(db, db_off)
+    got = gpu.search_topk(q, q_off, 7)
+    want = oracle.search_topk(db, db_off, q, q_off, 7, n_threads=4)
+    assert np.array_equal(got, want)
+    assert (got[0]["clip"] == 0xFFFFFFFF).all()          # the empty query matches nothing
+
+
+def test_search_query_longer_than_lds_window(gpu, oracle):
+    """a query of 6000 hashprints does not fit the matrix-core kernel's LDS window: the library
+    takes the xor/popcount kernel by itself and the answer is the same"""
+    rng = np.random.default_rng(15)
+    db, db_off = _ragged(rng, [7000, 100, 6500])
+    q = np.concatenate([db[db_off[0] + 300: db_off[0] + 6300], rng.integers(0, 2 ** 64, size=40, dtype=np.uint64)])
+    q_off = np.array([0, 6000, 6040], np.int64)
+    gpu.index_clear()
+    gpu.index_add(db, db_off)
+    got = gpu.search_topk(q, q_off, 3)
+    assert np.array_equal(got, oracle.search_topk(db, db_off, q, q_off, 3, n_threads=4))
+    assert got[0, 0]["clip"] == 0 and got[0, 0]["offset"] == 300 and got[0, 0]["dist"] == 0
+
+
+def test_search_empty_and_small_index(gpu, oracle, scan_path):
     rng = np.random.default_rng(13)
     q = rng.integers(0, 2 ** 64, size=30, dtype=np.uint64)
     q_off = np.array([0, 30], np.int64)
