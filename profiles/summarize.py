@@ -59,7 +59,7 @@ def main():
             d["hbm_bytes_per_launch"] = (2.0 * f_ + w_) * 1024.0
     if pmc:
         json.dump(pmc, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
-        pk = pmc.get("project_kernel", {})
+        pk = next((v for k, v in sorted(pmc.items()) if k.startswith("project_kernel<true") or k == "project_kernel"), {})
         if "hbm_bytes_per_launch" in pk:
             json.dump({"project_mfma_hbm_bytes_per_clip": pk["hbm_bytes_per_launch"] / clips,
                        "clips_per_launch_profiled": clips, "source": f"{tag}_pmc.json",
