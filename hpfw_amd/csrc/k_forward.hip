@@ -23,6 +23,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kPairsTile = 64;
 
+// VEC: the tile (nt * n1 samples) is copied in 16-byte pieces -- the launcher checks that every tile
+// starts 16-byte aligned and holds a multiple of 8 samples; otherwise sample by sample.
+template <bool VEC>
 __global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n2, const int16_t *__restrict__ pcm,
                                                         i16x2 *__restrict__ pairs)
 {
@@ -33,15 +36,26 @@ __global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n
     const int nt = min(kPairsTile, n2 - t0);
     const int np = (n1 + 1) / 2;
     const int16_t *src = pcm + (int64_t)clip * n + (int64_t)t0 * n1;
-    for (int i = tid; i < nt * n1; i += 256) tile[i] = src[i];
+    if (VEC) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *t4 = reinterpret_cast<uint4 *>(tile);
+        for (int i = tid; i < nt * n1 / 8; i += 256) t4[i] = s4[i];
+    } else {
+        for (int i = tid; i < nt * n1; i += 256) tile[i] = src[i];
+    }
     __syncthreads();
     i16x2 *dst = pairs + (int64_t)clip * np * n2 + t0;
+    const bool even = (n1 & 1) == 0; // then a pair is one aligned 32-bit word of the tile
     for (int i = tid; i < np * kPairsTile; i += 256) {
         const int p = i / kPairsTile, tt = i - p * kPairsTile;
         if (tt < nt) {
             i16x2 v;
-            v.x = tile[tt * n1 + 2 * p];
-            v.y = (2 * p + 1 < n1) ? tile[tt * n1 + 2 * p + 1] : (short)0;
+            if (even) {
+                v = *reinterpret_cast<const i16x2 *>(tile + tt * n1 + 2 * p);
+            } else {
+                v.x = tile[tt * n1 + 2 * p];
+                v.y = (2 * p + 1 < n1) ? tile[tt * n1 + 2 * p + 1] : (short)0;
+            }
             dst[(int64_t)p * n2 + tt] = v;
         }
     }
@@ -163,8 +177,14 @@ __global__ __launch_bounds__(256, 2) void fwd_cols_kernel(ColsArgs ca, int tile0
 void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s)
 {
     dim3 grid((n2 + kPairsTile - 1) / kPairsTile, n_clips);
-    hipLaunchKernelGGL(pcm_pairs_kernel, grid, dim3(256), (size_t)kPairsTile * n1 * sizeof(int16_t), s, n, n1, n2,
-                       d_pcm, d_pairs);
+    const int tail = n2 % kPairsTile;
+    const bool vec = (reinterpret_cast<uintptr_t>(d_pcm) % 16 == 0) && (n * 2 % 16 == 0) && (kPairsTile * n1 % 8 == 0) &&
+                     (tail * n1 % 8 == 0);
+    const size_t lds = ((size_t)kPairsTile * n1 * sizeof(int16_t) + 15) / 16 * 16;
+    if (vec)
+        hipLaunchKernelGGL(pcm_pairs_kernel<true>, grid, dim3(256), lds, s, n, n1, n2, d_pcm, d_pairs);
+    else
+        hipLaunchKernelGGL(pcm_pairs_kernel<false>, grid, dim3(256), lds, s, n, n1, n2, d_pcm, d_pairs);
 }
 
 size_t fwd_rows_lds_bytes(const RowsArgs &a) { return (size_t)a.n2 * sizeof(cf); }
