@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency section (configs[4])")
+    ap.add_argument("--stream-clips", type=int, default=125000, help="stream: indexed clips per GPU (1 M / 8)")
+    ap.add_argument("--stream-queries", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips-per-core", type=int, default=64)
     args = ap.parse_args()
@@ -198,6 +201,11 @@ def main():
         search = bench_search(torch, tdist if world > 1 else None, gpu, hdist, synth, args, rank, world, device,
                               stream, barrier, max_over_ranks, rehearse)
 
+    stream_res = None
+    if not args.no_search and not args.no_stream:
+        stream_res = bench_stream(torch, tdist if world > 1 else None, gpu, hdist, synth, args, rank, world, device,
+                                  stream, barrier, rehearse)
+
     if rank == 0:
         line = {
             "metric": "hashprints/sec (index) + Hamming matches/sec (search), 30 s@44.1 kHz clips",
@@ -212,6 +220,7 @@ def main():
             "event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
             "kernel_ms_one_pass": split,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "search": search,
+            "stream": stream_res,
         }
         print(json.dumps(line), flush=True)
     gpu.close()
@@ -293,6 +302,62 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
             "ms_per_search": round(dt * 1e3 / reps, 3), "queries_per_s": round(nq * reps / dt, 1),
             "planted_queries_found": ok,
             "scan_kernel": _scan_roofline(scan_rate)}
+
+
+def bench_stream(torch, tdist, gpu, hdist, synth, args, rank, world, device, stream, barrier, rehearse=False):
+    """configs[4] per GPU: an index shard of 1 M / 8 clips resident in HBM; 5 s query windows arrive one
+    at a time (and in batches of 32, as 32 concurrent streams would deliver them); each goes
+    PCM -> hashprints -> scan of the shard -> (N > 1: all-gather + merge) -> host.  Reported: end-to-end
+    latency percentiles on rank 0 and the number of real-time 5 s streams that rate sustains."""
+    import hpfw_amd
+    n_hp, n_local, n_q = 2320, args.stream_clips, args.stream_queries
+    q_samples = 5 * 44100
+    geo = gpu.geometry(q_samples)
+    g = torch.Generator(device=device)
+    g.manual_seed(0x57E + rank)
+    db = torch.randint(-2 ** 63, 2 ** 63 - 1, (n_local, n_hp), dtype=torch.int64, generator=g, device=device)
+    gpu.index_clear()
+    gpu.index_set_clip_base(rank * n_local)
+    gpu.index_add_dev(db.data_ptr(), np.arange(0, (n_local + 1) * n_hp, n_hp, dtype=np.int64), stream)
+    del db
+    pcm = synth_clips_gpu(torch, n_q, q_samples, 0x57E, device)          # the same queries on every rank
+    out = {}
+    for batch in (1, 32):
+        nb = n_q // batch
+        d_hp = torch.empty((batch, geo.n_hp), dtype=torch.int64, device=device)
+        hits = torch.empty((batch, args.topk, 4), dtype=torch.int32, device=device)
+        gathered = torch.empty((world, batch, args.topk, 4), dtype=torch.int32,
+                               device="cpu" if rehearse else device) if world > 1 else None
+        q_off = np.arange(0, (batch + 1) * geo.n_hp, geo.n_hp, dtype=np.int64)
+        lat = []
+        barrier()
+        for i in range(nb + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gpu.extract_dev(pcm[i % nb * batch].data_ptr(), q_samples, batch, d_hp.data_ptr(), stream)
+            gpu.search_topk_dev(d_hp.data_ptr(), q_off, args.topk, hits.data_ptr(), stream)
+            if world > 1 and rehearse:
+                tdist.all_gather([gathered[r] for r in range(world)], hits.cpu())
+                res = gathered.numpy()
+            elif world > 1:
+                tdist.all_gather_into_tensor(gathered, hits)
+                res = gathered.cpu().numpy()
+            else:
+                res = hits.cpu().numpy()
+            if world > 1:
+                hpfw_amd.merge_topk(res.reshape(world, batch, args.topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(
+                    world, batch, args.topk), args.topk)
+            if i >= 2:                                                       # two warm-up rounds
+                lat.append((time.perf_counter() - t0) * 1e3)
+        lat = np.sort(np.array(lat))
+        qps = batch * 1e3 / float(lat.mean())
+        out[f"batch_{batch}"] = {"latency_ms_p50": round(float(np.percentile(lat, 50)), 3),
+                                 "latency_ms_p99": round(float(np.percentile(lat, 99)), 3),
+                                 "queries_per_s": round(qps, 1), "realtime_5s_streams": int(qps * 5), "rounds": int(lat.size)}
+    out["workload"] = (f"configs[4] per GPU: {n_local}-clip index shard ({n_local * n_hp * 8 / 1e9:.2f} GB of hashprints) "
+                       f"in HBM, 5 s PCM windows -> extraction -> top-{args.topk} scan"
+                       + (f" -> all-gather over {world} ranks + merge" if world > 1 else "") + " -> host, measured on rank 0")
+    return out
 
 
 def _scan_roofline(scan_rate):

@@ -878,8 +878,12 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
     qgroup = std::min<int64_t>(qgroup, (n_q + 31) / 32 * 32);
     if ((rc = ensure((void **)&h->d_best, &h->best_cap, (size_t)qgroup * n_clips * 8))) return rc;
     // The scan runs on the matrix cores (k_search_mfma.hip) unless the window does not fit the LDS
-    // (queries of several thousand hashprints) or HPFW_SEARCH_POPC asks for the xor/popcount kernel.
-    const bool mfma = !std::getenv("HPFW_SEARCH_POPC") && hpfw::hamming_mfma_lds_bytes((int)k_max) <= 160 * 1024 && k_max > 0;
+    // (queries of several thousand hashprints), there are only a few queries, or HPFW_SEARCH_POPC asks for
+    // the xor/popcount kernel (HPFW_SEARCH_MFMA forces the matrix path for any number of queries).
+    // A group of 32 queries is one MFMA tile: with fewer than 8 queries most of its rows would be padding
+    // and the popcount kernel (one workgroup per 8 queries) does less work.
+    const bool mfma = !std::getenv("HPFW_SEARCH_POPC") && hpfw::hamming_mfma_lds_bytes((int)k_max) <= 160 * 1024 &&
+                      k_max > 0 && (n_q >= 8 || std::getenv("HPFW_SEARCH_MFMA"));
     const int kt_pad = hpfw::hamming_mfma_kt_pad((int)k_max);
     int64_t n_max = 0;
     for (int64_t i = 0; i < n_clips; ++i) n_max = std::max(n_max, h->db_off[i + 1] - h->db_off[i]);

@@ -17,7 +17,6 @@ namespace hpfw {
 extern __shared__ __align__(16) unsigned char smem_raw[];
 
 constexpr int kHsThreads = 256;
-constexpr int kHsQt = 8;
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
@@ -29,6 +28,9 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
     return v;
 }
 
+// kHsQt = queries per workgroup (8, or fewer when there are fewer queries: a single streaming query
+// would otherwise pay for seven empty slots)
+template <int kHsQt>
 __global__ __launch_bounds__(kHsThreads) void hamming_scan_kernel(SearchArgs a)
 {
     uint64_t *r_lds = reinterpret_cast<uint64_t *>(smem_raw);                  // [256 + k_max]
@@ -175,18 +177,30 @@ __global__ __launch_bounds__(256) void topk_kernel(const uint64_t *__restrict__ 
     }
 }
 
-static int g_hs_lds_set = 0;
+template <int QT>
+static void launch_hamming_scan_t(const SearchArgs &a, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_scan_kernel<QT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const size_t lds = ((size_t)kHsThreads + a.k_max + 4 * QT) * sizeof(uint64_t);
+    dim3 grid(a.n_clips, (a.n_q + QT - 1) / QT);
+    hipLaunchKernelGGL(hamming_scan_kernel<QT>, grid, dim3(kHsThreads), lds, s, a);
+}
 
 void launch_hamming_scan(const SearchArgs &a, hipStream_t s)
 {
-    if (!g_hs_lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_scan_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        g_hs_lds_set = 1;
-    }
-    const size_t lds = ((size_t)kHsThreads + a.k_max + 4 * kHsQt) * sizeof(uint64_t);
-    dim3 grid(a.n_clips, (a.n_q + kHsQt - 1) / kHsQt);
-    hipLaunchKernelGGL(hamming_scan_kernel, grid, dim3(kHsThreads), lds, s, a);
+    if (a.n_q == 1)
+        launch_hamming_scan_t<1>(a, s);
+    else if (a.n_q == 2)
+        launch_hamming_scan_t<2>(a, s);
+    else if (a.n_q <= 4)
+        launch_hamming_scan_t<4>(a, s);
+    else
+        launch_hamming_scan_t<8>(a, s);
 }
 
 void launch_topk(const uint64_t *d_best, int n_q, int n_clips, int k, uint32_t clip_base, void *d_out,

@@ -133,10 +133,10 @@ def _ragged(rng, lens):
 def scan_path(request):
     """both scan kernels: the fp4 matrix-core contraction (default) and the xor/popcount kernel"""
     import os
-    if request.param == "popcount":
-        os.environ["HPFW_SEARCH_POPC"] = "1"
+    os.environ["HPFW_SEARCH_POPC" if request.param == "popcount" else "HPFW_SEARCH_MFMA"] = "1"
     yield request.param
     os.environ.pop("HPFW_SEARCH_POPC", None)
+    os.environ.pop("HPFW_SEARCH_MFMA", None)
 
 
 def test_search_matches_oracle(gpu, oracle, scan_path):
