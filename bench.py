@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-search", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the streaming-latency section (configs[4])")
+    ap.add_argument("--no-learn", action="store_true", help="skip the filter-learning section (index() only)")
+    ap.add_argument("--learn-clips", type=int, default=256)
     ap.add_argument("--stream-clips", type=int, default=125000, help="stream: indexed clips per GPU (1 M / 8)")
     ap.add_argument("--stream-queries", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,6 +203,10 @@ def main():
         search = bench_search(torch, tdist if world > 1 else None, gpu, hdist, synth, args, rank, world, device,
                               stream, barrier, max_over_ranks, rehearse)
 
+    learn = None
+    if not args.no_learn and rank == 0 and world == 1:
+        learn = bench_learn(torch, gpu, args, pcm, n_samples, stream, filt)
+
     stream_res = None
     if not args.no_search and not args.no_stream:
         stream_res = bench_stream(torch, tdist if world > 1 else None, gpu, hdist, synth, args, rank, world, device,
@@ -220,7 +226,7 @@ def main():
             "event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
             "kernel_ms_one_pass": split,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "search": search,
-            "stream": stream_res,
+            "stream": stream_res, "filter_learning": learn,
         }
         print(json.dumps(line), flush=True)
     gpu.close()
@@ -302,6 +308,30 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
             "ms_per_search": round(dt * 1e3 / reps, 3), "queries_per_s": round(nq * reps / dt, 1),
             "planted_queries_found": ok,
             "scan_kernel": _scan_roofline(scan_rate)}
+
+
+def bench_learn(torch, gpu, args, pcm, n_samples, stream, filt):
+    """index()-only work: frame covariance of the first clips of the
+    batch accumulated on the GPU (front end included), then the eigen-solve on the host."""
+    n = min(args.learn_clips, pcm.shape[0])
+    gpu.cov_reset()
+    gpu.cov_accumulate_dev(pcm.data_ptr(), n_samples, n, stream)
+    torch.cuda.synchronize()
+    gpu.cov_reset()
+    t0 = time.perf_counter()
+    gpu.cov_accumulate_dev(pcm.data_ptr(), n_samples, n, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    gpu.learn_filters()
+    et = time.perf_counter() - t1
+    gpu.set_filters(filt)                                    # back to the fixture for the sections that follow
+    n_frames = gpu.geometry(n_samples).n_frames
+    flop = 2.0 * 2420 * 2420 * n_frames                      # per clip, full matrix (SURVEY.md 8(d): 28.1 GFLOP)
+    return {"covariance_clips_per_s": round(n / dt, 1), "clips": n, "ms": round(dt * 1e3, 2),
+            "equivalent_tflops_full_matrix": round(flop * n / dt / 1e12, 1),
+            "eigen_solve_s": round(et, 2),
+            "note": "front end + covariance kernels per clip; the eigen-solve runs once per index on the host"}
 
 
 def bench_stream(torch, tdist, gpu, hdist, synth, args, rank, world, device, stream, barrier, rehearse=False):

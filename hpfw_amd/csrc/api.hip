@@ -107,16 +107,14 @@ struct hpfw_gpu {
     size_t q_off_cap = 0;
     // filter learning: accum_cov of ParallelCollector (parallel_collector.h:76), upper tiles only
     float *d_cov = nullptr;
-    float *d_mu = nullptr;
+    float *d_cov_ws = nullptr; // scratch of the covariance kernels
+    size_t cov_ws_cap = 0;
     void *d_qa = nullptr;   // queries expanded to fp4 for the matrix-core scan
     size_t qa_cap = 0;
     int *d_gk = nullptr;    // longest query of each group of 32
     size_t gk_cap = 0;
     float *d_clipmax = nullptr; // per-clip maximum magnitude (reference level of the dB conversion)
     size_t clipmax_cap = 0;
-    float *d_cov_part = nullptr;
-    size_t cov_part_cap = 0;
-    size_t mu_cap = 0;
     int *d_cov_tiles = nullptr;
     int64_t cov_files = 0;
     // timing
@@ -370,11 +368,10 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
         if (p) (void)hipFree(p);
     if (h->d_fpack) (void)hipFree(h->d_fpack);
     if (h->d_cov) (void)hipFree(h->d_cov);
-    if (h->d_mu) (void)hipFree(h->d_mu);
+    if (h->d_cov_ws) (void)hipFree(h->d_cov_ws);
     if (h->d_qa) (void)hipFree(h->d_qa);
     if (h->d_gk) (void)hipFree(h->d_gk);
     if (h->d_clipmax) (void)hipFree(h->d_clipmax);
-    if (h->d_cov_part) (void)hipFree(h->d_cov_part);
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
     if (h->d_db) (void)hipFree(h->d_db);
     if (h->d_db_off) (void)hipFree(h->d_db_off);
@@ -645,16 +642,13 @@ int hpfw_gpu_cov_accumulate_db(hpfw_gpu *h, const float *d_db, int64_t n_clips, 
     hipStream_t s = (hipStream_t)stream;
     int rc = cov_prepare(h, s);
     if (rc) return rc;
-    const int64_t chunk = 4096;
-    if ((rc = ensure((void **)&h->d_mu, &h->mu_cap, (size_t)std::min(chunk, std::max<int64_t>(n_clips, 1)) * hpfw::kFrame * 4)))
-        return rc;
-    if ((rc = ensure((void **)&h->d_cov_part, &h->cov_part_cap,
-                     hpfw::cov_part_bytes((int)std::min(chunk, std::max<int64_t>(n_clips, 1)), (int)c))))
+    const int64_t chunk = 128; // clips per pass: bounds the workspace (Z, correction vectors, partial sums)
+    if ((rc = ensure((void **)&h->d_cov_ws, &h->cov_ws_cap,
+                     hpfw::cov_workspace_bytes((int)std::min(chunk, std::max<int64_t>(n_clips, 1)), (int)c))))
         return rc;
     for (int64_t c0 = 0; c0 < n_clips; c0 += chunk) {
         const int nb = (int)std::min(chunk, n_clips - c0);
-        hpfw::launch_frame_mean(d_db + c0 * 121 * c, nb, (int)c, h->d_mu, s);
-        hpfw::launch_cov(d_db + c0 * 121 * c, h->d_mu, nb, (int)c, h->d_cov_tiles, h->d_cov_part, h->d_cov, s);
+        hpfw::launch_cov(d_db + c0 * 121 * c, nb, (int)c, h->d_cov_tiles, h->d_cov_ws, h->d_cov, s);
         if ((rc = check_launch("covariance"))) return rc;
     }
     h->cov_files += n_clips;

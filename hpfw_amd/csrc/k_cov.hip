@@ -3,12 +3,24 @@
 // Replaces HashprintHandle::calc_cov + the accumulation under a mutex (reference
 // include/hpfw/core/hashprint_handle.h:96-102, include/hpfw/core/parallel_collector.h:93-97):
 // per file, frames^T [n_frames x 2420] is centred column-wise (its own mean over frames) and
-// cov = centred^T centred / (n_frames - 1) is added to accum_cov.  28 GFLOP per 30 s clip -- the
-// largest FLOP item of the whole product -- so it runs on v_mfma_f32_32x32x2_f32 with the same
-// implicit im2col as the projection: frames[b*20 + t, n] = S[b, n + t] is read from an LDS slab of
-// S, never materialised.  Only tiles on or above the diagonal are computed (190 of 361); the host
-// mirrors the result.  Accuracy bar: tolerance against a float64 numpy evaluation (the reference's
-// own result depends on MKL's summation order).
+// cov = centred^T centred / (n_frames - 1) is added to accum_cov: 28 GFLOP per 30 s clip as a dense
+// product, the largest FLOP item of the whole reference.
+//
+// The frames are windows of one spectrogram, frames[b*20 + t, n] = S[b, n + t], so the product is a
+// set of lag correlations and does not need 2420 x 2420 x n_frames multiply-adds.  With Z = S minus
+// each bin's mean over the clip, d = t - t' >= 0 and U the number of columns:
+//   sum_n frames[(b,t), n] frames[(b',t'), n]
+//     = G[(b,d), b']                      G[(b,d), b'] = sum_u Z[b, u + d] Z[b', u]   (all u in range)
+//     - sum_{j=1..min(t,t')} Z[b, t - j] Z[b', t' - j]                                 (columns before the window)
+//     - sum_{j=0..18-max(t,t')} Z[b, nf + t + j] Z[b', nf + t' + j]                    (columns after it)
+// and the centring on the window means adds - nf delta[(b,t)] delta[(b',t')].  The three corrections
+// are 39 rank-one terms: V V^T with V [2420 x 39] per clip.  So per clip
+//   lag_corr_kernel   G = [2420 x U] . [U x 121]     1.4 GFLOP on v_mfma_f32_32x32x2_f32 (implicit im2col)
+//   vvt_kernel        V V^T, tiles on or above the diagonal   0.23 GFLOP on the same instruction
+// instead of 14.9 GFLOP, and one expansion G -> [2420 x 2420] per call instead of per clip.  The
+// result differs from the dense product only by rounding (tolerance-tested against float64; the
+// reference's own bits depend on MKL's summation order).  Partial sums are kept per split of the
+// work and reduced in a fixed order, so the result does not depend on scheduling.
 #include "kernels.h"
 
 #include <algorithm>
@@ -17,99 +29,118 @@ namespace hpfw {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// mu[clip][b*20 + t] = mean over n < nf of S[b][n + t]
-__global__ __launch_bounds__(256) void frame_mean_kernel(const float *__restrict__ sdb, int c, int nf,
-                                                         float *__restrict__ mu)
+constexpr int kCvTile = 128;                 // rows (and columns) of an output tile
+constexpr int kCvVec = 40;                   // correction vectors per clip (39 used)
+constexpr int kLgRowsPad = 19 * kCvTile;     // 2432 >= 2420 rows (b, d) of G
+constexpr int kLgCols = 128;                 // >= 121 bins
+constexpr int kLgChunk = 64;                 // spectrogram columns per staged chunk
+constexpr int kLgRowA = kLgChunk + kCtx;     // 84: slab row stride of the shifted operand
+constexpr int kLgRowB = kLgChunk + 1;        // 65: slab row stride of the plain operand (odd: no bank conflicts)
+constexpr int kLgBinsA = 8;                  // bins a 128-wide range of rows (b, d) can touch
+constexpr int kLgSplits = 53;                // 19 x 53 = 1007 workgroups: four per CU
+constexpr int kVvSplits = 8;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One workgroup per (bin, clip): Z = S - mean over the clip's columns (in a workspace), and this bin's 20
+// rows of the clip's correction vectors V [40][2420]:
+//   v 0..18  (j = 1..19):  Z[b, t - j]        for t >= j,        else 0
+//   v 19..37 (j = 0..18):  Z[b, nf + t + j]   for t + j <= 18,   else 0
+//   v 38:                  sqrt(nf) * (mean of Z over the window of t)
+__global__ __launch_bounds__(256) void lag_prep_kernel(const float *__restrict__ sdb, int c, int nf,
+                                                       float *__restrict__ z, float *__restrict__ v)
 {
     __shared__ double part[4];
+    __shared__ float edge[2 * kCtx]; // Z[0..19] and Z[nf - 1 .. nf + 18]
     const int b = blockIdx.x, clip = blockIdx.y, tid = threadIdx.x;
     const float *row = sdb + ((int64_t)clip * kBins + b) * c;
+    float *zrow = z + ((int64_t)clip * kBins + b) * c;
     double s = 0.0;
     for (int i = tid; i < c; i += 256) s += (double)row[i];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    s = wave_sum(s);
     if ((tid & 63) == 0) part[tid >> 6] = s;
     __syncthreads();
+    const float m = (float)((part[0] + part[1] + part[2] + part[3]) / (double)c);
+    __syncthreads();
+    double zs = 0.0;
+    for (int i = tid; i < c; i += 256) {
+        const float zz = row[i] - m;
+        zrow[i] = zz;
+        zs += (double)zz;
+        if (i < kCtx) edge[i] = zz;
+        if (i >= nf - 1) edge[kCtx + i - (nf - 1)] = zz;
+    }
+    zs = wave_sum(zs);
+    if ((tid & 63) == 0) part[tid >> 6] = zs;
+    __syncthreads();
+    const double total = part[0] + part[1] + part[2] + part[3];
+    float *vc = v + (int64_t)clip * kCvVec * kFrame + b * kCtx;
     if (tid < kCtx) {
-        double tot = part[0] + part[1] + part[2] + part[3];
-        for (int i = 0; i < tid; ++i) tot -= (double)row[i];          // columns before the window
-        for (int i = tid + nf; i < c; ++i) tot -= (double)row[i];     // columns after it
-        mu[(int64_t)clip * kFrame + b * kCtx + tid] = (float)(tot / (double)nf);
+        const int t = tid;
+        double win = total;
+        for (int i = 0; i < t; ++i) win -= (double)edge[i];                         // columns before the window
+        for (int i = t + nf; i < c; ++i) win -= (double)edge[kCtx + i - (nf - 1)];  // columns after it
+        vc[(int64_t)38 * kFrame + t] = (float)(sqrt((double)nf) * (win / (double)nf));
+        vc[(int64_t)39 * kFrame + t] = 0.0f;
+        for (int j = 1; j <= 19; ++j) vc[(int64_t)(j - 1) * kFrame + t] = t >= j ? edge[t - j] : 0.0f;
+        for (int j = 0; j <= 18; ++j) vc[(int64_t)(19 + j) * kFrame + t] = t + j <= 18 ? edge[kCtx + 1 + t + j] : 0.0f;
     }
 }
 
-constexpr int kCvTile = 128;                // rows (and columns) of the covariance per workgroup
-constexpr int kCvFrames = 256;              // frames per staged chunk
-constexpr int kCvRow = kCvFrames + kCtx;    // LDS slab row stride (276 floats)
-constexpr int kCvBins = 8;                  // bins a 128-wide range of k = b*20 + t can touch
-constexpr int kCvSplits = 16;               // work splits per tile pair (190 x 16 workgroups)
-
-// One workgroup = one 128 x 128 tile pair x one split of the work items (item = clip x 256-frame
-// chunk): part[split][tile][128][128] = sum over the split's items of
-// (X[ka][n] - mu[ka]) (X[kb][n] - mu[kb]); wave (wr, wc) of the 2 x 2 wave grid owns 64 x 64.
-// Splitting is what fills the chip: 190 tile pairs alone would leave a quarter of the CUs idle and
-// the rest with one wave per SIMD.  The partials are summed in split order by cov_reduce_kernel,
-// so the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void cov_kernel(const float *__restrict__ sdb, const float *__restrict__ mu,
-                                                  int c, int nf, int n_chunks, int n_items, int items_per_split,
-                                                  const int2 *__restrict__ tiles, float *__restrict__ part)
+// part[split][row (b,d)][bin b'] = sum over the split's (clip, 64-column chunk) items of Z[b, u + d] Z[b', u].
+// Workgroup = 128 rows x 128 bins; wave (wr, wc) of the 2 x 2 wave grid owns 64 x 64.
+__global__ __launch_bounds__(256) void lag_corr_kernel(const float *__restrict__ z, int c, int n_chunks, int n_items,
+                                                       int items_per_split, float *__restrict__ part)
 {
-    __shared__ float slab[2][kCvBins * kCvRow];
+    __shared__ float slab_a[kLgBinsA * kLgRowA];
+    __shared__ float slab_b[kLgCols * kLgRowB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, hb = lane >> 5, li = lane & 31;
-    const int2 tile = tiles[blockIdx.x];
-    const int k0[2] = {tile.x * kCvTile, tile.y * kCvTile};
-    const int bin0[2] = {k0[0] / kCtx, k0[1] / kCtx};
-    const bool same = tile.x == tile.y;
-    int krow[2][2], off[2][2]; // [operand A/B][32-row tile]
-    bool valid[2][2];
+    const int r0 = blockIdx.x * kCvTile, bin0 = r0 / kCtx;
+    int off_a[2], off_b[2];
+    bool ok_a[2];
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int k = k0[o] + (o == 0 ? wr : wc) * 64 + t * 32 + li;
-            valid[o][t] = k < kFrame;
-            const int kk = valid[o][t] ? k : kFrame - 1;
-            krow[o][t] = kk;
-            off[o][t] = (kk / kCtx - bin0[o]) * kCvRow + kk % kCtx;
-        }
+    for (int t = 0; t < 2; ++t) {
+        const int r = r0 + wr * 64 + t * 32 + li;
+        ok_a[t] = r < kFrame;
+        const int rr = ok_a[t] ? r : kFrame - 1;
+        off_a[t] = (rr / kCtx - bin0) * kLgRowA + rr % kCtx;
+        off_b[t] = (wc * 64 + t * 32 + li) * kLgRowB;
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
-
     const int item0 = blockIdx.y * items_per_split, item1 = min(n_items, item0 + items_per_split);
-    int cur_clip = -1;
-    float m[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
     for (int item = item0; item < item1; ++item) {
-        const int clip = item / n_chunks, n0 = (item - clip * n_chunks) * kCvFrames;
-        const float *S = sdb + (int64_t)clip * kBins * c;
-        if (clip != cur_clip) {
-            cur_clip = clip;
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) m[o][t] = mu[(int64_t)clip * kFrame + krow[o][t]];
+        const int clip = item / n_chunks, u0 = (item - clip * n_chunks) * kLgChunk;
+        const float *Z = z + (int64_t)clip * kBins * c;
+        __syncthreads();
+        for (int i = tid; i < kLgBinsA * (kLgChunk + kCtx - 1); i += 256) {
+            const int bl = i / (kLgChunk + kCtx - 1), col = i - bl * (kLgChunk + kCtx - 1);
+            const int b = bin0 + bl, gc = u0 + col;
+            slab_a[bl * kLgRowA + col] = (b < kBins && gc < c) ? Z[(int64_t)b * c + gc] : 0.0f;
         }
-        const int nfr = min(kCvFrames, nf - n0);
+        for (int i = tid; i < kLgCols * kLgChunk; i += 256) {
+            const int b = i / kLgChunk, col = i - b * kLgChunk;
+            const int gc = u0 + col;
+            slab_b[b * kLgRowB + col] = (b < kBins && gc < c) ? Z[(int64_t)b * c + gc] : 0.0f;
+        }
         __syncthreads();
-        for (int o = 0; o < (same ? 1 : 2); ++o)
-            for (int i = tid; i < kCvBins * (kCvFrames + kCtx - 1); i += 256) {
-                const int bl = i / (kCvFrames + kCtx - 1), col = i - bl * (kCvFrames + kCtx - 1);
-                const int b = bin0[o] + bl, gc = n0 + col;
-                slab[o][bl * kCvRow + col] = (b < kBins && gc < c) ? S[(int64_t)b * c + gc] : 0.0f;
-            }
-        __syncthreads();
-        const float *sa = slab[0], *sb = slab[same ? 0 : 1];
-        for (int st = 0; st < (nfr + 1) / 2; ++st) {
+#pragma unroll 4
+        for (int st = 0; st < kLgChunk / 2; ++st) {
             const int n = 2 * st + hb;
-            const bool in = n < nfr;
             float av[2], bv[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                av[t] = (in && valid[0][t]) ? sa[off[0][t] + n] - m[0][t] : 0.0f;
-                bv[t] = (in && valid[1][t]) ? sb[off[1][t] + n] - m[1][t] : 0.0f;
+                av[t] = ok_a[t] ? slab_a[off_a[t] + n] : 0.0f;
+                bv[t] = slab_b[off_b[t] + n];
             }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
@@ -117,7 +148,72 @@ __global__ __launch_bounds__(256) void cov_kernel(const float *__restrict__ sdb,
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
         }
     }
-    // D layout: column = lane & 31 (operand B row), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // D layout: column = lane & 31 (operand B: bin), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float *out = part + (int64_t)blockIdx.y * kLgRowsPad * kLgCols;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = r0 + wr * 64 + ta * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hb;
+                out[(int64_t)r * kLgCols + wc * 64 + tb * 32 + li] = acc[ta][tb][reg];
+            }
+}
+
+// gsum = part[0] + part[1] + ... in split order
+__global__ __launch_bounds__(256) void lag_reduce_kernel(const float *__restrict__ part, int n_splits,
+                                                         float *__restrict__ gsum)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.0f;
+    for (int g = 0; g < n_splits; ++g) s += part[(int64_t)g * kLgRowsPad * kLgCols + i];
+    gsum[i] = s;
+}
+
+// part[split][tile][128][128] = sum over the split's clips of V V^T on the tile pair tiles[blockIdx.x];
+// operands straight from global memory (a lane's row of a correction vector: 128 contiguous bytes per
+// half-wave), two correction vectors per MFMA.
+__global__ __launch_bounds__(256) void vvt_kernel(const float *__restrict__ v, int n_clips, int clips_per_split,
+                                                  const int2 *__restrict__ tiles, float *__restrict__ part)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, hb = lane >> 5, li = lane & 31;
+    const int2 tile = tiles[blockIdx.x];
+    int ka[2], kb[2];
+    bool ok_a[2], ok_b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        ka[t] = tile.x * kCvTile + wr * 64 + t * 32 + li;
+        kb[t] = tile.y * kCvTile + wc * 64 + t * 32 + li;
+        ok_a[t] = ka[t] < kFrame;
+        ok_b[t] = kb[t] < kFrame;
+        ka[t] = ok_a[t] ? ka[t] : 0;
+        kb[t] = ok_b[t] ? kb[t] : 0;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
+    const int c0 = blockIdx.y * clips_per_split, c1 = min(n_clips, c0 + clips_per_split);
+    for (int clip = c0; clip < c1; ++clip) {
+        const float *vc = v + ((int64_t)clip * kCvVec + hb) * kFrame;
+#pragma unroll 4
+        for (int st = 0; st < kCvVec / 2; ++st) {
+            const float *vr = vc + (int64_t)2 * st * kFrame;
+            float av[2], bv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                av[t] = ok_a[t] ? vr[ka[t]] : 0.0f;
+                bv[t] = ok_b[t] ? vr[kb[t]] : 0.0f;
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
+        }
+    }
     float *out = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kCvTile * kCvTile);
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta)
@@ -130,22 +226,23 @@ __global__ __launch_bounds__(256) void cov_kernel(const float *__restrict__ sdb,
             }
 }
 
-// accum[ka][kb] += scale * (part[0] + part[1] + ... in split order)
-__global__ __launch_bounds__(256) void cov_reduce_kernel(const float *__restrict__ part, int n_splits, float scale,
-                                                         const int2 *__restrict__ tiles, float *__restrict__ accum)
+// accum[k][k'] += scale * (G[(b, d), b'] or G[(b', -d), b]  -  sum over splits of the V V^T partial tiles)
+// for k = (b, t), k' = (b', t'), d = t - t', on the tile pair tiles[blockIdx.x]
+__global__ __launch_bounds__(256) void cov_expand_kernel(const float *__restrict__ gsum, const float *__restrict__ vpart,
+                                                         int n_vsplits, float scale, const int2 *__restrict__ tiles,
+                                                         float *__restrict__ accum)
 {
     const int2 tile = tiles[blockIdx.x];
     const int e = blockIdx.y * 256 + threadIdx.x;
     const int ka = tile.x * kCvTile + e / kCvTile, kb = tile.y * kCvTile + e % kCvTile;
-    float s = 0.0f;
-    for (int g = 0; g < n_splits; ++g)
-        s += part[((int64_t)g * gridDim.x + blockIdx.x) * (kCvTile * kCvTile) + e];
-    if (ka < kFrame && kb < kFrame) accum[(int64_t)ka * kFrame + kb] += scale * s;
-}
-
-void launch_frame_mean(const float *d_db, int n_clips, int c, float *d_mu, hipStream_t s)
-{
-    hipLaunchKernelGGL(frame_mean_kernel, dim3(kBins, n_clips), dim3(256), 0, s, d_db, c, c - (kCtx - 1), d_mu);
+    float vv = 0.0f;
+    for (int g = 0; g < n_vsplits; ++g) vv += vpart[((int64_t)g * gridDim.x + blockIdx.x) * (kCvTile * kCvTile) + e];
+    if (ka < kFrame && kb < kFrame) {
+        const int ba = ka / kCtx, ta = ka - ba * kCtx, bb = kb / kCtx, tb = kb - bb * kCtx;
+        const float g = ta >= tb ? gsum[(int64_t)(ba * kCtx + ta - tb) * kLgCols + bb]
+                                 : gsum[(int64_t)(bb * kCtx + tb - ta) * kLgCols + ba];
+        accum[(int64_t)ka * kFrame + kb] += scale * (g - vv);
+    }
 }
 
 int cov_tile_count()
@@ -166,29 +263,47 @@ void cov_tile_list(int *xy)
         }
 }
 
-int cov_splits(int n_clips, int c)
+// workspace of one launch_cov over n_clips clips of c columns: Z, V, partial G, G, partial V V^T
+static size_t cov_ws_floats(int n_clips, int c, size_t off[5])
 {
-    const int nf = c - (kCtx - 1), n_chunks = (nf + kCvFrames - 1) / kCvFrames;
-    return (int)std::min<int64_t>(kCvSplits, (int64_t)n_clips * n_chunks);
+    size_t o = 0;
+    off[0] = o;
+    o += (size_t)n_clips * kBins * c;
+    off[1] = o;
+    o += (size_t)n_clips * kCvVec * kFrame;
+    off[2] = o;
+    o += (size_t)kLgSplits * kLgRowsPad * kLgCols;
+    off[3] = o;
+    o += (size_t)kLgRowsPad * kLgCols;
+    off[4] = o;
+    o += (size_t)kVvSplits * cov_tile_count() * kCvTile * kCvTile;
+    return o;
 }
 
-size_t cov_part_bytes(int n_clips, int c)
+size_t cov_workspace_bytes(int n_clips, int c)
 {
-    return (size_t)cov_splits(n_clips, c) * cov_tile_count() * kCvTile * kCvTile * sizeof(float);
+    size_t off[5];
+    return cov_ws_floats(n_clips, c, off) * sizeof(float);
 }
 
-void launch_cov(const float *d_db, const float *d_mu, int n_clips, int c, const int *d_tiles, float *d_part,
-                float *d_accum, hipStream_t s)
+void launch_cov(const float *d_db, int n_clips, int c, const int *d_tiles, float *d_ws, float *d_accum, hipStream_t s)
 {
-    const int nf = c - (kCtx - 1), n_chunks = (nf + kCvFrames - 1) / kCvFrames;
-    const int n_items = n_clips * n_chunks, n_splits = cov_splits(n_clips, c);
-    const int per = (n_items + n_splits - 1) / n_splits;
+    size_t off[5];
+    cov_ws_floats(n_clips, c, off);
+    float *z = d_ws + off[0], *v = d_ws + off[1], *gpart = d_ws + off[2], *gsum = d_ws + off[3], *vpart = d_ws + off[4];
+    const int nf = c - (kCtx - 1);
     const float scale = 1.0f / (float)(nf - 1); // hashprint_handle.h:101: / (rows - 1)
     const int2 *tiles = reinterpret_cast<const int2 *>(d_tiles);
-    hipLaunchKernelGGL(cov_kernel, dim3(cov_tile_count(), n_splits), dim3(256), 0, s, d_db, d_mu, c, nf, n_chunks,
-                       n_items, per, tiles, d_part);
-    hipLaunchKernelGGL(cov_reduce_kernel, dim3(cov_tile_count(), kCvTile * kCvTile / 256), dim3(256), 0, s, d_part,
-                       n_splits, scale, tiles, d_accum);
+    hipLaunchKernelGGL(lag_prep_kernel, dim3(kBins, n_clips), dim3(256), 0, s, d_db, c, nf, z, v);
+    const int n_chunks = (c + kLgChunk - 1) / kLgChunk, n_items = n_clips * n_chunks;
+    const int g_splits = std::min(kLgSplits, n_items), per = (n_items + g_splits - 1) / g_splits;
+    hipLaunchKernelGGL(lag_corr_kernel, dim3(kLgRowsPad / kCvTile, g_splits), dim3(256), 0, s, z, c, n_chunks, n_items,
+                       per, gpart);
+    hipLaunchKernelGGL(lag_reduce_kernel, dim3(kLgRowsPad * kLgCols / 256), dim3(256), 0, s, gpart, g_splits, gsum);
+    const int v_splits = std::min(kVvSplits, n_clips), cper = (n_clips + v_splits - 1) / v_splits;
+    hipLaunchKernelGGL(vvt_kernel, dim3(cov_tile_count(), v_splits), dim3(256), 0, s, v, n_clips, cper, tiles, vpart);
+    hipLaunchKernelGGL(cov_expand_kernel, dim3(cov_tile_count(), kCvTile * kCvTile / 256), dim3(256), 0, s, gsum, vpart,
+                       v_splits, scale, tiles, d_accum);
 }
 
 } // namespace hpfw

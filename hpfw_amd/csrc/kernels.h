@@ -78,14 +78,12 @@ void launch_project(const float *d_fpack, const float *d_db, const float *d_tmax
 void launch_pack(const float *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s);
 
 // ---- filter learning (index() only) -------------------------------------------------------
-// per-clip mean of every frame component: mu [n_clips][2420]
-void launch_frame_mean(const float *d_db, int n_clips, int c, float *d_mu, hipStream_t s);
-// accum [2420][2420] (tiles on or above the diagonal) += sum over clips of centred^T centred / (nf - 1)
+// accum [2420][2420] (tiles on or above the diagonal) += sum over clips of centred^T centred / (nf - 1),
+// by lag correlations (k_cov.hip); d_ws: cov_workspace_bytes(n_clips, c) of scratch
 int cov_tile_count();
 void cov_tile_list(int *xy /* 2 * cov_tile_count() */);
-size_t cov_part_bytes(int n_clips, int c); // workspace of per-split partial tiles for one launch_cov
-void launch_cov(const float *d_db, const float *d_mu, int n_clips, int c, const int *d_tiles, float *d_part,
-                float *d_accum, hipStream_t s);
+size_t cov_workspace_bytes(int n_clips, int c);
+void launch_cov(const float *d_db, int n_clips, int c, const int *d_tiles, float *d_ws, float *d_accum, hipStream_t s);
 // host: unit eigenvectors of the m largest eigenvalues of a symmetric n x n matrix (eigen_host.cpp)
 int top_eigenvectors(const float *cov, int n, int m, float *out, double *evals);
 
