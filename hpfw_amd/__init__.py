@@ -4,8 +4,9 @@ Only what the path needs: csrc/ (HIP kernels + the C-ABI of include/hpfw_gpu.h),
 binding, a twin of the reference's Python class (modules/python/pyhpfw/pyhpfw.py) and the
 synthetic-audio generator used by tests and bench.py.  No CPU fallback exists.
 """
-from ._lib import Gpu, HpfwError, HIT_DTYPE, KERNEL_KINDS, LIB_PATH, lib, merge_topk, plan_checksum  # noqa: F401
+from ._lib import (Gpu, HpfwError, HIT_DTYPE, VOTE_DTYPE, KERNEL_KINDS, LIB_PATH, lib, merge_topk,  # noqa: F401
+                   plan_checksum)
 from .collector import ParallelCollector  # noqa: F401
 
-__all__ = ["Gpu", "HpfwError", "HIT_DTYPE", "KERNEL_KINDS", "LIB_PATH", "lib", "merge_topk",
+__all__ = ["Gpu", "HpfwError", "HIT_DTYPE", "VOTE_DTYPE", "KERNEL_KINDS", "LIB_PATH", "lib", "merge_topk",
            "plan_checksum", "ParallelCollector"]

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhpfw_gpu.so")
 
 HIT_DTYPE = np.dtype([("dist", "<u4"), ("clip", "<u4"), ("offset", "<i4"), ("pad", "<u4")])
+VOTE_DTYPE = np.dtype([("clip", "<u4"), ("pad", "<u4"), ("offset", "<i8"), ("cnt", "<f4"), ("pad2", "<f4")])
 
 KERNEL_KINDS = ("fwd_rows", "fwd_cols", "cq_chirpz", "db", "project_mfma", "delta_pack",
                 "hamming_scan", "topk")
@@ -29,6 +30,7 @@ EXPORTS = (
     "hpfw_gpu_index_size", "hpfw_gpu_index_set_clip_base", "hpfw_gpu_search_topk_device",
     "hpfw_gpu_search_topk", "hpfw_gpu_merge_topk", "hpfw_gpu_timer_start", "hpfw_gpu_timer_stop",
     "hpfw_gpu_index_get", "hpfw_gpu_extract_db_host", "hpfw_gpu_stage_spectrogram",
+    "hpfw_gpu_search_votes", "hpfw_gpu_knn_windows",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_save", "par_collector_load",
@@ -100,6 +102,8 @@ def lib():
     L.hpfw_gpu_timer_start.argtypes = [vp, vp]
     L.hpfw_gpu_timer_stop.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.hpfw_gpu_stage_spectrogram.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_search_votes.argtypes = [vp, vp, vp, i64, vp]
+    L.hpfw_gpu_knn_windows.argtypes = [vp, vp, vp, i64, vp, i64]
     L.hpfw_gpu_index_get.argtypes = [vp, vp, vp, ctypes.c_int64]
     L.hpfw_gpu_extract_db_host.argtypes = [vp, vp, i32, i32, vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.hpfw_gpu_set_kernel_timing.argtypes = [vp, i32]
@@ -277,6 +281,23 @@ class Gpu:
         out = np.zeros((off.size - 1, k), HIT_DTYPE)
         check(lib().hpfw_gpu_search_topk(self._h, _hp(q), _hp(off), off.size - 1, int(k), _hp(out)))
         return out
+
+    def search_votes(self, q_hp, q_off):
+        """AnnStorage-style voting search with exact neighbours: VOTE_DTYPE [n_q]"""
+        q = np.ascontiguousarray(q_hp, np.uint64).ravel()
+        off = np.ascontiguousarray(q_off, np.int64)
+        out = np.zeros(off.size - 1, VOTE_DTYPE)
+        check(lib().hpfw_gpu_search_votes(self._h, _hp(q), _hp(off), off.size - 1, _hp(out)))
+        return out
+
+    def knn_windows(self, q_hp, q_off):
+        """the 5 nearest 64-hashprint windows of every query position: keys [n_windows][5]"""
+        q = np.ascontiguousarray(q_hp, np.uint64).ravel()
+        off = np.ascontiguousarray(q_off, np.int64)
+        n_win = int(np.maximum(np.diff(off) - 63, 0).sum())
+        keys = np.zeros((n_win, 5), np.uint64)
+        check(lib().hpfw_gpu_knn_windows(self._h, _hp(q), _hp(off), off.size - 1, _hp(keys), keys.size))
+        return keys
 
     def search_topk_dev(self, d_q, q_off, k, d_out, stream=0):
         off = np.ascontiguousarray(q_off, np.int64)

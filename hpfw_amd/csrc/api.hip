@@ -956,6 +956,127 @@ int hpfw_gpu_search_topk(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off
     return rc;
 }
 
+// ---- voting search (AnnStorage semantics, exact neighbours) ------------------------------------
+namespace {
+constexpr int kVoteWin = 64, kVoteNn = 5;
+
+// keys [n_win][5] of the windows of all queries, sorted per window; w_first[q] = first window of query q
+int knn_windows_impl(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, int64_t n_q, std::vector<uint64_t> &keys,
+                     std::vector<int64_t> &w_first)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    w_first.assign((size_t)n_q + 1, 0);
+    std::vector<int64_t> w_start;
+    for (int64_t q = 0; q < n_q; ++q) {
+        if (q_off[q + 1] < q_off[q]) return fail(HPFW_E_INVALID, "q_off must be non-decreasing");
+        const int64_t k = q_off[q + 1] - q_off[q];
+        for (int64_t i = 0; i + kVoteWin <= k; ++i) w_start.push_back(q_off[q] - q_off[0] + i);
+        w_first[(size_t)q + 1] = (int64_t)w_start.size();
+    }
+    const int64_t n_win = (int64_t)w_start.size();
+    keys.assign((size_t)n_win * kVoteNn, ~0ull);
+    const int64_t n_clips = (int64_t)h->db_off.size() - 1;
+    int64_t n_max = 0;
+    for (int64_t i = 0; i < n_clips; ++i) n_max = std::max(n_max, h->db_off[i + 1] - h->db_off[i]);
+    if (n_win == 0 || n_max < kVoteWin) return 0;
+    if (n_win > (int64_t)1 << 24) return fail(HPFW_E_UNSUPPORTED, "too many query windows in one call");
+    int rc;
+    if (h->db_off_dirty) {
+        if ((rc = ensure((void **)&h->d_db_off, &h->db_off_cap, h->db_off.size() * 8))) return rc;
+        HIP_TRY(hipMemcpy(h->d_db_off, h->db_off.data(), h->db_off.size() * 8, hipMemcpyHostToDevice));
+        h->db_off_dirty = false;
+    }
+    const int64_t total = q_off[n_q] - q_off[0];
+    const int kt_pad = hpfw::hamming_mfma_kt_pad(kVoteWin);
+    uint64_t *d_q = nullptr, *d_slots = nullptr;
+    int64_t *d_ws = nullptr;
+    void *d_qa = nullptr;
+    const size_t n_groups = (size_t)(n_win + 31) / 32;
+    if (hipMalloc((void **)&d_q, (size_t)total * 8) != hipSuccess || hipMalloc((void **)&d_ws, (size_t)n_win * 8) != hipSuccess ||
+        hipMalloc((void **)&d_slots, (size_t)n_win * 64) != hipSuccess || hipMalloc(&d_qa, n_groups * kt_pad * 1024) != hipSuccess)
+        rc = fail(HPFW_E_NOMEM, "hipMalloc failed");
+    else
+        rc = 0;
+    if (!rc && (hipMemcpy(d_q, q_hp + q_off[0], (size_t)total * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_ws, w_start.data(), (size_t)n_win * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemset(d_slots, 0xff, (size_t)n_win * 64) != hipSuccess))
+        rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (!rc) {
+        hpfw::launch_expand_windows(d_q, d_ws, (int)n_win, kVoteWin, kt_pad, d_qa, nullptr);
+        hpfw::launch_knn_windows(h->d_db, h->d_db_off, (int)n_clips, (int)(n_max - kVoteWin + 1), d_qa, kt_pad, (int)n_win,
+                                 kVoteWin, kVoteNn, d_slots, nullptr);
+        rc = check_launch("knn_windows");
+    }
+    std::vector<uint64_t> slots((size_t)n_win * 8);
+    if (!rc && hipMemcpy(slots.data(), d_slots, slots.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(HPFW_E_HIP, "kernel execution failed");
+    if (d_q) (void)hipFree(d_q);
+    if (d_ws) (void)hipFree(d_ws);
+    if (d_slots) (void)hipFree(d_slots);
+    if (d_qa) (void)hipFree(d_qa);
+    if (rc) return rc;
+    for (int64_t w = 0; w < n_win; ++w) { // the device keeps the 5 smallest keys unsorted
+        uint64_t *s5 = &slots[(size_t)w * 8];
+        std::sort(s5, s5 + kVoteNn);
+        for (int r = 0; r < kVoteNn; ++r) keys[(size_t)w * kVoteNn + r] = s5[r];
+    }
+    return 0;
+}
+} // namespace
+
+int hpfw_gpu_knn_windows(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, int64_t n_q, uint64_t *keys,
+                         int64_t keys_cap)
+{
+    if (!h || !q_hp || !q_off || !keys || n_q < 0) return fail(HPFW_E_INVALID, "bad argument");
+    std::vector<uint64_t> k;
+    std::vector<int64_t> wf;
+    int rc = knn_windows_impl(h, q_hp, q_off, n_q, k, wf);
+    if (rc) return rc;
+    if ((int64_t)k.size() > keys_cap) return fail(HPFW_E_INVALID, "keys buffer too small");
+    std::memcpy(keys, k.data(), k.size() * 8);
+    return 0;
+}
+
+int hpfw_gpu_search_votes(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, int64_t n_q, hpfw_vote *out)
+{
+    if (!h || !q_hp || !q_off || !out || n_q < 0) return fail(HPFW_E_INVALID, "bad argument");
+    std::vector<uint64_t> keys;
+    std::vector<int64_t> wf;
+    int rc = knn_windows_impl(h, q_hp, q_off, n_q, keys, wf);
+    if (rc) return rc;
+    struct Bucket {
+        int64_t clip, off;
+        float cnt;
+    };
+    std::vector<Bucket> buckets;
+    for (int64_t q = 0; q < n_q; ++q) {
+        hpfw_vote best = {0xffffffffu, 0, 0, 0.0f, 0.0f}; // annoy_storage.h:43
+        buckets.clear();
+        for (int64_t w = wf[(size_t)q]; w < wf[(size_t)q + 1]; ++w) {
+            const int64_t i = w - wf[(size_t)q];
+            for (int r = 0; r < kVoteNn; ++r) {
+                const uint64_t key = keys[(size_t)w * kVoteNn + r];
+                if (key == ~0ull) continue;
+                const uint64_t d = key >> 40;
+                const int64_t pos = (int64_t)(key & (((uint64_t)1 << 40) - 1));
+                const int64_t clip = (int64_t)(std::upper_bound(h->db_off.begin(), h->db_off.end(), pos) - h->db_off.begin()) - 1;
+                const int64_t off = i - (pos - h->db_off[(size_t)clip]);
+                size_t s = 0;
+                while (s < buckets.size() && !(buckets[s].clip == clip && buckets[s].off == off)) ++s;
+                if (s == buckets.size()) buckets.push_back({clip, off, 0.0f});
+                buckets[s].cnt = (float)((double)buckets[s].cnt + 1.0 / (double)(float)(d + 1)); // :53
+                if (buckets[s].cnt > best.cnt) {                                                  // :55-59
+                    best.clip = h->clip_base + (uint32_t)clip;
+                    best.offset = off;
+                    best.cnt = buckets[s].cnt;
+                }
+            }
+        }
+        out[q] = best;
+    }
+    return 0;
+}
+
 int hpfw_gpu_merge_topk(const hpfw_hit *in, int n_shards, int64_t n_q, int k, hpfw_hit *out)
 {
     if (!in || !out || n_shards < 1 || n_q < 0 || k < 1) return fail(HPFW_E_INVALID, "bad argument");

@@ -71,6 +71,22 @@ __global__ __launch_bounds__(256) void expand_queries_kernel(const uint64_t *__r
     qa[((int64_t)g * kt_pad + j) * 64 + lane] = v;
 }
 
+// the same image for windows of one or more queries: row w of group w / 32 is the `win` hashprints
+// starting at q[w_start[w]] (annoy_storage.h:23,32: 64 consecutive words per item)
+__global__ __launch_bounds__(256) void expand_windows_kernel(const uint64_t *__restrict__ q,
+                                                             const int64_t *__restrict__ w_start, int n_win, int win,
+                                                             int kt_pad, v4i *__restrict__ qa)
+{
+    const int g = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= kt_pad * 64) return;
+    const int j = idx >> 6, lane = idx & 63, m = lane & 31, h = lane >> 5;
+    const int w = g * 32 + m;
+    v4i v = {0, 0, 0, 0};
+    if (w < n_win && j < win) v = expand32((uint32_t)(q[w_start[w] + j] >> (32 * h)));
+    qa[((int64_t)g * kt_pad + j) * 64 + lane] = v;
+}
+
 struct SearchMfmaArgs {
     const uint64_t *db;
     const int64_t *db_off;
@@ -82,8 +98,13 @@ struct SearchMfmaArgs {
     const int *gk;        // [2 g]: longest query of group g; [2 g + 1]: its shortest non-empty one
     uint64_t *best;       // [n_q][n_clips], initialised to ~0
     int chunks;           // workgroups (of 1024 offsets) per clip
+    // nearest-window mode (KNN): rows are windows of `win` hashprints, every row has length win, and the
+    // nn smallest (distance, global position) keys of each row are kept in slots [n_q][8]
+    int win, nn;
+    unsigned long long *slots;
 };
 
+template <bool KNN>
 __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaArgs a)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,10 +112,10 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
     const int clip = blockIdx.x / a.chunks, g = blockIdx.y;
     const int64_t r0 = a.db_off[clip];
     const int n = (int)(a.db_off[clip + 1] - r0);
-    const int kt = a.gk[2 * g];
+    const int kt = KNN ? a.win : a.gk[2 * g];
     if (n <= 0 || kt <= 0) return;
     const int o0 = (blockIdx.x - clip * a.chunks) * kSmWgOffs;
-    const int kmin = min(a.gk[2 * g + 1], n);
+    const int kmin = KNN ? a.win : min(a.gk[2 * g + 1], n);
     if (o0 > n - kmin) return; // no query of the group has an offset in this chunk (off <= n - k)
 
     const int win = kSmWgOffs + kt;                      // window slots (one spare)
@@ -119,8 +140,13 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
     if (tid < 32) {
         const int qi = g * 32 + tid;
         int k = 0;
-        if (qi < a.n_q) k = (int)(a.q_off[qi + 1] - a.q_off[qi]);
-        kq_s[tid] = k < n ? k : n; // storage.h:37-39
+        if (KNN) {
+            k = qi < a.n_q ? a.win : 0; // a window is never shortened: clips below win hashprints hold no item
+        } else {
+            if (qi < a.n_q) k = (int)(a.q_off[qi + 1] - a.q_off[qi]);
+            k = k < n ? k : n; // storage.h:37-39
+        }
+        kq_s[tid] = k;
     }
     // first chunk of the A operand
     const v4i *qa = a.qa + (int64_t)g * a.kt_pad * 64;
@@ -163,36 +189,82 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
         __syncthreads();
     }
 
-    // acc[t][reg]: query row m = (reg & 3) + 8 (reg >> 2) + 4 h, offset o0 + wave 128 + t 32 + n_lane.
-    // key = dist << 12 | offset inside the workgroup's 1024 (dist <= 64 k < 2^20): smaller distance, then
-    // smaller offset -- the first strict minimum of storage.h:50.
+    if constexpr (KNN) {
+        // the nn nearest windows of each row among this wave's 128 offsets: nn rounds of "smallest
+        // (distance, offset) key across the half-wave", each winner offered to the row's global slots --
+        // a chain of atomicMin that keeps the nn smallest keys seen by anyone (unsorted; the host sorts)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        const int k = kq_s[m];
-        unsigned key = 0xffffffffu;
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int k = kq_s[m];
+            unsigned cand[kSmTiles];
 #pragma unroll
-        for (int t = 0; t < kSmTiles; ++t) {
-            const int lo = wave * kSmWaveOffs + t * 32 + n_lane;
-            const int dist = (64 * k - (int)acc[t][reg]) >> 1;
-            const unsigned cand = ((unsigned)dist << 12) | (unsigned)lo;
-            if (k > 0 && o0 + lo <= n - k && cand < key) key = cand;
+            for (int t = 0; t < kSmTiles; ++t) {
+                const int lo = wave * kSmWaveOffs + t * 32 + n_lane;
+                const int dist = (64 * k - (int)acc[t][reg]) >> 1;
+                cand[t] = (k > 0 && o0 + lo <= n - k) ? (((unsigned)dist << 12) | (unsigned)lo) : 0xffffffffu;
+            }
+            const int row = g * 32 + m;
+            for (int r = 0; r < a.nn; ++r) {
+                unsigned mine = cand[0];
+#pragma unroll
+                for (int t = 1; t < kSmTiles; ++t) mine = cand[t] < mine ? cand[t] : mine;
+                unsigned best = mine;
+#pragma unroll
+                for (int s2 = 16; s2 >= 1; s2 >>= 1) {
+                    const unsigned o = (unsigned)__shfl_xor((int)best, s2);
+                    best = o < best ? o : best;
+                }
+                if (best == 0xffffffffu) break; // uniform across the half-wave
+#pragma unroll
+                for (int t = 0; t < kSmTiles; ++t)
+                    if (cand[t] == best) cand[t] = 0xffffffffu; // keys are unique: exactly one lane and tile
+                if (n_lane == 0 && row < a.n_q) {
+                    unsigned long long *sl = a.slots + (int64_t)row * 8;
+                    unsigned long long cur = ((unsigned long long)(best >> 12) << 40) |
+                                             (unsigned long long)(r0 + o0 + (int)(best & 0xfff));
+                    if (cur < __atomic_load_n(sl + a.nn - 1, __ATOMIC_RELAXED)) {
+                        for (int s2 = 0; s2 < a.nn; ++s2) {
+                            const unsigned long long old = atomicMin(sl + s2, cur);
+                            cur = old > cur ? old : cur; // the larger of the two moves on
+                        }
+                    }
+                }
+            }
         }
+        return;
+    } else {
+        // acc[t][reg]: query row m = (reg & 3) + 8 (reg >> 2) + 4 h, offset o0 + wave 128 + t 32 + n_lane.
+        // key = dist << 12 | offset inside the workgroup's 1024 (dist <= 64 k < 2^20): smaller distance, then
+        // smaller offset -- the first strict minimum of storage.h:50.
 #pragma unroll
-        for (int s = 16; s >= 1; s >>= 1) { // minimum over the 32 offset columns of this half-wave
-            const unsigned o = (unsigned)__shfl_xor((int)key, s);
-            key = o < key ? o : key;
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const int k = kq_s[m];
+            unsigned key = 0xffffffffu;
+#pragma unroll
+            for (int t = 0; t < kSmTiles; ++t) {
+                const int lo = wave * kSmWaveOffs + t * 32 + n_lane;
+                const int dist = (64 * k - (int)acc[t][reg]) >> 1;
+                const unsigned cand = ((unsigned)dist << 12) | (unsigned)lo;
+                if (k > 0 && o0 + lo <= n - k && cand < key) key = cand;
+            }
+#pragma unroll
+            for (int s = 16; s >= 1; s >>= 1) { // minimum over the 32 offset columns of this half-wave
+                const unsigned o = (unsigned)__shfl_xor((int)key, s);
+                key = o < key ? o : key;
+            }
+            if (n_lane == 0) red[wave * 32 + m] = key;
         }
-        if (n_lane == 0) red[wave * 32 + m] = key;
-    }
-    __syncthreads();
-    if (tid < 32) {
-        unsigned key = red[tid];
-        for (int w = 1; w < kSmThreads / 64; ++w) key = red[w * 32 + tid] < key ? red[w * 32 + tid] : key;
-        const int qi = g * 32 + tid;
-        if (qi < a.n_q && key != 0xffffffffu) {
-            const unsigned long long full = ((unsigned long long)(key >> 12) << 32) | (unsigned)(o0 + (int)(key & 0xfff));
-            atomicMin(reinterpret_cast<unsigned long long *>(a.best) + (int64_t)qi * a.n_clips + clip, full);
+        __syncthreads();
+        if (tid < 32) {
+            unsigned key = red[tid];
+            for (int w = 1; w < kSmThreads / 64; ++w) key = red[w * 32 + tid] < key ? red[w * 32 + tid] : key;
+            const int qi = g * 32 + tid;
+            if (qi < a.n_q && key != 0xffffffffu) {
+                const unsigned long long full = ((unsigned long long)(key >> 12) << 32) | (unsigned)(o0 + (int)(key & 0xfff));
+                atomicMin(reinterpret_cast<unsigned long long *>(a.best) + (int64_t)qi * a.n_clips + clip, full);
+            }
         }
     }
 }
@@ -212,15 +284,50 @@ void launch_expand_queries(const uint64_t *d_q, const int64_t *d_q_off, int n_q,
                        reinterpret_cast<v4i *>(d_qa));
 }
 
-void launch_hamming_mfma(const SearchArgs &a, const void *d_qa, int kt_pad, const int *d_gk, int n_max, hipStream_t s)
+static void mfma_scan_attrs()
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_mfma_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_mfma_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_mfma_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    SearchMfmaArgs m;
+}
+
+void launch_expand_windows(const uint64_t *d_q, const int64_t *d_w_start, int n_win, int win, int kt_pad, void *d_qa,
+                           hipStream_t s)
+{
+    dim3 grid((kt_pad * 64 + 255) / 256, (n_win + 31) / 32);
+    hipLaunchKernelGGL(expand_windows_kernel, grid, dim3(256), 0, s, d_q, d_w_start, n_win, win, kt_pad,
+                       reinterpret_cast<v4i *>(d_qa));
+}
+
+// nearest windows: rows = n_win windows of `win` hashprints (image d_qa), slots [n_win][8] preset to ~0
+void launch_knn_windows(const uint64_t *d_db, const int64_t *d_db_off, int n_clips, int n_off_max, const void *d_qa,
+                        int kt_pad, int n_win, int win, int nn, void *d_slots, hipStream_t s)
+{
+    mfma_scan_attrs();
+    SearchMfmaArgs m = {};
+    m.db = d_db;
+    m.db_off = d_db_off;
+    m.n_clips = n_clips;
+    m.n_q = n_win;
+    m.qa = reinterpret_cast<const v4i *>(d_qa);
+    m.kt_pad = kt_pad;
+    m.win = win;
+    m.nn = nn;
+    m.slots = reinterpret_cast<unsigned long long *>(d_slots);
+    m.chunks = (n_off_max + kSmWgOffs - 1) / kSmWgOffs;
+    dim3 grid((unsigned)m.chunks * (unsigned)n_clips, (n_win + 31) / 32);
+    hipLaunchKernelGGL(hamming_mfma_kernel<true>, grid, dim3(kSmThreads), hamming_mfma_lds_bytes(win), s, m);
+}
+
+void launch_hamming_mfma(const SearchArgs &a, const void *d_qa, int kt_pad, const int *d_gk, int n_max, hipStream_t s)
+{
+    mfma_scan_attrs();
+    SearchMfmaArgs m = {};
     m.db = a.db;
     m.db_off = a.db_off;
     m.n_clips = a.n_clips;
@@ -233,7 +340,7 @@ void launch_hamming_mfma(const SearchArgs &a, const void *d_qa, int kt_pad, cons
     const int n_groups = (a.n_q + 31) / 32;
     m.chunks = (n_max + kSmWgOffs - 1) / kSmWgOffs;
     dim3 grid((unsigned)m.chunks * (unsigned)a.n_clips, n_groups);
-    hipLaunchKernelGGL(hamming_mfma_kernel, grid, dim3(kSmThreads), hamming_mfma_lds_bytes(a.k_max), s, m);
+    hipLaunchKernelGGL(hamming_mfma_kernel<false>, grid, dim3(kSmThreads), hamming_mfma_lds_bytes(a.k_max), s, m);
 }
 
 } // namespace hpfw

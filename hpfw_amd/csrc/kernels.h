@@ -106,6 +106,12 @@ void launch_hamming_scan(const SearchArgs &a, hipStream_t s);
 int hamming_mfma_kt_pad(int k_max);            // rows of the expanded-query image per group of 32
 size_t hamming_mfma_lds_bytes(int k_max);      // dynamic LDS of the scan; > 160 KB: use launch_hamming_scan
 void launch_expand_queries(const uint64_t *d_q, const int64_t *d_q_off, int n_q, int kt_pad, void *d_qa, hipStream_t s);
+// nearest windows (AnnStorage semantics with exact neighbours): rows = windows of `win` hashprints
+void launch_expand_windows(const uint64_t *d_q, const int64_t *d_w_start, int n_win, int win, int kt_pad, void *d_qa,
+                           hipStream_t s);
+void launch_knn_windows(const uint64_t *d_db, const int64_t *d_db_off, int n_clips, int n_off_max, const void *d_qa,
+                        int kt_pad, int n_win, int win, int nn, void *d_slots /* [n_win][8] u64, preset to ~0 */,
+                        hipStream_t s);
 // d_gk: per group of 32 queries {longest, shortest non-empty}; n_off_max: most offsets any (query, clip) has
 void launch_hamming_mfma(const SearchArgs &a, const void *d_qa, int kt_pad, const int *d_gk, int n_off_max, hipStream_t s);
 void launch_topk(const uint64_t *d_best, int n_q, int n_clips, int k, uint32_t clip_base, void *d_out,

@@ -75,6 +75,25 @@ public:
 
     size_t size() const { return names_.size(); }
 
+    /// AnnStorage<Collector>::find (reference annoy_storage.h:41-63) with exact nearest neighbours in
+    /// place of the Annoy forest: per query position the 5 nearest 64-hashprint windows vote
+    /// 1 / (distance + 1) for (track, offset); returns the reference's {filename, cnt, offset} of
+    /// the winning bucket ({"", 0, 0} when nothing votes).
+    struct VoteResult { // annoy_storage.h:16-20
+        std::string filename;
+        float cnt;
+        int64_t offset;
+    };
+    auto find_votes(const typename Collector::Hashprint &hp) const -> VoteResult
+    {
+        if (hp.empty() || names_.empty()) return {"", 0.0f, 0};
+        const int64_t q_off[2] = {0, (int64_t)hp.size()};
+        hpfw_vote v;
+        check(hpfw_gpu_search_votes(h_, hp.data(), q_off, 1, &v));
+        if (v.clip == 0xffffffffu) return {"", 0.0f, 0};
+        return {names_[v.clip], v.cnt, v.offset};
+    }
+
     /// storage.h:67-75: the cereal BinaryOutputArchive image of std::vector<FilenameFingerprintPair>
     /// (parallel_collector.h:26-35): u64 count, then per entry u64 length + bytes of the filename and
     /// u64 length + that many u64 hashprints.  A dump written by the reference loads here and vice versa.

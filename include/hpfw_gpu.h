@@ -164,6 +164,28 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
 /* host convenience: copies queries in and hits out, synchronises */
 int hpfw_gpu_search_topk(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, int64_t n_q,
                          int k, hpfw_hit *out);
+/* AnnStorage::find (annoy_storage.h:41-63) with the approximate Annoy forest replaced by exact nearest
+ * neighbours.  Items are windows of 64 consecutive hashprints (the reference indexes 64 uint64 words per
+ * item, annoy_storage.h:23,32; its items whose window runs past the end of a hashprint -- an
+ * out-of-bounds read -- are not created).  For every position i of a query, the 5 windows of the index
+ * nearest in Hamming distance over the 4096 bits, by (distance, position in the database), vote
+ * cnt[clip][i - p] += 1 / (d + 1) (float accumulator, :53); the first bucket to exceed the running
+ * maximum wins (:55-59).  Host arrays; out[n_q]; clip = 0xffffffff when the query has no window or the
+ * index no item. */
+typedef struct {
+    uint32_t clip;
+    uint32_t pad;
+    int64_t offset; /* i - p of the winning bucket */
+    float cnt;      /* its votes */
+    float pad2;
+} hpfw_vote;
+int hpfw_gpu_search_votes(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, int64_t n_q,
+                          hpfw_vote *out);
+/* the neighbours themselves (for tests): keys [n_windows][5], dist << 40 | global hashprint position,
+ * ascending, ~0 where fewer exist; windows of all queries in order, n_windows = sum max(k - 63, 0) */
+int hpfw_gpu_knn_windows(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, int64_t n_q,
+                         uint64_t *keys, int64_t keys_cap);
+
 /* deterministic merge of per-shard top-k lists (e.g. after an all-gather): in [n_shards][n_q][k]
  * -> out [n_q][k], ascending (dist, clip).  Host arrays. */
 int hpfw_gpu_merge_topk(const hpfw_hit *in, int n_shards, int64_t n_q, int k, hpfw_hit *out);

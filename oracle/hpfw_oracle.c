@@ -850,6 +850,74 @@ void hpfw_oracle_search_topk(const uint64_t *db, const int64_t *db_off, int64_t 
     for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
 }
 
+/* annoy_storage.h:41-63 with exact neighbours (see hpfw_oracle.h) */
+void hpfw_oracle_knn_windows(const uint64_t *db, const int64_t *db_off, int64_t n_clips, const uint64_t *q,
+                             int64_t k, int win, int nn, uint64_t *keys)
+{
+    const int64_t n_win = k - win + 1;
+    for (int64_t i = 0; i < n_win; ++i) {
+        uint64_t *best = keys + i * nn;
+        for (int r = 0; r < nn; ++r) best[r] = ~0ull;
+        for (int64_t c = 0; c < n_clips; ++c) {
+            const int64_t r0 = db_off[c], n = db_off[c + 1] - r0;
+            for (int64_t p = 0; p + win <= n; ++p) {
+                uint64_t d = 0;
+                for (int w = 0; w < win; ++w) d += (uint64_t)__builtin_popcountll(q[i + w] ^ db[r0 + p + w]);
+                uint64_t key = (d << 40) | (uint64_t)(r0 + p);
+                if (key >= best[nn - 1]) continue;
+                int r = nn - 1;
+                while (r > 0 && best[r - 1] > key) {
+                    best[r] = best[r - 1];
+                    --r;
+                }
+                best[r] = key;
+            }
+        }
+    }
+}
+
+void hpfw_oracle_vote_windows(const uint64_t *keys, int64_t n_win, int nn, const int64_t *db_off, int64_t n_clips,
+                              hpfw_oracle_vote *out)
+{
+    /* buckets (clip, offset) -> float count; at most n_win * nn of them */
+    const int64_t cap = n_win > 0 ? n_win * nn : 1;
+    int64_t *b_clip = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+    int64_t *b_off = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+    float *b_cnt = (float *)malloc((size_t)cap * sizeof(float));
+    int64_t nb = 0;
+    out->clip = -1;
+    out->offset = 0;
+    out->cnt = 0.0f;
+    out->pad = 0.0f;
+    for (int64_t i = 0; i < n_win; ++i)
+        for (int r = 0; r < nn; ++r) {
+            const uint64_t key = keys[i * nn + r];
+            if (key == ~0ull) continue;
+            const uint64_t d = key >> 40;
+            const int64_t pos = (int64_t)(key & ((1ull << 40) - 1));
+            int64_t c = 0;
+            while (c + 1 < n_clips && db_off[c + 1] <= pos) ++c; /* clip holding this position */
+            const int64_t off = i - (pos - db_off[c]);
+            int64_t s = 0;
+            while (s < nb && !(b_clip[s] == c && b_off[s] == off)) ++s;
+            if (s == nb) {
+                b_clip[s] = c;
+                b_off[s] = off;
+                b_cnt[s] = 0.0f;
+                ++nb;
+            }
+            b_cnt[s] = (float)((double)b_cnt[s] + 1.0 / (double)(float)(d + 1)); /* annoy_storage.h:53 */
+            if (b_cnt[s] > out->cnt) {
+                out->clip = c;
+                out->offset = off;
+                out->cnt = b_cnt[s];
+            }
+        }
+    free(b_clip);
+    free(b_off);
+    free(b_cnt);
+}
+
 /* FNV-1a checksums of the plan tables, so a test can compare them with the product's tables
  * without either side exposing the tables themselves. */
 static uint64_t fnv1a(const void *data, size_t bytes, uint64_t h)

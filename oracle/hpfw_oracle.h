@@ -89,6 +89,29 @@ typedef struct {
     uint32_t pad;
 } hpfw_oracle_hit;
 
+/* AnnStorage::find (annoy_storage.h:41-63) with the approximate Annoy forest replaced by the exact
+ * nearest neighbours.  Items are windows of `win` (64: the reference indexes 64 consecutive uint64
+ * words per item, AnnoyIndex<..., Hamming, ...>(64), annoy_storage.h:23,32) consecutive hashprints;
+ * item id = global hashprint position db_off[clip] + p, p = 0 .. n_clip - win (the reference's items
+ * whose window runs past the end of the hashprint -- an out-of-bounds read -- are not created).
+ * knn: for every query position i = 0 .. k - win the `nn` items of smallest Hamming distance over the
+ * win * 64 bits, ascending (distance, item id): keys[i][r] = dist << 40 | item id, ~0 when fewer exist. */
+void hpfw_oracle_knn_windows(const uint64_t *db, const int64_t *db_off, int64_t n_clips, const uint64_t *q,
+                             int64_t k, int win, int nn, uint64_t *keys);
+
+typedef struct {
+    int64_t clip;   /* -1: no match (annoy_storage.h:43 initial best_match) */
+    int64_t offset; /* i - p of the winning (clip, offset) bucket            */
+    float cnt;      /* its accumulated 1 / (d + 1) votes                     */
+    float pad;
+} hpfw_oracle_vote;
+
+/* the voting of annoy_storage.h:45-61 over those neighbours, in the reference's order (i ascending,
+ * then rank): cnt[clip][i - p] += 1.0 / (float)(d + 1) into a float; the first bucket to exceed the
+ * running maximum wins. */
+void hpfw_oracle_vote_windows(const uint64_t *keys, int64_t n_win, int nn, const int64_t *db_off, int64_t n_clips,
+                              hpfw_oracle_vote *out);
+
 /* top-k over the whole database, ascending (dist, clip id): storage.h:56-60 keeps the first
  * strict minimum in database order; the notebook keeps the 10 smallest (liveid.ipynb cell 9).
  * db: concatenated hashprints, db_off[n_clips+1].  Unused slots: dist = clip = 0xffffffff. */

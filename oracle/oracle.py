@@ -62,6 +62,8 @@ def lib():
         L.hpfw_oracle_match_clip.argtypes = [vp, i64, vp, i64, vp, vp]
         L.hpfw_oracle_search_topk.argtypes = [vp, vp, i64, vp, vp, i64, i32, vp, i32]
         L.hpfw_oracle_log10.restype = ctypes.c_double
+        L.hpfw_oracle_knn_windows.argtypes = [vp, vp, i64, vp, i64, i32, i32, vp]
+        L.hpfw_oracle_vote_windows.argtypes = [vp, i64, i32, vp, i64, vp]
         L.hpfw_oracle_log10.argtypes = [ctypes.c_double]
         L.hpfw_oracle_twiddle.argtypes = [i64, i64, vp, vp]
         L.hpfw_oracle_fft_dif.argtypes = [vp, i64, vp, i32]
@@ -179,6 +181,36 @@ def search_topk(db_hp, db_off, q_hp, q_off, topk, n_threads=1):
     lib().hpfw_oracle_search_topk(_p(db_hp), _p(db_off), db_off.size - 1, _p(q_hp), _p(q_off), n_q,
                                   int(topk), _p(out), int(n_threads))
     return out
+
+
+VOTE_DTYPE = np.dtype([("clip", "<i8"), ("offset", "<i8"), ("cnt", "<f4"), ("pad", "<f4")])
+
+
+def knn_windows(db_hp, db_off, q_hp, win=64, nn=5):
+    """exact nearest windows of every query position: keys [k - win + 1][nn] = dist << 40 | global position"""
+    db_hp = _c(db_hp, np.uint64)
+    db_off = _c(db_off, np.int64)
+    q_hp = _c(q_hp, np.uint64)
+    n_win = max(q_hp.size - win + 1, 0)
+    keys = np.full((n_win, nn), np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+    if n_win:
+        lib().hpfw_oracle_knn_windows(_p(db_hp), _p(db_off), db_off.size - 1, _p(q_hp), q_hp.size, int(win), int(nn),
+                                      _p(keys))
+    return keys
+
+
+def vote_windows(keys, db_off):
+    """annoy_storage.h:45-61 over exact neighbours: the winning (clip, offset, count)"""
+    keys = _c(keys, np.uint64)
+    db_off = _c(db_off, np.int64)
+    out = np.zeros(1, VOTE_DTYPE)
+    nn = keys.shape[1] if keys.ndim == 2 else 5
+    lib().hpfw_oracle_vote_windows(_p(keys), keys.shape[0], int(nn), _p(db_off), db_off.size - 1, _p(out))
+    return out[0]
+
+
+def search_votes(db_hp, db_off, q_hp, win=64, nn=5):
+    return vote_windows(knn_windows(db_hp, db_off, q_hp, win, nn), db_off)
 
 
 def log10(x):

@@ -231,6 +231,42 @@ def test_search_query_longer_than_lds_window(gpu, oracle):
     assert got[0, 0]["clip"] == 0 and got[0, 0]["offset"] == 300 and got[0, 0]["dist"] == 0
 
 
+def test_voting_search_matches_oracle(gpu, oracle):
+    """row f4: AnnStorage::find with exact neighbours -- the 5 nearest 64-hashprint windows of every query
+    position (keys identical to the oracle's brute force, ties by database position) and the vote"""
+    rng = np.random.default_rng(16)
+    db_lens = [400, 64, 63, 1500, 2320, 100, 1100]
+    db, db_off = _ragged(rng, db_lens)
+    db[db_off[5]:db_off[6]] = db[db_off[0] + 50: db_off[0] + 150]          # clip 5 repeats part of clip 0: ties
+    qs = []
+    for c, o, k, flips in [(3, 700, 200, 6), (4, 2000, 305, 12), (0, 50, 100, 0), (6, 10, 64, 3)]:
+        seg = db[db_off[c] + o: db_off[c] + o + k].copy()
+        for _ in range(flips):
+            seg ^= np.uint64(1) << rng.integers(0, 64, size=k, dtype=np.uint64)
+        qs.append(seg)
+    qs.append(rng.integers(0, 2 ** 64, size=90, dtype=np.uint64))            # matches nothing in particular
+    qs.append(rng.integers(0, 2 ** 64, size=40, dtype=np.uint64))            # shorter than a window: no vote
+    q_off = np.concatenate([[0], np.cumsum([x.size for x in qs])]).astype(np.int64)
+    q = np.concatenate(qs)
+    gpu.index_clear()
+    gpu.index_add(db, db_off)
+    keys = gpu.knn_windows(q, q_off)
+    want_keys = np.concatenate([oracle.knn_windows(db, db_off, x) for x in qs if x.size >= 64])
+    assert np.array_equal(keys, want_keys)
+    got = gpu.search_votes(q, q_off)
+    for i, x in enumerate(qs):
+        want = oracle.search_votes(db, db_off, x)
+        if want["clip"] < 0:
+            assert got[i]["clip"] == 0xFFFFFFFF and got[i]["cnt"] == 0
+        else:
+            assert (int(got[i]["clip"]), int(got[i]["offset"])) == (int(want["clip"]), int(want["offset"]))
+            assert got[i]["cnt"] == want["cnt"]
+    assert (int(got[0]["clip"]), int(got[0]["offset"])) == (3, -700)
+    assert (int(got[1]["clip"]), int(got[1]["offset"])) == (4, -2000)
+    assert int(got[2]["clip"]) == 0 and int(got[2]["offset"]) == -50        # clip 0 comes before its copy, clip 5
+    assert got[5]["clip"] == 0xFFFFFFFF
+
+
 def test_search_empty_and_small_index(gpu, oracle, scan_path):
     rng = np.random.default_rng(13)
     q = rng.integers(0, 2 ** 64, size=30, dtype=np.uint64)

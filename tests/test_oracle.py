@@ -172,3 +172,33 @@ def test_golden_search(oracle):
     assert (t[1, 2]["offset"], t[1, 2]["dist"]) == (10, 200)
     top1 = oracle.search_topk(g["db"], g["db_off"], g["q"], g["q_off"], 1)
     assert np.array_equal(top1[:, 0], t[:, 0])
+
+
+def test_voting_search_oracle_against_numpy(oracle):
+    """AnnStorage::find with exact neighbours (annoy_storage.h:41-63): the C restatement against a
+    direct numpy evaluation of the same definition"""
+    rng = np.random.default_rng(5)
+    lens = [150, 64, 30, 260]
+    db = rng.integers(0, 2 ** 64, size=sum(lens), dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    q = db[off[3] + 40: off[3] + 40 + 100].copy()
+    q[::3] ^= np.uint64(0x8001)
+    keys = oracle.knn_windows(db, off, q)
+    pop = np.array([bin(i).count("1") for i in range(256)], np.uint64)
+
+    def dist(a, b):
+        return int(pop[np.bitwise_xor(a, b).view(np.uint8)].sum())
+
+    items = [(c, p) for c in range(len(lens)) for p in range(lens[c] - 63)]
+    cnt, best = {}, (-1, 0, np.float32(0))
+    for i in range(q.size - 63):
+        cand = sorted((dist(q[i:i + 64], db[off[c] + p: off[c] + p + 64]), int(off[c] + p), c, p) for c, p in items)[:5]
+        assert [int(k) for k in keys[i]] == [(d << 40) | pos for d, pos, _, _ in cand]
+        for d, _, c, p in cand:
+            key = (c, i - p)
+            cnt[key] = np.float32(np.float64(cnt.get(key, np.float32(0))) + 1.0 / np.float64(np.float32(d + 1)))
+            if cnt[key] > best[2]:
+                best = (c, i - p, cnt[key])
+    got = oracle.vote_windows(keys, off)
+    assert (int(got["clip"]), int(got["offset"])) == best[:2] == (3, -40) and got["cnt"] == best[2]
+    assert oracle.search_votes(db, off, q[:63])["clip"] == -1      # no window fits
