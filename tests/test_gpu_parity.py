@@ -11,6 +11,7 @@ from conftest import bits_equal, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
+import hpfw_amd  # noqa: E402
 from hpfw_amd import synth  # noqa: E402
 
 
@@ -86,6 +87,31 @@ def test_stages_bit_exact(gpu, torch_cuda, oracle, filters, seconds):
     hp_all = gpu.extract(clips)
     assert np.array_equal(hp_all, hp_ref)
     assert np.array_equal(hp_all, np.stack([plan.extract(filters, c) for c in clips]))
+
+
+@pytest.mark.parametrize("seconds", [2.0, 4.2, 7.0, 10.0, 12.5, 20.0, 45.0, 49.0])
+def test_extract_other_lengths(gpu, oracle, filters, seconds):
+    """other clip lengths (different n1, chirp-z classes from 64 to 16384 points, the run-time group
+    sequence when n2 is not 6300): hashprints and the dB spectrogram stay bit-exact"""
+    torch = pytest.importorskip("torch")
+    clips = np.stack([synth.gen_clip(900 + i, seconds) for i in range(2)])
+    n = clips.shape[1]
+    plan = oracle.Plan(n)
+    assert np.array_equal(gpu.extract(clips), np.stack([plan.extract(filters, c) for c in clips]))
+    d_pcm = _dev(torch, clips)
+    d_db = torch.empty((2, 121, plan.c), dtype=torch.float32, device="cuda")
+    gpu.stage_spectrogram_dev(d_pcm.data_ptr(), n, 2, d_db.data_ptr())
+    torch.cuda.synchronize()
+    want = np.stack([oracle.db(plan.cqmag(plan.spectrum(c))) for c in clips])
+    assert bits_equal(d_db.cpu().numpy(), want)
+
+
+def test_clip_too_short_is_an_error(gpu, filters):
+    """below 100 spectrogram columns there is no hashprint (the reference would resize a matrix to a
+    negative width, hashprint_handle.h:118); the library says so"""
+    with pytest.raises(hpfw_amd.HpfwError) as e:
+        gpu.extract(np.zeros((1, 44100), np.int16))
+    assert "too short" in str(e.value)
 
 
 def test_extract_batches_and_order(gpu, oracle, filters):
