@@ -1,6 +1,7 @@
-// fft_lds.h -- power-of-two FFTs held in LDS for the chirp-z (Bluestein) bands.
+// fft_lds.h -- FFTs of length 2^a or 3 * 2^a held in LDS for the chirp-z (Bluestein) bands.
 //
-// The arithmetic is the specification's sequence of radix-4 (and one radix-2) passes; here two
+// The arithmetic is the specification's sequence of radix-4 passes, then one radix-3 and / or one
+// radix-2 pass (the descending radix list [4.., 3, 2] of the length); here two
 // consecutive passes are fused in registers (16 points per thread, one LDS round trip instead of
 // two), the twiddles of a fused group come from a per-butterfly table in global memory (built by
 // the host from T_N, entry e of butterfly b at [e][b]: coalesced, L2 resident, no index
@@ -13,11 +14,18 @@ namespace hpfw {
 
 HPFW_DEVICE int pad16(int i) { return i + (i >> 4); }
 
-template <int LOGN>
-struct Pow2 {
-    static constexpr int N = 1 << LOGN;
+template <int N_>
+struct Size {
+    static constexpr int N = N_;
     static constexpr int DATA = N + N / 16; // padded data slots (complex)
 };
+
+constexpr bool cq_size_ok(int n) // 2^a or 3 * 2^a, 64 <= n <= 16384
+{
+    if (n < 64 || n > 16384) return false;
+    if (n % 3 == 0) n /= 3;
+    return (n & (n - 1)) == 0;
+}
 
 constexpr int kCqMaxGroups = 4;
 
@@ -33,11 +41,10 @@ struct CqTwiddles {
 // PRUNE: only inputs with index < nz inside the first quarter can be non-zero (nz <= LEN / R1 and
 // LEN == N): a radix-R1 butterfly whose inputs 1..R1-1 are zero returns its input 0 on every
 // output, so those loads and adds are skipped and the zero padding is never read.
-template <int LOGN, int LOGLEN, int R1, int R2, bool PRUNE, class Lds>
+template <int N, int LEN, int R1, int R2, bool PRUNE, class Lds>
 HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nthreads, int nz)
 {
-    using P = Pow2<LOGN>;
-    constexpr int LEN = 1 << LOGLEN;
+    using P = Size<N>;
     constexpr int M1 = LEN / R1, M2 = M1 / R2;
     constexpr int NB = P::N / (R1 * R2);
     for (int b = tid; b < NB; b += nthreads) {
@@ -95,11 +102,10 @@ HPFW_DEVICE void idft(cf *u)
 // ---- one fused group of the inverse DIT: radix R2 (or 1) at sub-length LEN / R1, then R1 ----
 // Same table as the forward group (the kernel conjugates).  Outputs with index >= keep are not
 // stored (only the first C samples of the last group are used).
-template <int LOGN, int LOGLEN, int R1, int R2, class Lds>
+template <int N, int LEN, int R1, int R2, class Lds>
 HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nthreads, int keep)
 {
-    using P = Pow2<LOGN>;
-    constexpr int LEN = 1 << LOGLEN;
+    using P = Size<N>;
     constexpr int M1 = LEN / R1, M2 = M1 / R2;
     constexpr int NB = P::N / (R1 * R2);
     for (int b = tid; b < NB; b += nthreads) {
@@ -139,11 +145,10 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
 // last DIF group (R1, R2 at LEN), pointwise product with V (digit-reversed positions = the LDS
 // positions), first inverse DIT group (R2, then R1) -- the same LEN points in both directions.
 // mt: the group's stage-1 entries (q2 (R1-1) + (s-1)), the same for every butterfly.
-template <int LOGN, int LOGLEN, int R1, int R2, class Lds>
+template <int N, int LEN, int R1, int R2, class Lds>
 HPFW_DEVICE void mid_group(Lds &lds, const cf *__restrict__ mt, int tid, int nthreads, const cf *__restrict__ vrev)
 {
-    using P = Pow2<LOGN>;
-    constexpr int LEN = 1 << LOGLEN;
+    using P = Size<N>;
     static_assert(LEN == R1 * R2, "the innermost group spans whole sub-transforms");
     constexpr int M1 = LEN / R1, M2 = 1;
     constexpr int NB = P::N / LEN;
@@ -193,57 +198,61 @@ HPFW_DEVICE void mid_group(Lds &lds, const cf *__restrict__ mt, int tid, int nth
     }
 }
 
-// ---- drivers: groups of the pass list [4 x (LOGN/2), 2 x (LOGN%2)] ----
-// LOGLEN = log2 of the sub-transform length still to be done.  The innermost group is handled by
-// mid_group; the outer ones by dif_group on the way in and idit_group on the way out.
-// (plan.cpp walks the same list to lay out the twiddle tables.)
-template <int LOGLEN>
-struct GroupOf { // radices of the next fused group when 2^LOGLEN remains
-    static constexpr int R1 = (LOGLEN >= 2) ? 4 : 2;
-    static constexpr int R2 = (LOGLEN >= 4) ? 4 : (LOGLEN == 3 ? 2 : 1);
-    static constexpr int BITS = (R1 == 4 ? 2 : 1) + (R2 == 4 ? 2 : (R2 == 2 ? 1 : 0));
+// ---- drivers: fused groups of the pass list [4 .., 3, 2] ----
+// LEN = the sub-transform length still to be done: 2^a or 3 * 2^a.  The next pass is radix 4 while
+// 4 divides LEN, then 3, then 2; a group fuses it with the pass after it (16, 12, 8 or 6 points per
+// thread) when there is one.  The innermost group is handled by mid_group; the outer ones by
+// dif_group on the way in and idit_group on the way out.  (plan.cpp walks the same list to lay out
+// the twiddle tables.)
+constexpr int cq_next_radix(int len) { return len % 4 == 0 ? 4 : (len % 3 == 0 ? 3 : 2); }
+
+template <int LEN>
+struct GroupOf {
+    static constexpr int R1 = cq_next_radix(LEN);
+    static constexpr int R2 = LEN / R1 > 1 ? cq_next_radix(LEN / R1) : 1;
+    static constexpr int REST = LEN / (R1 * R2);
 };
 
-template <int LOGN, int LOGLEN, int G, class Lds>
+template <int N, int LEN, int G, class Lds>
 HPFW_DEVICE void cq_transform(Lds &lds, const CqTwiddles &tw, int nthreads, int nz, int keep,
                               const cf *__restrict__ vrev)
 {
-    using GO = GroupOf<LOGLEN>;
-    constexpr int REST = LOGLEN - GO::BITS;
+    using GO = GroupOf<LEN>;
     constexpr bool FIRST = (G == 0);
-    if constexpr (REST == 0) {
+    if constexpr (GO::REST == 1) {
         const cf *mt = tw.tab + tw.mid_off;
-        HPFW_FOR_THREADS(t, nthreads) { mid_group<LOGN, LOGLEN, GO::R1, GO::R2>(lds, mt, t, nthreads, vrev); }
+        HPFW_FOR_THREADS(t, nthreads) { mid_group<N, LEN, GO::R1, GO::R2>(lds, mt, t, nthreads, vrev); }
         HPFW_BARRIER();
     } else {
         static_assert(G < kCqMaxGroups, "too many fused groups");
         const cf *gt = tw.tab + tw.off[G];
-        if (FIRST && nz <= (1 << LOGLEN) / GO::R1) {
-            HPFW_FOR_THREADS(t, nthreads) { dif_group<LOGN, LOGLEN, GO::R1, GO::R2, true>(lds, gt, t, nthreads, nz); }
+        if (FIRST && nz <= LEN / GO::R1) {
+            HPFW_FOR_THREADS(t, nthreads) { dif_group<N, LEN, GO::R1, GO::R2, true>(lds, gt, t, nthreads, nz); }
         } else {
-            HPFW_FOR_THREADS(t, nthreads) { dif_group<LOGN, LOGLEN, GO::R1, GO::R2, false>(lds, gt, t, nthreads, nz); }
+            HPFW_FOR_THREADS(t, nthreads) { dif_group<N, LEN, GO::R1, GO::R2, false>(lds, gt, t, nthreads, nz); }
         }
         HPFW_BARRIER();
-        cq_transform<LOGN, REST, G + 1>(lds, tw, nthreads, nz, keep, vrev);
+        cq_transform<N, GO::REST, G + 1>(lds, tw, nthreads, nz, keep, vrev);
         HPFW_FOR_THREADS(t, nthreads)
         {
-            idit_group<LOGN, LOGLEN, GO::R1, GO::R2>(lds, gt, t, nthreads, FIRST ? keep : (1 << LOGN));
+            idit_group<N, LEN, GO::R1, GO::R2>(lds, gt, t, nthreads, FIRST ? keep : N);
         }
         HPFW_BARRIER();
     }
 }
 
 // ---- the whole band: window*chirp, forward FFT, times V, inverse FFT, magnitudes ----
-// lds: Pow2<LOGP>::DATA complex slots; red: one float per thread (the largest value it stored).
+// lds: Size<NP>::DATA complex slots; red: one float per thread (the largest value it stored).
 // fin(m): what is stored for magnitude m -- m itself, or its dB term (monotone in m, so the
 // largest stored value belongs to the largest magnitude either way).
-template <int LOGP, class Lds, class Red, class Fin>
+template <int NP, class Lds, class Red, class Fin>
 HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const cf *__restrict__ xs, const cf *__restrict__ g,
                               int lg, const CqTwiddles &tw, const cf *__restrict__ vrev, int c,
                               float *__restrict__ out_mag, Fin fin)
 {
-    using P = Pow2<LOGP>;
-    const bool prune = lg <= P::N / 4;
+    using P = Size<NP>;
+    static_assert(cq_size_ok(NP), "chirp-z lengths are 2^a or 3 * 2^a");
+    const bool prune = lg <= P::N / 4; // the first pass is radix 4 for every admitted length
     HPFW_FOR_THREADS(tid, nthreads)
     {
         for (int i = tid; i < lg; i += nthreads) lds[pad16(i)] = c_mul(xs[i], g[i]);
@@ -251,7 +260,7 @@ HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const cf *__rest
             for (int i = lg + tid; i < P::N; i += nthreads) lds[pad16(i)] = {0.0f, 0.0f};
     }
     HPFW_BARRIER();
-    cq_transform<LOGP, LOGP, 0>(lds, tw, nthreads, lg, c, vrev);
+    cq_transform<NP, NP, 0>(lds, tw, nthreads, lg, c, vrev);
     HPFW_FOR_THREADS(tid, nthreads)
     {
         float mx = fin(0.0f);

@@ -19,9 +19,9 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-constexpr int cq_threads(int logp)
+constexpr int cq_threads(int n)
 {
-    const int t = (1 << logp) / 16; // one fused 16-point butterfly per thread and pass
+    const int t = n % 3 == 0 ? n / 12 : n / 16; // one fused 16-point (12-point) butterfly per thread and pass
     return t < 64 ? 64 : (t > 1024 ? 1024 : t);
 }
 
@@ -66,19 +66,19 @@ __device__ __forceinline__ float db_term(float pw)
 // DBT: store the dB term t(m^2) = (float)(10 log10(max(m^2, 1e-10))) of each magnitude instead of the
 // magnitude (extraction: the dB conversion then is S = max(t - t_max, -80) wherever S is read, and
 // no separate pass over the spectrogram is needed; the chirp-z has VALU slots to spare for it).
-template <int LOGP, bool DBT>
-__global__ __launch_bounds__(cq_threads(LOGP)) void cq_kernel(CqPlanDev cp, CqClassDev cc,
+template <int NP, bool DBT>
+__global__ __launch_bounds__(cq_threads(NP)) void cq_kernel(CqPlanDev cp, CqClassDev cc,
                                                               const cf *__restrict__ x, float *__restrict__ mag,
                                                               float *__restrict__ wavemax)
 {
-    using P = Pow2<LOGP>;
+    using P = Size<NP>;
     cf *lds = reinterpret_cast<cf *>(smem_raw);
     float *red = reinterpret_cast<float *>(lds + P::DATA); // one float per thread behind the data
     const int j = cc.band[blockIdx.x];
     const int clip = blockIdx.y;
     const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[j] - cp.kmin);
     float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
-    cq_band_body<LOGP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
+    cq_band_body<NP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
                        [](float m) { return DBT ? db_term(m * m) : m; });
     // wave maximum -> wavemax[clip][band][wave]: plain stores (clipmax_kernel reduces them); one
     // atomicMax per wave on a per-clip word cost 0.4 ms per 1000 clips in contention
@@ -149,39 +149,47 @@ __global__ __launch_bounds__(256) void db_finish_kernel(float *t, const float *_
     }
 }
 
-template <int LOGP>
+template <int NP>
 static void launch_cq_t(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
                         float *d_wavemax, bool db_term_out, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<LOGP, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<NP, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<LOGP, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<NP, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid(cc.n_bands, n_clips);
-    const size_t lds = (size_t)Pow2<LOGP>::DATA * sizeof(cf) + cq_threads(LOGP) * sizeof(float);
+    const size_t lds = (size_t)Size<NP>::DATA * sizeof(cf) + cq_threads(NP) * sizeof(float);
     if (db_term_out)
-        hipLaunchKernelGGL((cq_kernel<LOGP, true>), grid, dim3(cq_threads(LOGP)), lds, s, cp, cc, d_x, d_mag, d_wavemax);
+        hipLaunchKernelGGL((cq_kernel<NP, true>), grid, dim3(cq_threads(NP)), lds, s, cp, cc, d_x, d_mag, d_wavemax);
     else
-        hipLaunchKernelGGL((cq_kernel<LOGP, false>), grid, dim3(cq_threads(LOGP)), lds, s, cp, cc, d_x, d_mag, d_wavemax);
+        hipLaunchKernelGGL((cq_kernel<NP, false>), grid, dim3(cq_threads(NP)), lds, s, cp, cc, d_x, d_mag, d_wavemax);
 }
 
 void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
                      float *d_wavemax, bool db_term_out, hipStream_t s)
 {
     switch (cc.p) {
-    case 64: launch_cq_t<6>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
-    case 128: launch_cq_t<7>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
-    case 256: launch_cq_t<8>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
-    case 512: launch_cq_t<9>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
-    case 1024: launch_cq_t<10>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
-    case 2048: launch_cq_t<11>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
-    case 4096: launch_cq_t<12>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
-    case 8192: launch_cq_t<13>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
-    default: launch_cq_t<14>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break; // 16384: the plan admits nothing larger
+    case 64: launch_cq_t<64>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 96: launch_cq_t<96>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 128: launch_cq_t<128>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 192: launch_cq_t<192>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 256: launch_cq_t<256>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 384: launch_cq_t<384>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 512: launch_cq_t<512>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 768: launch_cq_t<768>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 1024: launch_cq_t<1024>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 1536: launch_cq_t<1536>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 2048: launch_cq_t<2048>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 3072: launch_cq_t<3072>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 4096: launch_cq_t<4096>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 6144: launch_cq_t<6144>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 8192: launch_cq_t<8192>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    case 12288: launch_cq_t<12288>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break;
+    default: launch_cq_t<16384>(cp, cc, d_x, n_clips, d_mag, d_wavemax, db_term_out, s); break; // the plan admits nothing larger
     }
 }
 

@@ -81,6 +81,47 @@ void fft_r2_double(std::vector<double> &re, std::vector<double> &im)
         }
     }
 }
+
+// DFT of length 2^a or 3 * 2^a in double (S5): for 3 m points, X[k] = (F0[k mod m] + W^k F1[k mod m]) +
+// W^2k F2[k mod m] with F_r the radix-2 transform of x[3 t + r] and W = e^{-2 pi i / (3 m)}
+void dft_double(std::vector<double> &re, std::vector<double> &im)
+{
+    const int64_t n = (int64_t)re.size();
+    if (n % 3 != 0) {
+        fft_r2_double(re, im);
+        return;
+    }
+    const int64_t m = n / 3;
+    std::vector<double> fr[3], fi[3];
+    for (int r = 0; r < 3; ++r) {
+        fr[r].resize((size_t)m);
+        fi[r].resize((size_t)m);
+        for (int64_t t = 0; t < m; ++t) {
+            fr[r][(size_t)t] = re[(size_t)(3 * t + r)];
+            fi[r][(size_t)t] = im[(size_t)(3 * t + r)];
+        }
+        fft_r2_double(fr[r], fi[r]);
+    }
+    for (int64_t k = 0; k < n; ++k) {
+        const size_t km = (size_t)(k % m);
+        double w1r, w1i, w2r, w2i;
+        twiddle_d(k, n, w1r, w1i);
+        twiddle_d((2 * k) % n, n, w2r, w2i);
+        const double ar = fr[0][km] + (w1r * fr[1][km] - w1i * fi[1][km]);
+        const double ai = fi[0][km] + (w1r * fi[1][km] + w1i * fr[1][km]);
+        re[(size_t)k] = ar + (w2r * fr[2][km] - w2i * fi[2][km]);
+        im[(size_t)k] = ai + (w2r * fi[2][km] + w2i * fr[2][km]);
+    }
+}
+
+// chirp-z length of a band (S7): the smallest of {2^a, 3 * 2^a}, at least 64, that holds `need` points
+int64_t chirpz_length(int64_t need)
+{
+    int64_t p2 = 64, p3 = 96;
+    while (p2 < need) p2 <<= 1;
+    while (p3 < need) p3 <<= 1;
+    return p3 < p2 ? p3 : p2;
+}
 } // namespace
 
 // Twiddles of one fused (r1, r2) DIF group at sub-length len of a length-n transform, laid out
@@ -295,8 +336,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
     int64_t goff = 0;
     for (int j = 0; j < kBins; ++j) {
         const int64_t need = p.lg[j] + p.c - 1;
-        int64_t ps = 64;
-        while (ps < need) ps <<= 1;
+        const int64_t ps = chirpz_length(need);
         if (ps > 16384) {
             why = "clip too long: chirp-z length exceeds the LDS";
             return false;
@@ -311,18 +351,16 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
             make_radix_list(ps, bc.radix);
             bc.tw = twiddle_table(ps);
             // per-butterfly twiddle tables of the fused groups, in the order the kernel walks them
-            // (fft_lds.h GroupOf): pairs of radix-4 passes, then (4,2) / (4) / (2); the innermost
-            // group's entries do not depend on the butterfly and are stored once
+            // (fft_lds.h GroupOf): pairs of passes of the list [4.., 3, 2]; the innermost group's
+            // entries do not depend on the butterfly and are stored once
             {
-                int loglen = 0;
-                while ((1 << loglen) < ps) ++loglen;
+                auto next_radix = [](int64_t len) { return len % 4 == 0 ? 4 : (len % 3 == 0 ? 3 : 2); };
+                int64_t len = ps;
                 int g = 0;
                 for (;;) {
-                    const int r1 = loglen >= 2 ? 4 : 2;
-                    const int r2 = loglen >= 4 ? 4 : (loglen == 3 ? 2 : 1);
-                    const int bits = (r1 == 4 ? 2 : 1) + (r2 == 4 ? 2 : (r2 == 2 ? 1 : 0));
-                    const int64_t len = (int64_t)1 << loglen;
-                    if (loglen - bits == 0) {
+                    const int r1 = next_radix(len);
+                    const int r2 = len / r1 > 1 ? next_radix(len / r1) : 1;
+                    if (len / (r1 * r2) == 1) {
                         std::vector<HostCf> tmp;
                         append_group_twiddles(bc.tw, ps, len, r1, r2, tmp);
                         const int64_t nb = ps / (r1 * r2);
@@ -336,7 +374,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
                     }
                     bc.goff[g++] = (int)bc.gtw.size();
                     append_group_twiddles(bc.tw, ps, len, r1, r2, bc.gtw);
-                    loglen -= bits;
+                    len /= r1 * r2;
                 }
             }
             std::vector<double> re((size_t)ps, 0.0), im((size_t)ps, 0.0);
@@ -347,7 +385,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
                 re[(size_t)idx] = cc;
                 im[(size_t)idx] = -ss;
             }
-            fft_r2_double(re, im);
+            dft_double(re, im);
             bc.vrev.resize((size_t)ps);
             for (int64_t kk = 0; kk < ps; ++kk) {
                 const int64_t pos = digit_pos(kk, ps, bc.radix);

@@ -391,6 +391,46 @@ static void fft_r2_double(double *re, double *im, int64_t n)
     }
 }
 
+/* S5 for lengths 3 m: X[k] = (F0[k mod m] + W^k F1[k mod m]) + W^2k F2[k mod m], F_r the radix-2
+ * transform of x[3 t + r], W = e^{-2 pi i / (3 m)} from twiddle_d */
+static void dft_double(double *re, double *im, int64_t n)
+{
+    if (n % 3 != 0) {
+        fft_r2_double(re, im, n);
+        return;
+    }
+    int64_t m = n / 3;
+    double *fr = (double *)malloc(sizeof(double) * (size_t)n), *fi = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int r = 0; r < 3; ++r) {
+        for (int64_t t = 0; t < m; ++t) {
+            fr[r * m + t] = re[3 * t + r];
+            fi[r * m + t] = im[3 * t + r];
+        }
+        fft_r2_double(fr + r * m, fi + r * m, m);
+    }
+    for (int64_t k = 0; k < n; ++k) {
+        int64_t km = k % m;
+        double w1r, w1i, w2r, w2i;
+        twiddle_d(k, n, &w1r, &w1i);
+        twiddle_d((2 * k) % n, n, &w2r, &w2i);
+        double ar = fr[km] + (w1r * fr[m + km] - w1i * fi[m + km]);
+        double ai = fi[km] + (w1r * fi[m + km] + w1i * fr[m + km]);
+        re[k] = ar + (w2r * fr[2 * m + km] - w2i * fi[2 * m + km]);
+        im[k] = ai + (w2r * fi[2 * m + km] + w2i * fr[2 * m + km]);
+    }
+    free(fr);
+    free(fi);
+}
+
+/* S7: chirp-z length of a band: the smallest of {2^a, 3 * 2^a}, at least 64, that holds `need` points */
+static int64_t chirpz_length(int64_t need)
+{
+    int64_t p2 = 64, p3 = 96;
+    while (p2 < need) p2 <<= 1;
+    while (p3 < need) p3 <<= 1;
+    return p3 < p2 ? p3 : p2;
+}
+
 static void chirp_d(int64_t m, int64_t big_m, double *c, double *s)
 {
     /* e^{+i pi 3 m^2 / M}; the phase is reduced exactly in integers first */
@@ -406,8 +446,7 @@ static int make_bluestein(hpfw_oracle_plan *p)
     int64_t big_m = p->info.m, c = p->info.c;
     p->n_cls = 0;
     for (int j = 0; j < HPFW_O_BINS; ++j) {
-        int64_t need = p->lg[j] + c - 1, ps = 64;
-        while (ps < need) ps <<= 1;
+        int64_t need = p->lg[j] + c - 1, ps = chirpz_length(need);
         p->psize[j] = (int32_t)ps;
         int k;
         for (k = 0; k < p->n_cls; ++k)
@@ -428,7 +467,7 @@ static int make_bluestein(hpfw_oracle_plan *p)
                 re[idx] = cc;
                 im[idx] = -ss;
             }
-            fft_r2_double(re, im, ps);
+            dft_double(re, im, ps);
             b->vrev = (cf *)malloc(sizeof(cf) * (size_t)ps);
             for (int64_t kk = 0; kk < ps; ++kk) {
                 int64_t pos = hpfw_oracle_digit_pos(kk, ps, b->radix, b->nr);

@@ -29,11 +29,11 @@ struct Checked {
     }
 };
 
-template <int LOGP>
+template <int NP>
 static void run_band(const hpfw::HostPlan &hp, const hpfw::BluesteinClass &bc, int j, const cf *x, float *mag)
 {
-    using P = hpfw::Pow2<LOGP>;
-    int nt = P::N / 16;
+    using P = hpfw::Size<NP>;
+    int nt = NP % 3 == 0 ? NP / 12 : NP / 16;
     if (nt < 64) nt = 64;
     if (nt > 1024) nt = 1024;
     std::vector<cf> lds_mem(P::DATA);
@@ -48,7 +48,7 @@ static void run_band(const hpfw::HostPlan &hp, const hpfw::BluesteinClass &bc, i
     tw.tab = reinterpret_cast<const cf *>(bc.gtw.data());
     for (int k = 0; k < 4; ++k) tw.off[k] = bc.goff[k];
     tw.mid_off = bc.mid_off;
-    hpfw::cq_band_body<LOGP>(lds, red, nt, xs, g, hp.lg[j], tw, reinterpret_cast<const cf *>(bc.vrev.data()), hp.c,
+    hpfw::cq_band_body<NP>(lds, red, nt, xs, g, hp.lg[j], tw, reinterpret_cast<const cf *>(bc.vrev.data()), hp.c,
                              mag + (size_t)j * hp.c, [](float m) { return m; });
 }
 
@@ -79,15 +79,23 @@ int main(int argc, char **argv)
     for (const hpfw::BluesteinClass &bc : hp.classes) {
         for (int j : bc.bands) {
             switch (bc.p) {
-            case 64: run_band<6>(hp, bc, j, xc, got.data()); break;
-            case 128: run_band<7>(hp, bc, j, xc, got.data()); break;
-            case 256: run_band<8>(hp, bc, j, xc, got.data()); break;
-            case 512: run_band<9>(hp, bc, j, xc, got.data()); break;
-            case 1024: run_band<10>(hp, bc, j, xc, got.data()); break;
-            case 2048: run_band<11>(hp, bc, j, xc, got.data()); break;
-            case 4096: run_band<12>(hp, bc, j, xc, got.data()); break;
-            case 8192: run_band<13>(hp, bc, j, xc, got.data()); break;
-            case 16384: run_band<14>(hp, bc, j, xc, got.data()); break;
+            case 64: run_band<64>(hp, bc, j, xc, got.data()); break;
+            case 96: run_band<96>(hp, bc, j, xc, got.data()); break;
+            case 128: run_band<128>(hp, bc, j, xc, got.data()); break;
+            case 192: run_band<192>(hp, bc, j, xc, got.data()); break;
+            case 256: run_band<256>(hp, bc, j, xc, got.data()); break;
+            case 384: run_band<384>(hp, bc, j, xc, got.data()); break;
+            case 512: run_band<512>(hp, bc, j, xc, got.data()); break;
+            case 768: run_band<768>(hp, bc, j, xc, got.data()); break;
+            case 1024: run_band<1024>(hp, bc, j, xc, got.data()); break;
+            case 1536: run_band<1536>(hp, bc, j, xc, got.data()); break;
+            case 2048: run_band<2048>(hp, bc, j, xc, got.data()); break;
+            case 3072: run_band<3072>(hp, bc, j, xc, got.data()); break;
+            case 4096: run_band<4096>(hp, bc, j, xc, got.data()); break;
+            case 6144: run_band<6144>(hp, bc, j, xc, got.data()); break;
+            case 8192: run_band<8192>(hp, bc, j, xc, got.data()); break;
+            case 12288: run_band<12288>(hp, bc, j, xc, got.data()); break;
+            case 16384: run_band<16384>(hp, bc, j, xc, got.data()); break;
             default: std::fprintf(stderr, "unexpected size %d\n", bc.p); return 2;
             }
         }
