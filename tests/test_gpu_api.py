@@ -127,10 +127,15 @@ def test_cpp_live_song_identification(wav_set, filters, tmp_path):
     g.set_filters(learned)
     assert all(np.array_equal(e[1], hp) for e, hp in zip(entries, g.extract(np.stack(clips))))
     g.close()
-    r3 = subprocess.run([exe, "--db", dump, "--search"] + [q[0] for q in qpaths], cwd=str(work),
+    r3 = subprocess.run([exe, "--db", dump, "--search"] + [q[0] for q in qpaths] + ["--votes"], cwd=str(work),
                         capture_output=True, text=True, timeout=300)
     assert r3.returncode == 0, r3.stdout + r3.stderr
     assert [ln for ln in r3.stdout.splitlines() if ln.startswith("=> ")] == lines
+    # the voting search (AnnStorage semantics) names the same tracks; its offset is i - p, minus the scan's
+    voted = [ln[3:].split() for ln in r3.stdout.splitlines() if ln.startswith("=# ")]
+    assert len(voted) == 3
+    for (qp, ci, start), (name, cnt, off) in zip(qpaths, voted):
+        assert name == f"track{ci:02d}" and float(cnt) > 0 and abs(-int(off) - start / hop) <= 2
 
 
 def test_index_readback_and_cached_spectrogram(torch_cuda, oracle, filters):
