@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kPjThreads, 3) void project_kernel(const float *__r
                                                              const float *__restrict__ tmax, int c, int nf,
                                                              float *__restrict__ proj)
 {
-    __shared__ float s_tile[kPjBinsPerChunk * kPjRow];
+    __shared__ float s_tiles[2][kPjBinsPerChunk * kPjRow]; // two slabs: chunk i + 1 is written while chunk i is read
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int kh = lane >> 5;
@@ -67,9 +67,7 @@ __global__ __launch_bounds__(kPjThreads, 3) void project_kernel(const float *__r
                            ? S[(int64_t)(chunk * kPjBinsPerChunk + b) * c + gc] : 0.0f;
         }
     };
-    stage_load(0);
-    for (int chunk = 0; chunk < kBins / kPjBinsPerChunk; ++chunk) {
-        __syncthreads(); // every wave is done reading the previous slab
+    auto stage_store = [&](float *s_tile) {
 #pragma unroll
         for (int j = 0; j < kStage; ++j) {
             const int i = tid + j * kPjThreads;
@@ -83,39 +81,52 @@ __global__ __launch_bounds__(kPjThreads, 3) void project_kernel(const float *__r
             }
             if (i < kPjBinsPerChunk * kPjCols) s_tile[b * kPjRow + (i - b * kPjCols)] = v;
         }
-        __syncthreads();
-        if (chunk + 1 < kBins / kPjBinsPerChunk) stage_load(chunk + 1);
-        if (n0 + wave * 64 >= nf) continue; // a wave whose 64 frames lie past the clip only helps staging
+    };
+    stage_load(0);
+    stage_store(s_tiles[0]);
+    constexpr int kChunks = kBins / kPjBinsPerChunk;
+    if (kChunks > 1) stage_load(1);
+    __syncthreads();
+    for (int chunk = 0; chunk < kChunks; ++chunk) {
+        const float *s_tile = s_tiles[chunk & 1];
+        const bool active = n0 + wave * 64 < nf; // a wave whose 64 frames lie past the clip only helps staging
+        if (active) {
 #pragma unroll 1
-        for (int b = 0; b < kPjBinsPerChunk; ++b) {
-            const int bin = chunk * kPjBinsPerChunk + b;
-            const int nbin = bin + 1 < kBins ? bin + 1 : bin; // the last prefetch re-reads the last bin
-            // next bin's filter operand first, pinned here: left alone the scheduler sinks these loads
-            // to the end of the bin and the wave then waits out their L2 latency before every copy
+            for (int b = 0; b < kPjBinsPerChunk; ++b) {
+                const int bin = chunk * kPjBinsPerChunk + b;
+                const int nbin = bin + 1 < kBins ? bin + 1 : bin; // the last prefetch re-reads the last bin
+                // next bin's filter operand first, pinned here: left alone the scheduler sinks these loads
+                // to the end of the bin and the wave then waits out their L2 latency before every copy
 #pragma unroll
-            for (int i = 0; i < kPjTp / 2; ++i) a_nxt[i] = ap[(size_t)nbin * 64 * (kPjTp / 2) + i];
-            const float *srow = s_tile + b * kPjRow + nl + kh;
-            float b0 = srow[0], b1 = srow[32];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tp = 0; tp < kPjTp; ++tp) {
-                const float4 a4 = a_cur[tp >> 1];
-                const float a0 = (tp & 1) ? a4.z : a4.x; // filter tile 0
-                const float a1 = (tp & 1) ? a4.w : a4.y; // filter tile 1
-                const float c0 = b0, c1 = b1;
-                if (tp + 1 < kPjTp) { // the S operands of the next step are read while this one multiplies
-                    b0 = srow[2 * tp + 2];
-                    b1 = srow[2 * tp + 34];
-                }
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c1, acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c0, acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, acc11, 0, 0, 0);
+                for (int i = 0; i < kPjTp / 2; ++i) a_nxt[i] = ap[(size_t)nbin * 64 * (kPjTp / 2) + i];
+                const float *srow = s_tile + b * kPjRow + nl + kh;
+                float b0 = srow[0], b1 = srow[32];
                 __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
-            for (int i = 0; i < kPjTp / 2; ++i) a_cur[i] = a_nxt[i];
+                for (int tp = 0; tp < kPjTp; ++tp) {
+                    const float4 a4 = a_cur[tp >> 1];
+                    const float a0 = (tp & 1) ? a4.z : a4.x; // filter tile 0
+                    const float a1 = (tp & 1) ? a4.w : a4.y; // filter tile 1
+                    const float c0 = b0, c1 = b1;
+                    if (tp + 1 < kPjTp) { // the S operands of the next step are read while this one multiplies
+                        b0 = srow[2 * tp + 2];
+                        b1 = srow[2 * tp + 34];
+                    }
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c1, acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c0, acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, acc11, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < kPjTp / 2; ++i) a_cur[i] = a_nxt[i];
+            }
         }
+        // chunk + 1 goes into the other slab (last read during chunk - 1, which every wave left before the
+        // barrier below ran for chunk - 1), then chunk + 2 starts loading: one barrier per chunk
+        if (chunk + 1 < kChunks) stage_store(s_tiles[(chunk + 1) & 1]);
+        if (chunk + 2 < kChunks) stage_load(chunk + 2);
+        __syncthreads();
     }
     // D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float *P = proj + (int64_t)clip * kFilters * nf;
