@@ -5,8 +5,8 @@ binding, a twin of the reference's Python class (modules/python/pyhpfw/pyhpfw.py
 synthetic-audio generator used by tests and bench.py.  No CPU fallback exists.
 """
 from ._lib import (Gpu, HpfwError, HIT_DTYPE, VOTE_DTYPE, KERNEL_KINDS, LIB_PATH, lib, merge_topk,  # noqa: F401
-                   plan_checksum)
+                   plan_checksum, supported_length)
 from .collector import ParallelCollector  # noqa: F401
 
 __all__ = ["Gpu", "HpfwError", "HIT_DTYPE", "VOTE_DTYPE", "KERNEL_KINDS", "LIB_PATH", "lib", "merge_topk",
-           "plan_checksum", "ParallelCollector"]
+           "plan_checksum", "supported_length", "ParallelCollector"]

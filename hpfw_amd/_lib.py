@@ -30,7 +30,7 @@ EXPORTS = (
     "hpfw_gpu_index_size", "hpfw_gpu_index_set_clip_base", "hpfw_gpu_search_topk_device",
     "hpfw_gpu_search_topk", "hpfw_gpu_merge_topk", "hpfw_gpu_timer_start", "hpfw_gpu_timer_stop",
     "hpfw_gpu_index_get", "hpfw_gpu_extract_db_host", "hpfw_gpu_stage_spectrogram",
-    "hpfw_gpu_search_votes", "hpfw_gpu_knn_windows",
+    "hpfw_gpu_search_votes", "hpfw_gpu_knn_windows", "hpfw_gpu_supported_length",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_save", "par_collector_load",
@@ -102,6 +102,8 @@ def lib():
     L.hpfw_gpu_timer_start.argtypes = [vp, vp]
     L.hpfw_gpu_timer_stop.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.hpfw_gpu_stage_spectrogram.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_supported_length.argtypes = [i64]
+    L.hpfw_gpu_supported_length.restype = i64
     L.hpfw_gpu_search_votes.argtypes = [vp, vp, vp, i64, vp]
     L.hpfw_gpu_knn_windows.argtypes = [vp, vp, vp, i64, vp, i64]
     L.hpfw_gpu_index_get.argtypes = [vp, vp, vp, ctypes.c_int64]
@@ -332,6 +334,11 @@ def merge_topk(per_shard_hits, k):
     out = np.zeros((n_q, k), HIT_DTYPE)
     check(lib().hpfw_gpu_merge_topk(_hp(a), n_shards, n_q, k, _hp(out)))
     return out
+
+
+def supported_length(n_samples):
+    """the smallest supported clip length >= n_samples, or -1"""
+    return int(lib().hpfw_gpu_supported_length(int(n_samples)))
 
 
 def plan_checksum(n_samples):

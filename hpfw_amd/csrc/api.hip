@@ -108,6 +108,8 @@ struct hpfw_gpu {
     // filter learning: accum_cov of ParallelCollector (parallel_collector.h:76), upper tiles only
     float *d_cov = nullptr;
     float *d_cov_ws = nullptr; // scratch of the covariance kernels
+    void *d_cqwork = nullptr;  // chirp-z bands too long for the LDS (k_cq_big.hip)
+    size_t cqwork_cap = 0;
     size_t cov_ws_cap = 0;
     void *d_qa = nullptr;   // queries expanded to fp4 for the matrix-core scan
     size_t qa_cap = 0;
@@ -249,6 +251,8 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         cd.gtw.mid_off = bc.mid_off;
         if ((rc = upload(bc.vrev, reinterpret_cast<const hpfw::HostCf **>(&cd.vrev), dp->owned))) return rc;
         if ((rc = upload(bc.bands, &cd.band, dp->owned))) return rc;
+        cd.len0 = bc.len0;
+        cd.outer = bc.outer;
         dp->cls.push_back(cd);
     }
     if ((size_t)p.n2 * sizeof(cf) > 150 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
@@ -258,8 +262,28 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
 }
 
 // nb: clips per front-end pass (large intermediates); ns: clips per back-end pass (S and P only)
-int ensure_ws(hpfw_gpu *h, const hpfw::HostPlan &p, int nb, int ns)
+// clips per front-end pass: the handle's batch, the number of clips, and what ~24 GB of workspace hold
+int pass_clips(hpfw_gpu *h, const DevPlan *dp, int64_t n_clips)
 {
+    const hpfw::HostPlan &p = dp->hp;
+    size_t per_clip = (size_t)2 * p.n1 * ((p.h + 31) / 32 * 32) * 4 + (size_t)(p.kmax - p.kmin) * 8 + (size_t)121 * p.c * 4 +
+                      (size_t)64 * std::max(p.n_frames, 1) * 4 + (size_t)((p.n1 + 1) / 2) * p.n2 * 4;
+    size_t work = 0;
+    for (const hpfw::CqClassDev &cd : dp->cls) work = std::max(work, hpfw::cq_big_work_bytes(cd, 1));
+    per_clip += work;
+    const int64_t fit = std::max<int64_t>(1, (int64_t)(((size_t)24 << 30) / per_clip));
+    return (int)std::min<int64_t>(std::min<int64_t>(h->batch, fit), std::max<int64_t>(n_clips, 1));
+}
+
+int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
+{
+    const hpfw::HostPlan &p = dp->hp;
+    size_t work = 0;
+    for (const hpfw::CqClassDev &cd : dp->cls) work = std::max(work, hpfw::cq_big_work_bytes(cd, nb));
+    if (work) {
+        int rc = ensure(&h->d_cqwork, &h->cqwork_cap, work);
+        if (rc) return rc;
+    }
     const size_t need[6] = {(size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4, (size_t)nb * (p.kmax - p.kmin) * 8,
                             (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4,
                             (size_t)ns * 121 * hpfw::kCqMaxWaves * 4, (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4};
@@ -299,7 +323,10 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
     if ((rc = check_launch("fwd_cols"))) return rc;
     for (const hpfw::CqClassDev &cd : dp->cls) {
         Timed t(h, K_CQ, s);
-        hpfw::launch_cq_class(dp->cq, cd, x, nb, mag, mm, true, s);
+        if (cd.outer)
+            hpfw::launch_cq_big_class(dp->cq, cd, x, nb, (cf *)h->d_cqwork, mag, mm, true, s);
+        else
+            hpfw::launch_cq_class(dp->cq, cd, x, nb, mag, mm, true, s);
     }
     if ((rc = check_launch("cq_chirpz"))) return rc;
     {
@@ -369,6 +396,7 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->d_fpack) (void)hipFree(h->d_fpack);
     if (h->d_cov) (void)hipFree(h->d_cov);
     if (h->d_cov_ws) (void)hipFree(h->d_cov_ws);
+    if (h->d_cqwork) (void)hipFree(h->d_cqwork);
     if (h->d_qa) (void)hipFree(h->d_qa);
     if (h->d_gk) (void)hipFree(h->d_gk);
     if (h->d_clipmax) (void)hipFree(h->d_clipmax);
@@ -432,9 +460,9 @@ int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
     if (rc) return rc;
     if (dp->hp.n_hp <= 0) return fail(HPFW_E_UNSUPPORTED, "clip too short to yield a hashprint");
     hipStream_t s = (hipStream_t)stream;
-    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
+    const int nbmax = pass_clips(h, dp, n_clips);
     const int nsmax = (int)std::min<int64_t>(std::max(kBackBatch, nbmax), std::max<int64_t>(n_clips, 1));
-    if ((rc = ensure_ws(h, dp->hp, nbmax, nsmax))) return rc;
+    if ((rc = ensure_ws(h, dp, nbmax, nsmax))) return rc;
     for (int64_t s0 = 0; s0 < n_clips; s0 += nsmax) {
         const int ns = (int)std::min<int64_t>(nsmax, n_clips - s0);
         for (int c0 = 0; c0 < ns; c0 += nbmax) {
@@ -486,8 +514,8 @@ int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples
     int rc = get_plan(h, n_samples, &dp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
-    if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
+    const int nbmax = pass_clips(h, dp, n_clips);
+    if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
@@ -514,14 +542,19 @@ int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64
     int rc = get_plan(h, n_samples, &dp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
-    if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
+    const int nbmax = pass_clips(h, dp, n_clips);
+    if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        for (const hpfw::CqClassDev &cd : dp->cls)
-            hpfw::launch_cq_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb,
-                                  d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s);
+        for (const hpfw::CqClassDev &cd : dp->cls) {
+            if (cd.outer)
+                hpfw::launch_cq_big_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb, (hpfw::cf *)h->d_cqwork,
+                                          d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s);
+            else
+                hpfw::launch_cq_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb,
+                                      d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s);
+        }
         if ((rc = check_launch("cq_chirpz"))) return rc;
     }
     return 0;
@@ -664,8 +697,8 @@ int hpfw_gpu_stage_spectrogram(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samp
     int rc = get_plan(h, n_samples, &dp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
-    if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
+    const int nbmax = pass_clips(h, dp, n_clips);
+    if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     const size_t per = (size_t)121 * dp->hp.c;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
@@ -685,8 +718,8 @@ int hpfw_gpu_cov_accumulate_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_s
     if (rc) return rc;
     if (dp->hp.n_frames < 2) return fail(HPFW_E_UNSUPPORTED, "clip too short for a covariance");
     hipStream_t s = (hipStream_t)stream;
-    const int nbmax = (int)std::min<int64_t>(h->batch, std::max<int64_t>(n_clips, 1));
-    if ((rc = ensure_ws(h, dp->hp, nbmax, nbmax))) return rc;
+    const int nbmax = pass_clips(h, dp, n_clips);
+    if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
         if ((rc = run_front(h, dp, d_pcm + c0 * n_samples, nb, 0, true, s))) return rc;

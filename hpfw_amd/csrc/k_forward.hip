@@ -21,13 +21,13 @@ extern __shared__ __align__(16) unsigned char smem_raw[];
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kPairsTile = 64;
+constexpr int kPairsTileMax = 64; // time steps per tile; fewer when n1 is large (the tile lives in LDS)
 
 // VEC: the tile (nt * n1 samples) is copied in 16-byte pieces -- the launcher checks that every tile
 // starts 16-byte aligned and holds a multiple of 8 samples; otherwise sample by sample.
 template <bool VEC>
-__global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n2, const int16_t *__restrict__ pcm,
-                                                        i16x2 *__restrict__ pairs)
+__global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n2, int kPairsTile,
+                                                        const int16_t *__restrict__ pcm, i16x2 *__restrict__ pairs)
 {
     int16_t *tile = reinterpret_cast<int16_t *>(smem_raw); // [kPairsTile][n1]
     const int tid = threadIdx.x;
@@ -176,15 +176,17 @@ __global__ __launch_bounds__(256, 2) void fwd_cols_kernel(ColsArgs ca, int tile0
 
 void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s)
 {
+    int kPairsTile = kPairsTileMax;
+    while (kPairsTile > 1 && (size_t)kPairsTile * n1 * sizeof(int16_t) > 60 * 1024) kPairsTile /= 2;
     dim3 grid((n2 + kPairsTile - 1) / kPairsTile, n_clips);
     const int tail = n2 % kPairsTile;
     const bool vec = (reinterpret_cast<uintptr_t>(d_pcm) % 16 == 0) && (n * 2 % 16 == 0) && (kPairsTile * n1 % 8 == 0) &&
                      (tail * n1 % 8 == 0);
     const size_t lds = ((size_t)kPairsTile * n1 * sizeof(int16_t) + 15) / 16 * 16;
     if (vec)
-        hipLaunchKernelGGL(pcm_pairs_kernel<true>, grid, dim3(256), lds, s, n, n1, n2, d_pcm, d_pairs);
+        hipLaunchKernelGGL(pcm_pairs_kernel<true>, grid, dim3(256), lds, s, n, n1, n2, kPairsTile, d_pcm, d_pairs);
     else
-        hipLaunchKernelGGL(pcm_pairs_kernel<false>, grid, dim3(256), lds, s, n, n1, n2, d_pcm, d_pairs);
+        hipLaunchKernelGGL(pcm_pairs_kernel<false>, grid, dim3(256), lds, s, n, n1, n2, kPairsTile, d_pcm, d_pairs);
 }
 
 size_t fwd_rows_lds_bytes(const RowsArgs &a) { return (size_t)a.n2 * sizeof(cf); }

@@ -35,6 +35,7 @@ struct CqClassDev {
     CqTwiddles gtw;     // per-butterfly twiddle tables of the fused groups
     const cf *vrev;     // DFT_p(chirp) at digit-reversed positions [p]
     const int *band;    // band index j                 [n_bands]
+    int len0, outer;    // p > 16384: `outer` radix-4 passes through global memory around blocks of len0 (k_cq_big.hip)
 };
 
 struct CqPlanDev {
@@ -60,6 +61,10 @@ constexpr int kCqMaxWaves = 16;
 // db_term_out: store t(m^2) = (float)(10 log10(max(m^2, 1e-10))) instead of the magnitude m
 void launch_cq_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips,
                      float *d_mag, float *d_wavemax, bool db_term_out, hipStream_t s);
+// the same for a class whose length exceeds the LDS (cc.outer > 0); d_work: cq_big_work_bytes(cc, n_clips)
+size_t cq_big_work_bytes(const CqClassDev &cc, int n_clips);
+void launch_cq_big_class(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, cf *d_work, float *d_mag,
+                         float *d_wavemax, bool db_term_out, hipStream_t s);
 // d_clipmax [n_clips] = the largest of each clip's wave maxima
 void launch_clipmax(const float *d_wavemax, float *d_clipmax, int n_clips, hipStream_t s);
 // dB terms -> dB spectrogram in place: S = max(t - t_max, -80)

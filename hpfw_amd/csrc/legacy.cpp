@@ -177,13 +177,25 @@ void par_collector_save(hpfw_legacy_collector *c, const char *cache)
     }
 }
 
+// A file of any length: the PCM is padded with zeros up to the next supported (7-smooth) length --
+// at most 0.8 % more samples; the reference transforms the exact length with FFTW, so this is a
+// deviation, confined to the file entry points and switched off by HPFW_STRICT_LENGTH.
+static bool read_clip(const std::string &path, std::vector<int16_t> &pcm, std::string &why)
+{
+    if (!read_wav_pcm16_mono(path, pcm, why)) return false;
+    if (std::getenv("HPFW_STRICT_LENGTH")) return true;
+    const int64_t want = hpfw_gpu_supported_length((int64_t)pcm.size());
+    if (want > (int64_t)pcm.size()) pcm.resize((size_t)want, 0);
+    return true;
+}
+
 uint64_t *par_collector_calc_hashprint(hpfw_legacy_collector *c, const char *filename, int *size)
 {
     if (size) *size = 0;
     if (!c || !filename || !size) return nullptr;
     std::vector<int16_t> pcm;
     std::string why;
-    if (!read_wav_pcm16_mono(filename, pcm, why)) {
+    if (!read_clip(filename, pcm, why)) {
         hpfw_internal_set_error(why.c_str());
         return nullptr;
     }
@@ -219,7 +231,7 @@ FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const cha
         for (int i = 0; i < n; ++i) {
             std::vector<int16_t> pcm;
             std::string why;
-            if (!read_wav_pcm16_mono(filenames[i], pcm, why)) continue; // skipped, parallel_collector.h:101-103
+            if (!read_clip(filenames[i], pcm, why)) continue; // skipped, parallel_collector.h:101-103
             if (hpfw_gpu_cov_accumulate_pcm16_host(c->gpu, pcm.data(), (int64_t)pcm.size(), 1) == 0) ++used;
         }
         if (used > 0) {

@@ -129,9 +129,9 @@ int64_t chirpz_length(int64_t need)
 // entry (r1-1) r2 + (s2-1) = T_n[ts2 j0 s2], with j0 = b mod m2.  The inverse DIT group uses the
 // same values (conjugated by the kernel).
 void append_group_twiddles(const std::vector<HostCf> &tw, int64_t n, int64_t len, int r1, int r2,
-                           std::vector<HostCf> &out)
+                           std::vector<HostCf> &out, int64_t nb_out)
 {
-    const int64_t m1 = len / r1, m2 = m1 / r2, ts1 = n / len, ts2 = n / m1, nb = n / (r1 * r2);
+    const int64_t m1 = len / r1, m2 = m1 / r2, ts1 = n / len, ts2 = n / m1, nb = nb_out ? nb_out : n / (r1 * r2);
     const size_t off = out.size();
     out.resize(off + (size_t)((r1 - 1) * r2 + (r2 - 1)) * nb);
     for (int64_t b = 0; b < nb; ++b) {
@@ -198,7 +198,7 @@ bool make_radix_list(int64_t n, std::vector<int> &radix)
     return radix.size() <= 24;
 }
 
-bool build_plan(int64_t n, HostPlan &p, std::string &why)
+bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
 {
     if (n < 2) {
         why = "clip too short";
@@ -239,6 +239,10 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
     p.n_hp = p.n_frames - kLag;
     if (p.n_frames < 0) p.n_frames = 0;
     if (p.n_hp < 0) p.n_hp = 0;
+    if (chirpz_length(big_m + p.c - 1) > (1 << 19)) { // the longest band's transform; checked before any table is built
+        why = "clip too long: chirp-z length above 2^19 (about 25 minutes)";
+        return false;
+    }
     // ---- forward split N = n1 * n2 ----
     // d0 = the smallest divisor with N / d0 <= kN2Max; among the divisors in [d0, 5 d0 / 4] prefer an
     // even n2 (its twiddle table halves exactly), then the fewest pairs of radix passes, then the
@@ -284,6 +288,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
     p.h = (int)(n2 / 2 + 1);
     p.k1lo = (int)(kmin / n2);
     p.k1hi = (int)((kmax - 1) / n2);
+    if (geometry_only) return true;
     p.tw_n2 = twiddle_table(n2);
     p.tw_n1 = twiddle_table(n1);
     // fuse consecutive passes in pairs of at most 36 points (kernel-side scheduling, same arithmetic;
@@ -337,8 +342,8 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
     for (int j = 0; j < kBins; ++j) {
         const int64_t need = p.lg[j] + p.c - 1;
         const int64_t ps = chirpz_length(need);
-        if (ps > 16384) {
-            why = "clip too long: chirp-z length exceeds the LDS";
+        if (ps > (1 << 19)) {
+            why = "clip too long: chirp-z length above 2^19";
             return false;
         }
         p.psize[j] = (int)ps;
@@ -355,15 +360,22 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
             // entries do not depend on the butterfly and are stored once
             {
                 auto next_radix = [](int64_t len) { return len % 4 == 0 ? 4 : (len % 3 == 0 ? 3 : 2); };
+                // above 16384 points: peel radix-4 passes off the front until a block fits the LDS
                 int64_t len = ps;
+                while (len > 8192) {
+                    len /= 4;
+                    ++bc.outer;
+                }
+                bc.len0 = (int)len;
+                const int64_t blk = len; // butterfly tables cover one block (the whole transform when it fits)
                 int g = 0;
                 for (;;) {
                     const int r1 = next_radix(len);
                     const int r2 = len / r1 > 1 ? next_radix(len / r1) : 1;
                     if (len / (r1 * r2) == 1) {
                         std::vector<HostCf> tmp;
-                        append_group_twiddles(bc.tw, ps, len, r1, r2, tmp);
-                        const int64_t nb = ps / (r1 * r2);
+                        append_group_twiddles(bc.tw, ps, len, r1, r2, tmp, blk / (r1 * r2));
+                        const int64_t nb = blk / (r1 * r2);
                         bc.mid_off = (int)bc.gtw.size();
                         for (int e = 0; e < (r1 - 1) * r2; ++e) bc.gtw.push_back(tmp[(size_t)e * nb]);
                         break;
@@ -373,7 +385,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why)
                         return false;
                     }
                     bc.goff[g++] = (int)bc.gtw.size();
-                    append_group_twiddles(bc.tw, ps, len, r1, r2, bc.gtw);
+                    append_group_twiddles(bc.tw, ps, len, r1, r2, bc.gtw, blk / (r1 * r2));
                     len /= r1 * r2;
                 }
             }
@@ -423,6 +435,25 @@ uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 1469598103934665603u
     return h;
 }
 } // namespace
+
+// the smallest supported clip length >= n_samples (include/hpfw_gpu.h), or -1
+extern "C" int64_t hpfw_gpu_supported_length(int64_t n_samples)
+{
+    for (int64_t n = n_samples > 2 ? n_samples : 2; n <= (int64_t)44100 * 1600; ++n) {
+        int64_t m = n;
+        for (int f : {2, 3, 5, 7})
+            while (m % f == 0) m /= f;
+        if (m != 1) continue;
+        hpfw::HostPlan hp;
+        std::string why;
+        if (hpfw::build_plan(n, hp, why, true)) {
+            if (hp.n_hp > 0) return n;
+        } else if (why.find("too long") != std::string::npos) {
+            return -1;
+        }
+    }
+    return -1;
+}
 
 extern "C" int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8)
 {

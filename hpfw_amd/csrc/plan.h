@@ -21,6 +21,10 @@ struct BluesteinClass {
     int mid_off = 0;           // start of the innermost group's entries
     std::vector<HostCf> vrev;  // DFT_p(chirp) at digit-reversed positions
     std::vector<int> bands;    // bands using this size
+    // p > 16384 does not fit the LDS: the first `outer` radix-4 passes (and the last `outer` inverse ones)
+    // run through global memory, the rest on blocks of len0 = p / 4^outer points in LDS; gtw then holds
+    // the groups of a length-len0 transform with the twiddles of length p
+    int len0 = 0, outer = 0;
 };
 
 struct HostPlan {
@@ -42,14 +46,16 @@ struct HostPlan {
 };
 
 // Returns false (and a reason) when the clip length is unsupported.
-bool build_plan(int64_t n_samples, HostPlan &out, std::string &why);
+// geometry_only: stop after the sizes (n1, n2, M, C, bins consumed) are known, build no table
+bool build_plan(int64_t n_samples, HostPlan &out, std::string &why, bool geometry_only = false);
 
 // e^{-2 pi i m / n} with exact octant symmetry, evaluated in double (S2)
 void twiddle_d(int64_t m, int64_t n, double &re, double &im);
 // mixed-radix digit reversal of the DIF pass list
 int64_t digit_pos(int64_t k, int64_t n, const std::vector<int> &radix);
 bool make_radix_list(int64_t n, std::vector<int> &radix);
+// nb_out > 0: only the first nb_out butterflies (the table of one block of a larger transform)
 void append_group_twiddles(const std::vector<HostCf> &tw, int64_t n, int64_t len, int r1, int r2,
-                           std::vector<HostCf> &out);
+                           std::vector<HostCf> &out, int64_t nb_out = 0);
 
 } // namespace hpfw

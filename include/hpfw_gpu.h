@@ -94,6 +94,12 @@ int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_sampl
 /* clips processed per internal pass (workspace = ~9.5 MB per clip at 30 s); 0 = default (256) */
 int hpfw_gpu_set_batch(hpfw_gpu *h, int clips_per_pass);
 
+/* The smallest supported clip length >= n_samples (lengths must be 7-smooth), or
+ * -1 beyond the longest supported clip.  Host-only.  The file entry points (par_collector_*) pad a
+ * file with zeros up to it -- at most 0.8 % more samples -- unless HPFW_STRICT_LENGTH is set; the
+ * PCM entry points never alter their input and reject other lengths. */
+int64_t hpfw_gpu_supported_length(int64_t n_samples);
+
 /* ---- per-stage entry points (parity checkpoints; same kernels the full chain runs) ------- */
 /* PCM -> forward DFT bins [kmin,kmax): d_x [n_clips][kmax-kmin][2]           cqt.h:45-52,66 */
 int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,

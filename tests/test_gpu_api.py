@@ -75,10 +75,21 @@ def test_stereo_and_unsupported_wav(wav_set, filters, tmp_path):
     synth.write_wav(mono, clips[0])
     assert np.array_equal(pc.calc_hashprint(p), pc.calc_hashprint(mono))
     bad = str(tmp_path / "odd.wav")
-    synth.write_wav(bad, clips[0][:44100 * 8 - 1])       # 352799 samples: prime factor 13 -> unsupported length
-    with pytest.raises(hpfw_amd.HpfwError) as e:
-        pc.calc_hashprint(bad)
-    assert "prime factor" in str(e.value)
+    synth.write_wav(bad, clips[0][:44100 * 8 - 1])       # 352799 samples: prime factor 13 -> not a supported length
+    os.environ["HPFW_STRICT_LENGTH"] = "1"
+    try:
+        with pytest.raises(hpfw_amd.HpfwError) as e:
+            pc.calc_hashprint(bad)
+        assert "prime factor" in str(e.value)
+    finally:
+        del os.environ["HPFW_STRICT_LENGTH"]
+    # by default a file is padded with zeros to the next supported length (here one sample)
+    assert hpfw_amd.supported_length(44100 * 8 - 1) == 44100 * 8
+    padded = np.concatenate([clips[0][:44100 * 8 - 1], np.zeros(1, np.int16)])
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filters)
+    assert np.array_equal(pc.calc_hashprint(bad), g.extract(padded)[0])
+    g.close()
     with pytest.raises(hpfw_amd.HpfwError):
         pc.calc_hashprint(str(tmp_path / "nope.wav"))
 

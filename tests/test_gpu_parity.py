@@ -89,18 +89,19 @@ def test_stages_bit_exact(gpu, torch_cuda, oracle, filters, seconds):
     assert np.array_equal(hp_all, np.stack([plan.extract(filters, c) for c in clips]))
 
 
-@pytest.mark.parametrize("seconds", [2.0, 4.2, 7.0, 10.0, 12.5, 20.0, 45.0, 49.0])
+@pytest.mark.parametrize("seconds", [2.0, 4.2, 7.0, 10.0, 12.5, 20.0, 45.0, 49.0, 60.0, 100.0, 180.0])
 def test_extract_other_lengths(gpu, oracle, filters, seconds):
-    """other clip lengths (different n1, chirp-z classes from 64 to 16384 points, the run-time group
-    sequence when n2 is not 6300): hashprints and the dB spectrogram stay bit-exact"""
+    """other clip lengths (different n1, chirp-z classes from 64 to 16384 points in LDS and, from 60 s on,
+    lengths up to 98304 points through global memory, the run-time group sequence when n2 is not 6300):
+    hashprints and the dB spectrogram stay bit-exact"""
     torch = pytest.importorskip("torch")
-    clips = np.stack([synth.gen_clip(900 + i, seconds) for i in range(2)])
+    clips = np.stack([synth.gen_clip(900 + i, seconds) for i in range(2 if seconds < 60 else 1)])
     n = clips.shape[1]
     plan = oracle.Plan(n)
     assert np.array_equal(gpu.extract(clips), np.stack([plan.extract(filters, c) for c in clips]))
     d_pcm = _dev(torch, clips)
-    d_db = torch.empty((2, 121, plan.c), dtype=torch.float32, device="cuda")
-    gpu.stage_spectrogram_dev(d_pcm.data_ptr(), n, 2, d_db.data_ptr())
+    d_db = torch.empty((len(clips), 121, plan.c), dtype=torch.float32, device="cuda")
+    gpu.stage_spectrogram_dev(d_pcm.data_ptr(), n, len(clips), d_db.data_ptr())
     torch.cuda.synchronize()
     want = np.stack([oracle.db(plan.cqmag(plan.spectrum(c))) for c in clips])
     assert bits_equal(d_db.cpu().numpy(), want)

@@ -47,9 +47,26 @@ def test_plan_tables_identical_to_oracle(oracle, n):
 
 
 def test_unsupported_lengths_fail_loudly():
-    for n in (1323001, 4410, 1, 44100 * 60):       # prime factor 11 ..., too short, too long for the LDS
+    for n in (1323001, 4410, 1, 44100 * 3600):     # prime factor 11 ..., too short, chirp-z length above 2^19
         with pytest.raises(hpfw_amd.HpfwError):
             hpfw_amd.plan_checksum(n)
+
+
+def test_supported_length():
+    """lengths are 7-smooth: the next one above a given length, as the file entry points pad to"""
+    assert hpfw_amd.supported_length(1323000) == 1323000
+    assert hpfw_amd.supported_length(1323001) == 1327104        # 2^14 * 3^4
+    for n in (220501, 352799, 5000000, 12345678):
+        m = hpfw_amd.supported_length(n)
+        assert m >= n and (m - n) / n < 0.016
+        k = m
+        for f in (2, 3, 5, 7):
+            while k % f == 0:
+                k //= f
+        assert k == 1
+        hpfw_amd.plan_checksum(m) if m < 2000000 else None     # the plan exists
+    assert hpfw_amd.supported_length(44100 * 3600) == -1
+    assert hpfw_amd.supported_length(10) == 54432                 # the shortest clip that yields a hashprint (1.23 s)
 
 
 def test_merge_topk_host():
