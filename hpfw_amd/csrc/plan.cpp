@@ -362,7 +362,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
                 auto next_radix = [](int64_t len) { return len % 4 == 0 ? 4 : (len % 3 == 0 ? 3 : 2); };
                 // above 16384 points: peel radix-4 passes off the front until a block fits the LDS
                 int64_t len = ps;
-                while (len > 8192) {
+                while (ps > 16384 && len > 8192) {
                     len /= 4;
                     ++bc.outer;
                 }
