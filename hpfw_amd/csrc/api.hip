@@ -210,8 +210,6 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     if ((rc = upload(p.pos_n2, &ra.pos_n2, dp->owned))) return rc;
     if ((rc = upload(p.kb_last, &ra.kb_last, dp->owned))) return rc;
     if (hpfw::fwd_rows_lds_bytes(ra) > 160 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
-    if (std::getenv("HPFW_DEBUG_ROWS_NOGROUPS")) ra.groups.n = 0; // timing ablations only (wrong results)
-    if (std::getenv("HPFW_DEBUG_ROWS_NOEPI")) ra.h = 0;
     // column DFT: coefficient image for the MFMA A operand
     hpfw::ColsArgs &ca = dp->cols;
     std::memset(&ca, 0, sizeof(ca));
@@ -224,7 +222,6 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     ca.k1lo = p.k1lo;
     ca.k1n = p.k1hi - p.k1lo + 1;
     ca.n_tiles = (2 * ca.k1n + 15) / 16;
-    ca.debug_same_a = std::getenv("HPFW_DEBUG_COLS_SAME_A") ? 1 : 0;
     {
         std::vector<float> apack((size_t)p.n1 * ca.n_tiles * 64);
         hpfw::pack_cols_coefficients(p.n1, ca.k1lo, ca.k1n, reinterpret_cast<const float *>(p.tw_n1.data()),

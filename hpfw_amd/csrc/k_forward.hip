@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void fwd_cols_kernel(ColsArgs ca, int tile0
     const int vb = (hb * ca.hpad + ctile * 32 + j) * 4;
     const int va = (tile0 * 64 + lane) * 4;
     const int sb = 2 * ca.hpad * 4;                          // bytes per residue in Y' (Re row, Im row)
-    const int sa = ca.debug_same_a ? 0 : ca.n_tiles * 256;   // bytes per residue in the coefficient image
+    const int sa = ca.n_tiles * 256;                         // bytes per residue in the coefficient image
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};

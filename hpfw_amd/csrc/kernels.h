@@ -22,7 +22,6 @@ struct ColsArgs {
     int kmin, kmax;     // forward bins consumed
     int k1lo, k1n;      // wanted rows k1lo .. k1lo + k1n - 1 (and their mirrors)
     int n_tiles;        // row tiles of 32 (16 complex rows each) covering 2 k1n complex rows
-    int debug_same_a;   // timing ablation only: every step reads the same coefficients (wrong results)
     const float *apack; // coefficient image [n1][n_tiles][64]
 };
 

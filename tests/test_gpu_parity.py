@@ -107,6 +107,22 @@ def test_extract_other_lengths(gpu, oracle, filters, seconds):
     assert bits_equal(d_db.cpu().numpy(), want)
 
 
+def test_rows_in_place_variant(oracle, filters):
+    """HPFW_ROWS_INPLACE=1: the row transform reads the pair words straight from the PCM (no pre-pass);
+    a measured-slower alternative that must give the same bits"""
+    import os
+    clips = np.stack([synth.gen_clip(940 + i, 5.0) for i in range(2)])
+    want = np.stack([oracle.Plan(clips.shape[1]).extract(filters, c) for c in clips])
+    os.environ["HPFW_ROWS_INPLACE"] = "1"
+    try:
+        g = hpfw_amd.Gpu(0)          # the switch is read when the plan of a clip length is built
+        g.set_filters(filters)
+        assert np.array_equal(g.extract(clips), want)
+        g.close()
+    finally:
+        del os.environ["HPFW_ROWS_INPLACE"]
+
+
 def test_clip_too_short_is_an_error(gpu, filters):
     """below 100 spectrogram columns there is no hashprint (the reference would resize a matrix to a
     negative width, hashprint_handle.h:118); the library says so"""
