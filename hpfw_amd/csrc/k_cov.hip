@@ -118,21 +118,46 @@ __global__ __launch_bounds__(256) void lag_corr_kernel(const float *__restrict__
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
     const int item0 = blockIdx.y * items_per_split, item1 = min(n_items, item0 + items_per_split);
-    for (int item = item0; item < item1; ++item) {
+    // the two slabs of an item go global -> registers while the previous item multiplies, registers ->
+    // LDS between two barriers: the loads' latency hides behind the MFMAs
+    constexpr int kNa = (kLgBinsA * (kLgChunk + kCtx - 1) + 255) / 256; // 3 words of slab A per thread
+    constexpr int kNb = kLgCols * kLgChunk / 256;                       // 32 words of slab B per thread
+    float ra[kNa], rb[kNb];
+    auto stage_load = [&](int item) {
         const int clip = item / n_chunks, u0 = (item - clip * n_chunks) * kLgChunk;
         const float *Z = z + (int64_t)clip * kBins * c;
-        __syncthreads();
-        for (int i = tid; i < kLgBinsA * (kLgChunk + kCtx - 1); i += 256) {
+#pragma unroll
+        for (int k = 0; k < kNa; ++k) {
+            const int i = tid + k * 256;
             const int bl = i / (kLgChunk + kCtx - 1), col = i - bl * (kLgChunk + kCtx - 1);
             const int b = bin0 + bl, gc = u0 + col;
-            slab_a[bl * kLgRowA + col] = (b < kBins && gc < c) ? Z[(int64_t)b * c + gc] : 0.0f;
+            ra[k] = (bl < kLgBinsA && b < kBins && gc < c) ? Z[(int64_t)b * c + gc] : 0.0f;
         }
-        for (int i = tid; i < kLgCols * kLgChunk; i += 256) {
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) {
+            const int i = tid + k * 256;
             const int b = i / kLgChunk, col = i - b * kLgChunk;
             const int gc = u0 + col;
-            slab_b[b * kLgRowB + col] = (b < kBins && gc < c) ? Z[(int64_t)b * c + gc] : 0.0f;
+            rb[k] = (b < kBins && gc < c) ? Z[(int64_t)b * c + gc] : 0.0f;
+        }
+    };
+    if (item0 < item1) stage_load(item0);
+    for (int item = item0; item < item1; ++item) {
+        __syncthreads(); // every wave is done with the previous slabs
+#pragma unroll
+        for (int k = 0; k < kNa; ++k) {
+            const int i = tid + k * 256;
+            const int bl = i / (kLgChunk + kCtx - 1), col = i - bl * (kLgChunk + kCtx - 1);
+            if (bl < kLgBinsA) slab_a[bl * kLgRowA + col] = ra[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kNb; ++k) {
+            const int i = tid + k * 256;
+            const int b = i / kLgChunk, col = i - b * kLgChunk;
+            slab_b[b * kLgRowB + col] = rb[k];
         }
         __syncthreads();
+        if (item + 1 < item1) stage_load(item + 1);
 #pragma unroll 4
         for (int st = 0; st < kLgChunk / 2; ++st) {
             const int n = 2 * st + hb;
