@@ -109,6 +109,8 @@ struct hpfw_gpu {
     float *d_cov = nullptr;
     float *d_cov_ws = nullptr; // scratch of the covariance kernels
     void *d_cqwork = nullptr;  // chirp-z bands too long for the LDS (k_cq_big.hip)
+    void *d_topk_scratch = nullptr;
+    size_t topk_scratch_cap = 0;
     size_t cqwork_cap = 0;
     size_t cov_ws_cap = 0;
     void *d_qa = nullptr;   // queries expanded to fp4 for the matrix-core scan
@@ -394,6 +396,7 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->d_cov) (void)hipFree(h->d_cov);
     if (h->d_cov_ws) (void)hipFree(h->d_cov_ws);
     if (h->d_cqwork) (void)hipFree(h->d_cqwork);
+    if (h->d_topk_scratch) (void)hipFree(h->d_topk_scratch);
     if (h->d_qa) (void)hipFree(h->d_qa);
     if (h->d_gk) (void)hipFree(h->d_gk);
     if (h->d_clipmax) (void)hipFree(h->d_clipmax);
@@ -902,8 +905,9 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
     qgroup = std::min<int64_t>(qgroup, (n_q + 31) / 32 * 32);
     if ((rc = ensure((void **)&h->d_best, &h->best_cap, (size_t)qgroup * n_clips * 8))) return rc;
     // The scan runs on the matrix cores (k_search_mfma.hip) unless the window does not fit the LDS
-    // (queries of several thousand hashprints), there are only a few queries, or HPFW_SEARCH_POPC asks for
-    // the xor/popcount kernel (HPFW_SEARCH_MFMA forces the matrix path for any number of queries).
+    // (queries of several thousand hashprints) or HPFW_SEARCH_POPC asks for the xor/popcount kernel; fewer than
+    // 8 queries go one by one through the shifted-rows variant (HPFW_SEARCH_MFMA / HPFW_SEARCH_SHIFT force
+    // the grouped / the shifted-rows kernel for any number of queries).
     // A group of 32 queries is one MFMA tile: with fewer than 8 queries most of its rows would be padding
     // and the popcount kernel (one workgroup per 8 queries) does less work.
     const bool mfma = !std::getenv("HPFW_SEARCH_POPC") && hpfw::hamming_mfma_lds_bytes((int)k_max) <= 160 * 1024 &&
@@ -928,7 +932,17 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
         a.n_q = ng;
         a.k_max = (int)k_max;
         a.best = h->d_best;
-        if (mfma && n_max > 0) {
+        const bool few = (!mfma || std::getenv("HPFW_SEARCH_SHIFT")) && !std::getenv("HPFW_SEARCH_POPC") && k_max > 0 && n_max > 0 &&
+                         hpfw::hamming_shift_lds_bytes((int)k_max) <= 160 * 1024;
+        if (few) { // a handful of queries: one launch each, the tile rows are shifts of the query
+            Timed t(h, K_SCAN, s);
+            for (int i = 0; i < ng; ++i) {
+                const int kq = (int)(q_off[g0 + i + 1] - q_off[g0 + i]);
+                if (kq <= 0) continue;
+                hpfw::launch_hamming_shift(h->d_db, h->d_db_off, (int)n_clips, (int)std::max<int64_t>(n_max - std::min<int64_t>(kq, n_max) + 1, 1),
+                                           d_q_hp + q_off[g0 + i], kq, h->d_best + (size_t)i * n_clips, s);
+            }
+        } else if (mfma && n_max > 0) {
             gk.assign((size_t)(ng + 31) / 32 * 2, 0); // per group: longest query, shortest non-empty query
             int kmin_all = 0;
             for (int i = 0; i < ng; ++i) {
@@ -951,7 +965,12 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
         if ((rc = check_launch("hamming_scan"))) return rc;
         {
             Timed t(h, K_TOPK, s);
-            hpfw::launch_topk(h->d_best, ng, (int)n_clips, k, h->clip_base, d_out + g0 * k, s);
+            if (n_clips >= 16384 && ng <= 64) { // one workgroup per query would crawl through the whole table
+                if ((rc = ensure(&h->d_topk_scratch, &h->topk_scratch_cap, hpfw::topk_scratch_bytes(ng, k)))) return rc;
+                hpfw::launch_topk_two_step(h->d_best, ng, (int)n_clips, k, h->clip_base, h->d_topk_scratch, d_out + g0 * k, s);
+            } else {
+                hpfw::launch_topk(h->d_best, ng, (int)n_clips, k, h->clip_base, d_out + g0 * k, s);
+            }
         }
         if ((rc = check_launch("topk"))) return rc;
     }

@@ -177,6 +177,119 @@ __global__ __launch_bounds__(256) void topk_kernel(const uint64_t *__restrict__ 
     }
 }
 
+// Large indexes: top-k in two steps so that one query is not the work of one workgroup.  Step 1: slice
+// g of query q (clips [g S, (g + 1) S)) -> its k best as (key = dist << 32 | clip, offset), ~0 where none;
+// step 2: topk_merge_kernel picks the k smallest keys of the G k candidates.
+constexpr int kTkSlices = 64;
+
+__global__ __launch_bounds__(256) void topk_slice_kernel(const uint64_t *__restrict__ best, int n_clips, int k,
+                                                         uint64_t *__restrict__ cand_key, int32_t *__restrict__ cand_off)
+{
+    __shared__ uint64_t red[4];
+    const int tid = threadIdx.x, g = blockIdx.x, q = blockIdx.y;
+    const int per = (n_clips + kTkSlices - 1) / kTkSlices, c0 = g * per, c1 = min(n_clips, c0 + per);
+    const uint64_t *row = best + (int64_t)q * n_clips;
+    uint64_t prev = 0;
+    bool first = true;
+    for (int t = 0; t < k; ++t) {
+        uint64_t mine = ~0ull;
+        for (int c = c0 + tid; c < c1; c += 256) {
+            const uint64_t b = row[c];
+            if (b == ~0ull) continue;
+            const uint64_t key = (b & 0xffffffff00000000ull) | (uint32_t)c;
+            if ((first || key > prev) && key < mine) mine = key;
+        }
+        mine = wave_min_u64(mine);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = mine;
+        __syncthreads();
+        uint64_t sel = red[0];
+        for (int w = 1; w < 4; ++w) sel = red[w] < sel ? red[w] : sel;
+        if (tid == 0) {
+            const int64_t o = ((int64_t)q * kTkSlices + g) * k + t;
+            cand_key[o] = sel;
+            cand_off[o] = sel == ~0ull ? 0 : (int32_t)(uint32_t)row[(uint32_t)sel];
+        }
+        prev = sel;
+        first = false;
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_merge_kernel(const uint64_t *__restrict__ cand_key,
+                                                         const int32_t *__restrict__ cand_off, int k, uint32_t clip_base,
+                                                         HitDev *__restrict__ out)
+{
+    __shared__ uint64_t red[4];
+    __shared__ int red_i[4];
+    const int tid = threadIdx.x, q = blockIdx.x;
+    const int n = kTkSlices * k;
+    const uint64_t *keys = cand_key + (int64_t)q * n;
+    uint64_t prev = 0;
+    bool first = true;
+    for (int t = 0; t < k; ++t) {
+        uint64_t mine = ~0ull;
+        int mi = 0;
+        for (int i = tid; i < n; i += 256) {
+            const uint64_t key = keys[i];
+            if (key != ~0ull && (first || key > prev) && key < mine) {
+                mine = key;
+                mi = i;
+            }
+        }
+        // the keys are distinct (they carry the clip id), so the winner's index follows its key
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)mine, s);
+            const int oi = __shfl_xor(mi, s);
+            if (o < mine) {
+                mine = o;
+                mi = oi;
+            }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = mine;
+            red_i[tid >> 6] = mi;
+        }
+        __syncthreads();
+        uint64_t sel = red[0];
+        int si = red_i[0];
+        for (int w = 1; w < 4; ++w)
+            if (red[w] < sel) {
+                sel = red[w];
+                si = red_i[w];
+            }
+        if (tid == 0) {
+            HitDev h;
+            if (sel == ~0ull) {
+                h.dist = 0xffffffffu;
+                h.clip = 0xffffffffu;
+                h.offset = 0;
+            } else {
+                h.dist = (uint32_t)(sel >> 32);
+                h.clip = clip_base + (uint32_t)sel;
+                h.offset = cand_off[(int64_t)q * n + si];
+            }
+            h.pad = 0;
+            out[(int64_t)q * k + t] = h;
+        }
+        prev = sel;
+        first = false;
+    }
+}
+
+size_t topk_scratch_bytes(int n_q, int k) { return (size_t)n_q * kTkSlices * k * (sizeof(uint64_t) + sizeof(int32_t)); }
+
+void launch_topk_two_step(const uint64_t *d_best, int n_q, int n_clips, int k, uint32_t clip_base, void *d_scratch,
+                          void *d_out, hipStream_t s)
+{
+    uint64_t *keys = reinterpret_cast<uint64_t *>(d_scratch);
+    int32_t *offs = reinterpret_cast<int32_t *>(keys + (size_t)n_q * kTkSlices * k);
+    hipLaunchKernelGGL(topk_slice_kernel, dim3(kTkSlices, n_q), dim3(256), 0, s, d_best, n_clips, k, keys, offs);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(n_q), dim3(256), 0, s, keys, offs, k, clip_base,
+                       reinterpret_cast<HitDev *>(d_out));
+}
+
 template <int QT>
 static void launch_hamming_scan_t(const SearchArgs &a, hipStream_t s)
 {

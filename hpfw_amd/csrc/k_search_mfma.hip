@@ -19,6 +19,8 @@
 //   out of that: a query longer than the clip meets zeros beyond n.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace hpfw {
 
 extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -267,6 +269,190 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
             }
         }
     }
+}
+
+// ---- one query (or a few, one launch each): the rows of the MFMA tile are 32 shifts of the query ----
+// acc(m, n) = sum_j <Q[j - m], R[t0 + 32 n + j]> = the dot product at offset t0 + 32 n + m, so one tile is
+// 1024 consecutive offsets of one clip and every row does useful work (a tile of hamming_mfma_kernel
+// would carry 31 rows of padding).  Workgroup = one tile; its four waves split the k + 31 steps and
+// add their accumulators through LDS.  The clip window is stored transposed (slot i at row i mod 32)
+// so that the columns' operands, 32 slots apart, are read from consecutive addresses.
+struct SearchShiftArgs {
+    const uint64_t *db;
+    const int64_t *db_off;
+    int n_clips;
+    const uint64_t *q; // the query's hashprints (device)
+    int k;             // its length
+    uint64_t *best;    // [n_clips], initialised to ~0
+    int chunks;        // tiles (of 1024 offsets) per clip
+    int w32;           // row stride of the transposed window (odd)
+};
+
+__global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m_lane = lane & 31, h = lane >> 5;
+    const int clip = blockIdx.x / a.chunks;
+    const int64_t r0 = a.db_off[clip];
+    const int n = (int)(a.db_off[clip + 1] - r0);
+    if (n <= 0 || a.k <= 0) return;
+    const int keff = a.k < n ? a.k : n; // storage.h:37-39
+    const int t0 = (blockIdx.x - clip * a.chunks) * 1024;
+    if (t0 > n - keff) return;
+    const int steps = a.k + 31;
+    const int win = 1024 + steps;                  // window slots used: 32 n + j < 992 + steps
+    const int plane = 32 * a.w32;                  // v4i per half-plane of the transposed window
+    v4i *wB = reinterpret_cast<v4i *>(smem_raw);   // [2][32][w32]
+    v4i *wA = wB + 2 * plane;                      // [2][steps + 31]: slot i = Q[i - 31]
+    const int qlen = steps + 31;
+    // every load of the staging (query first, then up to 8 window slots per thread and round) is issued
+    // before the first value is expanded, so their latencies overlap instead of adding up
+    constexpr int kLq = 2, kLd = 8;
+    uint64_t wq[kLq];
+#pragma unroll
+    for (int e = 0; e < kLq; ++e) {
+        const int j = tid + e * 256 - 31;
+        wq[e] = (j >= 0 && j < a.k) ? a.q[j] : 0ull;
+    }
+    for (int i0 = tid; i0 < win; i0 += kLd * 256) {
+        uint64_t w[kLd];
+#pragma unroll
+        for (int e = 0; e < kLd; ++e) {
+            const int gi = t0 + i0 + e * 256;
+            w[e] = (i0 + e * 256 < win && gi < n) ? a.db[r0 + gi] : 0ull;
+        }
+#pragma unroll
+        for (int e = 0; e < kLd; ++e) {
+            const int i = i0 + e * 256;
+            if (i < win) {
+                const bool in = t0 + i < n; // past the end of the clip: fp4 zeros, not expand(0) = all +1
+                const int slot = (i & 31) * a.w32 + (i >> 5);
+                wB[slot] = in ? expand32((uint32_t)w[e]) : v4i{0, 0, 0, 0};
+                wB[plane + slot] = in ? expand32((uint32_t)(w[e] >> 32)) : v4i{0, 0, 0, 0};
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kLq; ++e) {
+        const int i = tid + e * 256, j = i - 31;
+        if (i < qlen) {
+            const bool in = j >= 0 && j < a.k;
+            wA[i] = in ? expand32((uint32_t)wq[e]) : v4i{0, 0, 0, 0};
+            wA[qlen + i] = in ? expand32((uint32_t)(wq[e] >> 32)) : v4i{0, 0, 0, 0};
+        }
+    }
+    for (int i = tid + kLq * 256; i < qlen; i += 256) { // queries longer than 450 hashprints: the rest, plainly
+        const int j = i - 31;
+        const bool in = j >= 0 && j < a.k;
+        const uint64_t w = in ? a.q[j] : 0ull;
+        wA[i] = in ? expand32((uint32_t)w) : v4i{0, 0, 0, 0};
+        wA[qlen + i] = in ? expand32((uint32_t)(w >> 32)) : v4i{0, 0, 0, 0};
+    }
+    __syncthreads();
+    f32x16 acc = {0};
+    const int one = 0x7f7f7f7f;
+    const int per = (steps + 3) / 4, j0 = wave * per, j1 = min(steps, j0 + per);
+    const v4i *ap = wA + h * qlen + 31 - m_lane;   // + j
+    const v4i *bp = wB + h * plane + m_lane;       // lane index = column n here
+    // four steps per round: the eight operand reads of the next round are in flight behind the MFMAs of this one
+    constexpr int kSt = 4;
+    v4i ca[kSt], cb[kSt], na[kSt], nb[kSt];
+    auto fetch = [&](int j, v4i (&fa)[kSt], v4i (&fb)[kSt]) {
+#pragma unroll
+        for (int e = 0; e < kSt; ++e) {
+            const int jj = j + e < j1 ? j + e : j1 - 1; // the tail re-reads the last step (its product is not used)
+            fa[e] = ap[jj];
+            fb[e] = bp[(jj & 31) * a.w32 + (jj >> 5)];
+        }
+    };
+    if (j0 < j1) fetch(j0, ca, cb);
+    for (int j = j0; j < j1; j += kSt) {
+        if (j + kSt < j1) fetch(j + kSt, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < kSt; ++e) {
+            if (j + e < j1) {
+                const v8i av = {ca[e].x, ca[e].y, ca[e].z, ca[e].w, 0, 0, 0, 0};
+                const v8i bv = {cb[e].x, cb[e].y, cb[e].z, cb[e].w, 0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 4, 4, 0, one, 0, one);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < kSt; ++e) {
+            ca[e] = na[e];
+            cb[e] = nb[e];
+        }
+    }
+    __syncthreads(); // the windows are no longer read: their memory takes the partial sums
+    float *red = reinterpret_cast<float *>(smem_raw); // [4 waves][16 regs][64 lanes]
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) red[(wave * 16 + reg) * 64 + lane] = acc[reg];
+    __syncthreads();
+    // thread (reg = tid / 64 .. , lane): 16 regs x 64 lanes = 1024 sums, four per thread
+    unsigned key = 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int reg = wave * 4 + e;
+        const float dot = red[reg * 64 + lane] + red[(16 + reg) * 64 + lane] + red[(32 + reg) * 64 + lane] +
+                          red[(48 + reg) * 64 + lane];
+        const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h; // shift = offset inside the group of 32
+        const int lo = 32 * m_lane + m;                    // column m_lane: base offset 32 n
+        const int dist = (64 * keff - (int)dot) >> 1;
+        const unsigned cand = ((unsigned)dist << 12) | (unsigned)lo;
+        if (t0 + lo <= n - keff && cand < key) key = cand;
+    }
+#pragma unroll
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)key, s2);
+        key = o < key ? o : key;
+    }
+    __syncthreads();
+    unsigned *kr = reinterpret_cast<unsigned *>(smem_raw);
+    if (lane == 0) kr[wave] = key;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) key = kr[w] < key ? kr[w] : key;
+        if (key != 0xffffffffu) {
+            const unsigned long long full = ((unsigned long long)(key >> 12) << 32) | (unsigned)(t0 + (int)(key & 0xfff));
+            atomicMin(reinterpret_cast<unsigned long long *>(a.best) + clip, full);
+        }
+    }
+}
+
+static int shift_w32(int k)
+{
+    int w = (1024 + k + 31 + 31) / 32 + 1;
+    return w | 1;
+}
+
+size_t hamming_shift_lds_bytes(int k)
+{
+    const size_t win = (size_t)2 * 32 * shift_w32(k) * 16, qa = (size_t)2 * (k + 62) * 16;
+    return std::max(win + qa, (size_t)16 * 1024);
+}
+
+// one query of k hashprints at d_q against the whole index: best[clip] (preset to ~0) gets (dist << 32) | offset
+void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_clips, int n_off_max, const uint64_t *d_q,
+                          int k, uint64_t *d_best, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    SearchShiftArgs a;
+    a.db = d_db;
+    a.db_off = d_db_off;
+    a.n_clips = n_clips;
+    a.q = d_q;
+    a.k = k;
+    a.best = d_best;
+    a.chunks = (n_off_max + 1023) / 1024;
+    a.w32 = shift_w32(k);
+    hipLaunchKernelGGL(hamming_shift_kernel, dim3((unsigned)a.chunks * (unsigned)n_clips), dim3(256),
+                       hamming_shift_lds_bytes(k), s, a);
 }
 
 size_t hamming_mfma_lds_bytes(int kt)

@@ -110,6 +110,10 @@ void launch_hamming_scan(const SearchArgs &a, hipStream_t s);
 int hamming_mfma_kt_pad(int k_max);            // rows of the expanded-query image per group of 32
 size_t hamming_mfma_lds_bytes(int k_max);      // dynamic LDS of the scan; > 160 KB: use launch_hamming_scan
 void launch_expand_queries(const uint64_t *d_q, const int64_t *d_q_off, int n_q, int kt_pad, void *d_qa, hipStream_t s);
+// one query against the whole index with the tile rows = 32 shifts of the query (few queries: no padded rows)
+size_t hamming_shift_lds_bytes(int k);
+void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_clips, int n_off_max, const uint64_t *d_q,
+                          int k, uint64_t *d_best, hipStream_t s);
 // nearest windows (AnnStorage semantics with exact neighbours): rows = windows of `win` hashprints
 void launch_expand_windows(const uint64_t *d_q, const int64_t *d_w_start, int n_win, int win, int kt_pad, void *d_qa,
                            hipStream_t s);
@@ -120,6 +124,10 @@ void launch_knn_windows(const uint64_t *d_db, const int64_t *d_db_off, int n_cli
 void launch_hamming_mfma(const SearchArgs &a, const void *d_qa, int kt_pad, const int *d_gk, int n_off_max, hipStream_t s);
 void launch_topk(const uint64_t *d_best, int n_q, int n_clips, int k, uint32_t clip_base, void *d_out,
                  hipStream_t s);
+// the same result in two steps (64 slices of the clips per query, then a merge): large indexes, few queries
+size_t topk_scratch_bytes(int n_q, int k);
+void launch_topk_two_step(const uint64_t *d_best, int n_q, int n_clips, int k, uint32_t clip_base, void *d_scratch,
+                          void *d_out, hipStream_t s);
 
 // fail-loud launch check
 const char *last_launch_error();

@@ -172,14 +172,15 @@ def _ragged(rng, lens):
     return (np.concatenate(hp) if hp else np.zeros(0, np.uint64)), off
 
 
-@pytest.fixture(params=["mfma", "popcount"])
+@pytest.fixture(params=["mfma", "shift", "popcount"])
 def scan_path(request):
-    """both scan kernels: the fp4 matrix-core contraction (default) and the xor/popcount kernel"""
+    """the three scan kernels: the fp4 matrix-core contraction over groups of 32 queries (default), its
+    one-query variant with shifted rows (default below 8 queries) and the xor/popcount kernel"""
     import os
-    os.environ["HPFW_SEARCH_POPC" if request.param == "popcount" else "HPFW_SEARCH_MFMA"] = "1"
+    var = {"mfma": "HPFW_SEARCH_MFMA", "shift": "HPFW_SEARCH_SHIFT", "popcount": "HPFW_SEARCH_POPC"}[request.param]
+    os.environ[var] = "1"
     yield request.param
-    os.environ.pop("HPFW_SEARCH_POPC", None)
-    os.environ.pop("HPFW_SEARCH_MFMA", None)
+    os.environ.pop(var, None)
 
 
 def test_search_matches_oracle(gpu, oracle, scan_path):
@@ -258,6 +259,27 @@ def test_search_many_ragged_queries(gpu, oracle, scan_path):
     want = oracle.search_topk(db, db_off, q, q_off, 7, n_threads=4)
     assert np.array_equal(got, want)
     assert (got[0]["clip"] == 0xFFFFFFFF).all()          # the empty query matches nothing
+
+
+def test_search_large_index_few_queries(gpu, oracle):
+    """20 000 clips and 5 queries: the one-query scan kernel and the two-step top-k (64 slices per query,
+    then a merge), duplicates included -- the same hits as the oracle, in the same order"""
+    rng = np.random.default_rng(17)
+    n_clips, n = 20000, 70
+    db = rng.integers(0, 2 ** 64, size=(n_clips, n), dtype=np.uint64)
+    db[15000] = db[123]                                   # identical clips far apart: ties by clip id
+    db[19999] = db[123]
+    db_off = np.arange(n_clips + 1, dtype=np.int64) * n
+    qs = [db[123, 3:67].copy(), db[7777, 0:64] ^ np.uint64(5), db[19998, 6:70].copy(),
+          rng.integers(0, 2 ** 64, size=64, dtype=np.uint64), db[0, 1:41].copy()]
+    q_off = np.concatenate([[0], np.cumsum([x.size for x in qs])]).astype(np.int64)
+    q = np.concatenate(qs)
+    gpu.index_clear()
+    gpu.index_add(db.ravel(), db_off)
+    for k in (1, 10, 12):
+        got = gpu.search_topk(q, q_off, k)
+        assert np.array_equal(got, oracle.search_topk(db.ravel(), db_off, q, q_off, k, n_threads=4))
+    assert [int(x) for x in got[0]["clip"][:3]] == [123, 15000, 19999] and (got[0]["dist"][:3] == 0).all()
 
 
 def test_search_query_longer_than_lds_window(gpu, oracle):
