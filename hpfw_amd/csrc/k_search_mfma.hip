@@ -305,6 +305,19 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
     v4i *wB = reinterpret_cast<v4i *>(smem_raw);   // [2][32][w32]
     v4i *wA = wB + 2 * plane;                      // [2][steps + 31]: slot i = Q[i - 31]
     const int qlen = steps + 31;
+    // byte -> eight E2M1 nibbles by table: the expansion is this kernel's largest VALU item otherwise
+    // (every workgroup expands its own window for a single query)
+    uint32_t *lut = reinterpret_cast<uint32_t *>(wA + 2 * qlen);
+    lut[tid] = expand8((uint32_t)tid);
+    __syncthreads();
+    auto expand32_lut = [&](uint32_t w) {
+        v4i r;
+        r.x = (int)lut[w & 0xff];
+        r.y = (int)lut[(w >> 8) & 0xff];
+        r.z = (int)lut[(w >> 16) & 0xff];
+        r.w = (int)lut[w >> 24];
+        return r;
+    };
     // every load of the staging (query first, then up to 8 window slots per thread and round) is issued
     // before the first value is expanded, so their latencies overlap instead of adding up
     constexpr int kLq = 2, kLd = 8;
@@ -327,8 +340,8 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
             if (i < win) {
                 const bool in = t0 + i < n; // past the end of the clip: fp4 zeros, not expand(0) = all +1
                 const int slot = (i & 31) * a.w32 + (i >> 5);
-                wB[slot] = in ? expand32((uint32_t)w[e]) : v4i{0, 0, 0, 0};
-                wB[plane + slot] = in ? expand32((uint32_t)(w[e] >> 32)) : v4i{0, 0, 0, 0};
+                wB[slot] = in ? expand32_lut((uint32_t)w[e]) : v4i{0, 0, 0, 0};
+                wB[plane + slot] = in ? expand32_lut((uint32_t)(w[e] >> 32)) : v4i{0, 0, 0, 0};
             }
         }
     }
@@ -337,16 +350,16 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
         const int i = tid + e * 256, j = i - 31;
         if (i < qlen) {
             const bool in = j >= 0 && j < a.k;
-            wA[i] = in ? expand32((uint32_t)wq[e]) : v4i{0, 0, 0, 0};
-            wA[qlen + i] = in ? expand32((uint32_t)(wq[e] >> 32)) : v4i{0, 0, 0, 0};
+            wA[i] = in ? expand32_lut((uint32_t)wq[e]) : v4i{0, 0, 0, 0};
+            wA[qlen + i] = in ? expand32_lut((uint32_t)(wq[e] >> 32)) : v4i{0, 0, 0, 0};
         }
     }
     for (int i = tid + kLq * 256; i < qlen; i += 256) { // queries longer than 450 hashprints: the rest, plainly
         const int j = i - 31;
         const bool in = j >= 0 && j < a.k;
         const uint64_t w = in ? a.q[j] : 0ull;
-        wA[i] = in ? expand32((uint32_t)w) : v4i{0, 0, 0, 0};
-        wA[qlen + i] = in ? expand32((uint32_t)(w >> 32)) : v4i{0, 0, 0, 0};
+        wA[i] = in ? expand32_lut((uint32_t)w) : v4i{0, 0, 0, 0};
+        wA[qlen + i] = in ? expand32_lut((uint32_t)(w >> 32)) : v4i{0, 0, 0, 0};
     }
     __syncthreads();
     f32x16 acc = {0};
@@ -365,24 +378,26 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
             fb[e] = bp[(jj & 31) * a.w32 + (jj >> 5)];
         }
     };
-    if (j0 < j1) fetch(j0, ca, cb);
-    for (int j = j0; j < j1; j += kSt) {
-        if (j + kSt < j1) fetch(j + kSt, na, nb);
-        __builtin_amdgcn_sched_barrier(0);
+    auto mult = [&](int j, const v4i (&fa)[kSt], const v4i (&fb)[kSt]) {
 #pragma unroll
         for (int e = 0; e < kSt; ++e) {
             if (j + e < j1) {
-                const v8i av = {ca[e].x, ca[e].y, ca[e].z, ca[e].w, 0, 0, 0, 0};
-                const v8i bv = {cb[e].x, cb[e].y, cb[e].z, cb[e].w, 0, 0, 0, 0};
+                const v8i av = {fa[e].x, fa[e].y, fa[e].z, fa[e].w, 0, 0, 0, 0};
+                const v8i bv = {fb[e].x, fb[e].y, fb[e].z, fb[e].w, 0, 0, 0, 0};
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 4, 4, 0, one, 0, one);
             }
         }
+    };
+    if (j0 < j1) fetch(j0, ca, cb);
+    for (int j = j0; j < j1; j += 2 * kSt) { // two register sets in turn, no copies
+        if (j + kSt < j1) fetch(j + kSt, na, nb);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < kSt; ++e) {
-            ca[e] = na[e];
-            cb[e] = nb[e];
-        }
+        mult(j, ca, cb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 2 * kSt < j1) fetch(j + 2 * kSt, ca, cb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + kSt < j1) mult(j + kSt, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads(); // the windows are no longer read: their memory takes the partial sums
     float *red = reinterpret_cast<float *>(smem_raw); // [4 waves][16 regs][64 lanes]
@@ -428,8 +443,8 @@ static int shift_w32(int k)
 
 size_t hamming_shift_lds_bytes(int k)
 {
-    const size_t win = (size_t)2 * 32 * shift_w32(k) * 16, qa = (size_t)2 * (k + 62) * 16;
-    return std::max(win + qa, (size_t)16 * 1024);
+    const size_t win = (size_t)2 * 32 * shift_w32(k) * 16, qa = (size_t)2 * (k + 62) * 16, lut = 1024;
+    return std::max(win + qa + lut, (size_t)16 * 1024);
 }
 
 // one query of k hashprints at d_q against the whole index: best[clip] (preset to ~0) gets (dist << 32) | offset
