@@ -14,5 +14,5 @@ for c in fetch:FETCH_SIZE write:WRITE_SIZE; do
   echo "$d done"
 done
 # keep only what the summariser reads (the raw traces are large)
-find gpurun_out/prof -name "*_kernel_trace.csv" -size +20M -delete
+find gpurun_out/prof/fetch gpurun_out/prof/write -name "*_kernel_trace.csv" -delete
 ls -R gpurun_out/prof | head -40
