@@ -31,6 +31,7 @@ EXPORTS = (
     "hpfw_gpu_search_topk", "hpfw_gpu_merge_topk", "hpfw_gpu_timer_start", "hpfw_gpu_timer_stop",
     "hpfw_gpu_index_get", "hpfw_gpu_extract_db_host", "hpfw_gpu_stage_spectrogram",
     "hpfw_gpu_search_votes", "hpfw_gpu_knn_windows", "hpfw_gpu_supported_length",
+    "hpfw_gpu_mel_frames", "hpfw_gpu_mel_spectrogram_pcm16", "hpfw_gpu_mel_spectrogram_pcm16_host",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_save", "par_collector_load",
@@ -102,6 +103,10 @@ def lib():
     L.hpfw_gpu_timer_start.argtypes = [vp, vp]
     L.hpfw_gpu_timer_stop.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_float)]
     L.hpfw_gpu_stage_spectrogram.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_mel_frames.argtypes = [i64]
+    L.hpfw_gpu_mel_frames.restype = i64
+    L.hpfw_gpu_mel_spectrogram_pcm16.argtypes = [vp, vp, i64, i64, vp, vp, vp]
+    L.hpfw_gpu_mel_spectrogram_pcm16_host.argtypes = [vp, vp, i64, i64, vp, vp]
     L.hpfw_gpu_supported_length.argtypes = [i64]
     L.hpfw_gpu_supported_length.restype = i64
     L.hpfw_gpu_search_votes.argtypes = [vp, vp, vp, i64, vp]
@@ -204,6 +209,18 @@ class Gpu:
 
     def stage_spectrogram_dev(self, d_pcm, n_samples, n_clips, d_db, stream=0):
         check(lib().hpfw_gpu_stage_spectrogram(self._h, d_pcm, n_samples, n_clips, d_db, stream))
+
+    # ---- Mel front-end ---------------------------------------------------------------------
+    def mel_spectrogram(self, pcm):
+        """pcm int16 [n_clips][n] (host) -> list of dB-mel spectrograms [33][kept columns] (mel.h:34-104)"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        nf = int(lib().hpfw_gpu_mel_frames(pcm.shape[1]))
+        out = np.zeros((pcm.shape[0], 33, nf), np.float32)
+        cols = np.zeros(pcm.shape[0], np.int32)
+        check(lib().hpfw_gpu_mel_spectrogram_pcm16_host(self._h, _hp(pcm), pcm.shape[1], pcm.shape[0], _hp(out), _hp(cols)))
+        return [np.ascontiguousarray(out[i, :, :cols[i]]) for i in range(pcm.shape[0])]
 
     # ---- filter learning ------------------------------------------------------------------
     def cov_reset(self):

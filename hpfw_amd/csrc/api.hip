@@ -111,6 +111,14 @@ struct hpfw_gpu {
     void *d_cqwork = nullptr;  // chirp-z bands too long for the LDS (k_cq_big.hip)
     void *d_topk_scratch = nullptr;
     size_t topk_scratch_cap = 0;
+    // Mel front-end: tables (owned by mel_owned), workspaces
+    bool mel_ready = false;
+    hpfw::HostPlan mel_plan;
+    hpfw::RowsArgs mel_rows;
+    const float *d_mel_win = nullptr, *d_mel_cpack = nullptr;
+    std::vector<void *> mel_owned;
+    void *d_mel_work = nullptr, *d_mel_small = nullptr;
+    size_t mel_work_cap = 0, mel_small_cap = 0;
     size_t cqwork_cap = 0;
     size_t cov_ws_cap = 0;
     void *d_qa = nullptr;   // queries expanded to fp4 for the matrix-core scan
@@ -397,6 +405,9 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->d_cov_ws) (void)hipFree(h->d_cov_ws);
     if (h->d_cqwork) (void)hipFree(h->d_cqwork);
     if (h->d_topk_scratch) (void)hipFree(h->d_topk_scratch);
+    for (void *q : h->mel_owned) (void)hipFree(q);
+    if (h->d_mel_work) (void)hipFree(h->d_mel_work);
+    if (h->d_mel_small) (void)hipFree(h->d_mel_small);
     if (h->d_qa) (void)hipFree(h->d_qa);
     if (h->d_gk) (void)hipFree(h->d_gk);
     if (h->d_clipmax) (void)hipFree(h->d_clipmax);
@@ -639,6 +650,94 @@ int hpfw_gpu_extract_db_host(hpfw_gpu *h, const float *s_colmajor, int32_t rows,
     if (d_s) (void)hipFree(d_s);
     if (d_p) (void)hipFree(d_p);
     if (d_h) (void)hipFree(d_h);
+    return rc;
+}
+
+// ---- Mel front-end (f3): MelSpectrogram<>::spectrogram (mel.h:34-104) ---------------------------
+int64_t hpfw_gpu_mel_frames(int64_t n_samples) { return hpfw::mel_frames(n_samples); }
+
+static int mel_prepare(hpfw_gpu *h)
+{
+    if (h->mel_ready) return 0;
+    std::string why;
+    if (!hpfw::build_frame_transform(hpfw::kMelFrame, h->mel_plan, why)) return fail(HPFW_E_UNSUPPORTED, why.c_str());
+    const hpfw::HostPlan &p = h->mel_plan;
+    hpfw::RowsArgs &ra = h->mel_rows;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.n1 = 2;
+    ra.n2 = p.n2;
+    ra.h = p.h;
+    ra.hpad = 2208;
+    ra.pair_stride = 1;
+    ra.groups.n = (int)p.groups.size();
+    for (size_t g = 0; g < p.groups.size(); ++g) {
+        ra.groups.r1[g] = p.groups[g].first;
+        ra.groups.r2[g] = p.groups[g].second;
+        ra.groups.tw_off[g] = p.rows_gtw_off[g];
+    }
+    int rc;
+    if ((rc = upload(p.rows_gtw, reinterpret_cast<const hpfw::HostCf **>(&ra.gtw), h->mel_owned))) return rc;
+    if ((rc = upload(p.tw_big, reinterpret_cast<const hpfw::HostCf **>(&ra.tw_big), h->mel_owned))) return rc;
+    if ((rc = upload(p.pos_n2, &ra.pos_n2, h->mel_owned))) return rc;
+    if ((rc = upload(p.kb_last, &ra.kb_last, h->mel_owned))) return rc;
+    std::vector<float> win, cpack;
+    hpfw::mel_tables(win, cpack);
+    if ((rc = upload(win, &h->d_mel_win, h->mel_owned))) return rc;
+    if ((rc = upload(cpack, &h->d_mel_cpack, h->mel_owned))) return rc;
+    h->mel_ready = true;
+    return 0;
+}
+
+int hpfw_gpu_mel_spectrogram_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips, float *d_out,
+                                   int32_t *d_cols, void *stream)
+{
+    if (!h || !d_pcm || !d_out || !d_cols || n_clips < 0 || n_samples < 1) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = mel_prepare(h);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nf = hpfw::mel_frames(n_samples), n_blk = (int)((n_samples + hpfw::kMelHop - 1) / hpfw::kMelHop);
+    // clips per pass: the split spectra take 2 * 2208 floats per frame
+    const int64_t per_clip = (int64_t)hpfw::mel_work_bytes(n_samples, 1);
+    const int nbmax = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(n_clips, 1), ((int64_t)8 << 30) / per_clip));
+    if ((rc = ensure(&h->d_mel_work, &h->mel_work_cap, hpfw::mel_work_bytes(n_samples, nbmax)))) return rc;
+    if ((rc = ensure(&h->d_mel_small, &h->mel_small_cap, (size_t)nbmax * ((size_t)n_blk * 8 + (size_t)nf * 4 + 8)))) return rc;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
+        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
+        int64_t *blk = (int64_t *)h->d_mel_small;
+        int *pos = (int *)(blk + (size_t)nbmax * n_blk);
+        float *pmax = (float *)(pos + (size_t)nbmax * nf);
+        hpfw::launch_mel(h->mel_rows, h->d_mel_win, h->d_mel_cpack, d_pcm + c0 * n_samples, n_samples, nb, blk, pos,
+                         d_cols + c0, pmax, (float *)h->d_mel_work, d_out + c0 * hpfw::kMelBands * nf, s);
+        if ((rc = check_launch("mel"))) return rc;
+    }
+    return 0;
+}
+
+int hpfw_gpu_mel_spectrogram_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples, int64_t n_clips, float *out,
+                                        int32_t *cols)
+{
+    if (!h || !pcm || !out || !cols || n_clips < 0 || n_samples < 1) return fail(HPFW_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_clips == 0) return 0;
+    const size_t per = (size_t)hpfw::kMelBands * hpfw::mel_frames(n_samples);
+    int16_t *d_pcm = nullptr;
+    float *d_out = nullptr;
+    int32_t *d_cols = nullptr;
+    int rc = 0;
+    if (hipMalloc((void **)&d_pcm, (size_t)n_clips * n_samples * 2) != hipSuccess ||
+        hipMalloc((void **)&d_out, (size_t)n_clips * per * 4) != hipSuccess || hipMalloc((void **)&d_cols, (size_t)n_clips * 4) != hipSuccess)
+        rc = fail(HPFW_E_NOMEM, "hipMalloc failed");
+    if (!rc && (hipMemcpy(d_pcm, pcm, (size_t)n_clips * n_samples * 2, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemset(d_out, 0, (size_t)n_clips * per * 4) != hipSuccess))
+        rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (!rc) rc = hpfw_gpu_mel_spectrogram_pcm16(h, d_pcm, n_samples, n_clips, d_out, d_cols, nullptr);
+    if (!rc && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_out, (size_t)n_clips * per * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(cols, d_cols, (size_t)n_clips * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(HPFW_E_HIP, "kernel execution or D2H copy failed");
+    if (d_pcm) (void)hipFree(d_pcm);
+    if (d_out) (void)hipFree(d_out);
+    if (d_cols) (void)hipFree(d_cols);
     return rc;
 }
 

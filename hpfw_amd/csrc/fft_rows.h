@@ -306,9 +306,18 @@ using Groups6300 = StaticGroups<7, 3, 5, 3, 5, 4>;
 // Output: rows 2 a0 .. 2 a0 + 3 of the planar matrix Y' [2 n1][hpad] (row 2a = Re, 2a + 1 = Im of
 // residue a) -- the B operand of the column-DFT MFMA kernel; ya / yb point at the Re rows of a0 and
 // a0 + 1 (yb may be null).
-template <class Groups, class Lds>
-HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x2 *__restrict__ pairs, int a0,
-                           float *__restrict__ ya, float *__restrict__ yb)
+// load(t) -> the two real samples of time step t as a cf (real part: first sequence): PairLoad for the
+// forward transform's residue pairs; the STFT of the Mel front-end passes windowed frames (k_mel.hip).
+struct PairLoad {
+    const i16x2 *pairs;
+    int stride;
+    HPFW_DEVICE_MEMBER i16x2 raw(int t) const { return pairs[(int64_t)t * stride]; }
+    HPFW_DEVICE_STATIC cf conv(i16x2 p, int) { return {(float)p.x / 32768.0f, (float)p.y / 32768.0f}; }
+};
+
+template <class Groups, class Lds, class Load>
+HPFW_DEVICE void rows_body_from(Lds &lds, const RowsArgs &a, int nthreads, const Load &load, int a0,
+                                float *__restrict__ ya, float *__restrict__ yb)
 {
     const int n2 = a.n2;
     HPFW_FOR_THREADS(tid, nthreads)
@@ -316,16 +325,16 @@ HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x
         // loads in batches of kLd so that their latencies overlap
         constexpr int kLd = 9;
         for (int t0 = tid; t0 < n2; t0 += kLd * nthreads) {
-            i16x2 p[kLd];
+            decltype(load.raw(0)) p[kLd];
 #pragma unroll
             for (int e = 0; e < kLd; ++e) {
                 const int t = t0 + e * nthreads;
-                p[e] = pairs[(int64_t)(t < n2 ? t : 0) * a.pair_stride];
+                p[e] = load.raw(t < n2 ? t : 0);
             }
 #pragma unroll
             for (int e = 0; e < kLd; ++e) {
                 const int t = t0 + e * nthreads;
-                if (t < n2) lds[t] = {(float)p[e].x / 32768.0f, (float)p[e].y / 32768.0f};
+                if (t < n2) lds[t] = load.conv(p[e], t);
             }
         }
     }
@@ -372,6 +381,13 @@ HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x
             }
         }
     }
+}
+
+template <class Groups, class Lds>
+HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x2 *__restrict__ pairs, int a0,
+                           float *__restrict__ ya, float *__restrict__ yb)
+{
+    rows_body_from<Groups>(lds, a, nthreads, PairLoad{pairs, a.pair_stride}, a0, ya, yb);
 }
 
 } // namespace hpfw

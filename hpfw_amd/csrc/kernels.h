@@ -94,6 +94,14 @@ int top_eigenvectors(const float *cov, int n, int m, float *out, double *evals);
 // host helper: [kp][lane][2] operand image of the filters for v_mfma_f32_32x32x2_f32
 void pack_filters_for_mfma(const float *filters_colmajor, float *fpack /* 64*2420 */);
 
+// ---- Mel front-end (f3, k_mel.hip) ----------------------------------------------------------
+constexpr int kMelFrame = 4410, kMelHop = 441, kMelBins = 2206, kMelBands = 33;
+int mel_frames(int64_t n_samples);
+size_t mel_work_bytes(int64_t n_samples, int n_clips);
+// d_out [n_clips][33][frames] (kept columns at the front of every row), d_count [n_clips] their number
+void launch_mel(const RowsArgs &rows, const float *d_win, const float *d_cpack, const int16_t *d_pcm, int64_t n, int n_clips,
+                int64_t *d_blk, int *d_pos, int *d_count, float *d_pmax, float *d_work, float *d_out, hipStream_t s);
+
 // ---- search ------------------------------------------------------------------------------
 struct SearchArgs {
     const uint64_t *db;      // concatenated hashprints

@@ -436,6 +436,99 @@ uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 1469598103934665603u
 }
 } // namespace
 
+namespace hpfw {
+
+// The row transform alone, for frames of n2 real samples taken in pairs (the STFT of the Mel front-end):
+// the same pass order, fused groups, butterfly tables and output positions as the forward transform's
+// rows; the table that multiplies the split spectra holds ones (two rows: the pair's two frames).
+bool build_frame_transform(int n2, HostPlan &p, std::string &why)
+{
+    p = HostPlan();
+    std::vector<int> desc;
+    if (n2 < 2 || n2 > kN2Max || !make_radix_list(n2, desc)) {
+        why = "frame length not supported";
+        return false;
+    }
+    for (size_t lo = 0, hi = desc.size(); lo < hi;) {
+        p.radix.push_back(desc[lo++]);
+        if (lo < hi) p.radix.push_back(desc[--hi]);
+    }
+    p.n = n2;
+    p.n1 = 2;
+    p.n2 = n2;
+    p.h = n2 / 2 + 1;
+    p.tw_n2 = twiddle_table(n2);
+    for (size_t i = 0; i < p.radix.size();) {
+        if (i + 1 < p.radix.size() && p.radix[i] * p.radix[i + 1] <= 36) {
+            p.groups.push_back({p.radix[i], p.radix[i + 1]});
+            i += 2;
+        } else {
+            p.groups.push_back({p.radix[i], 1});
+            i += 1;
+        }
+    }
+    int64_t len = n2;
+    for (const auto &g : p.groups) {
+        p.rows_gtw_off.push_back((int)p.rows_gtw.size());
+        append_group_twiddles(p.tw_n2, n2, len, g.first, g.second, p.rows_gtw);
+        len /= g.first * g.second;
+    }
+    p.tw_big.assign((size_t)2 * p.h, HostCf{1.0f, 0.0f});
+    p.pos_n2.resize((size_t)n2);
+    for (int64_t k = 0; k < n2; ++k) p.pos_n2[(size_t)k] = (int)digit_pos(k, n2, p.radix);
+    { // the last group's output map, as in build_plan (the compile-time group sequences use it)
+        const int r1 = p.groups.back().first, r2 = p.groups.back().second, glen = r1 * r2;
+        const int nb = n2 / glen;
+        p.kb_last.assign((size_t)nb, -1);
+        for (int k = 0; k < nb; ++k) p.kb_last[(size_t)(p.pos_n2[(size_t)k] / glen)] = k;
+        for (int b = 0; b < nb; ++b)
+            for (int s = 0; s < r1; ++s)
+                for (int s2 = 0; s2 < r2; ++s2)
+                    if (p.kb_last[(size_t)b] < 0 ||
+                        p.pos_n2[(size_t)(p.kb_last[(size_t)b] + nb * (s + r1 * s2))] != glen * b + s * r2 + s2) {
+                        why = "internal: last-group output map";
+                        return false;
+                    }
+    }
+    return true;
+}
+
+// Tables of the Mel front-end: essentia Windowing "hann" of 4410 points normalised to
+// area 2, and MelBands(2206 -> 33; 0..22050 Hz, htkMel, weighting "warping", normalize "unit_sum") as the
+// MFMA operand image cpack [2208 bins][64 rows] (rows >= 33 and bins >= 2206 are zero).
+void mel_tables(std::vector<float> &window, std::vector<float> &cpack)
+{
+    const int n = 4410, nbins = 2206, nbands = 33;
+    window.resize((size_t)n);
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) sum += 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / (double)(n - 1));
+    for (int i = 0; i < n; ++i)
+        window[(size_t)i] = (float)((0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / (double)(n - 1))) * (2.0 / sum));
+    auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+    auto mel2hz = [](double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); };
+    std::vector<double> fb((size_t)nbands + 2);
+    const double lo = hz2mel(0.0), hi = hz2mel(22050.0), inc = (hi - lo) / (nbands + 1);
+    for (int i = 0; i < nbands + 2; ++i) fb[(size_t)i] = mel2hz(lo + inc * i);
+    const double fscale = (44100.0 / 2.0) / (double)(nbins - 1);
+    cpack.assign((size_t)2208 * 64, 0.0f);
+    std::vector<double> c((size_t)nbins);
+    for (int i = 0; i < nbands; ++i) {
+        const double w0 = hz2mel(fb[(size_t)i]), w1 = hz2mel(fb[(size_t)i + 1]), w2 = hz2mel(fb[(size_t)i + 2]);
+        const int jb = (int)(fb[(size_t)i] / fscale + 0.5), je = (int)(fb[(size_t)i + 2] / fscale + 0.5);
+        double weight = 0.0;
+        std::fill(c.begin(), c.end(), 0.0);
+        for (int j = jb; j <= je && j < nbins; ++j) {
+            const double bf = j * fscale;
+            if (bf >= fb[(size_t)i] && bf < fb[(size_t)i + 1]) c[(size_t)j] = (hz2mel(bf) - w0) / (w1 - w0);
+            else if (bf >= fb[(size_t)i + 1] && bf < fb[(size_t)i + 2]) c[(size_t)j] = (w2 - hz2mel(bf)) / (w2 - w1);
+            weight += c[(size_t)j];
+        }
+        for (int j = 0; j < nbins; ++j) cpack[(size_t)j * 64 + i] = (float)(weight > 0.0 ? c[(size_t)j] / weight : 0.0);
+    }
+}
+
+} // namespace hpfw
+
 // the smallest supported clip length >= n_samples (include/hpfw_gpu.h), or -1
 extern "C" int64_t hpfw_gpu_supported_length(int64_t n_samples)
 {

@@ -49,6 +49,12 @@ struct HostPlan {
 // geometry_only: stop after the sizes (n1, n2, M, C, bins consumed) are known, build no table
 bool build_plan(int64_t n_samples, HostPlan &out, std::string &why, bool geometry_only = false);
 
+// the row transform alone for frames of n2 samples (STFT of the Mel front-end): radix, groups, rows_gtw,
+// pos_n2 of `out`, and tw_big = two rows of ones
+bool build_frame_transform(int n2, HostPlan &out, std::string &why);
+// window [4410] and filterbank operand image [2208][64] of the Mel front-end
+void mel_tables(std::vector<float> &window, std::vector<float> &cpack);
+
 // e^{-2 pi i m / n} with exact octant symmetry, evaluated in double (S2)
 void twiddle_d(int64_t m, int64_t n, double &re, double &im);
 // mixed-radix digit reversal of the DIF pass list

@@ -14,6 +14,7 @@
 #include <cstdint>
 #define HPFW_DEVICE static inline
 #define HPFW_DEVICE_STATIC static inline
+#define HPFW_DEVICE_MEMBER inline
 #define HPFW_FOR_THREADS(tid, nt) for (int tid = 0; tid < (nt); ++tid)
 #define HPFW_BARRIER() ((void)0)
 // registers a thread keeps across a barrier: one array per emulated thread
@@ -24,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #define HPFW_DEVICE __device__ __forceinline__
 #define HPFW_DEVICE_STATIC static __device__ __forceinline__
+#define HPFW_DEVICE_MEMBER __device__ __forceinline__
 #define HPFW_FOR_THREADS(tid, nt) for (int tid = threadIdx.x, hpfw_once_ = 1; hpfw_once_; hpfw_once_ = 0)
 #define HPFW_BARRIER() __syncthreads()
 #define HPFW_CARRY(type, name, count, nt) type name##_store[count]

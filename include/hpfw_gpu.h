@@ -123,6 +123,17 @@ int hpfw_gpu_stage_pack(hpfw_gpu *h, const float *d_proj, int64_t n_clips, int64
 int hpfw_gpu_stage_spectrogram(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
                                int64_t n_clips, float *d_db, void *stream);
 
+/* ---- Mel front-end: spectrum::MelSpectrogram<44100, 33, 4410, 441>::spectrogram (mel.h:34-104) ----
+ * essentia FrameCutter(4410, 441) -> Windowing(hann) -> Spectrum -> MelBands(33) per frame, silent frames
+ * dropped (mel.h:94-96), power_to_db over the kept columns (mel.h:103).  Any clip length.
+ * hpfw_gpu_mel_frames: frames cut from n_samples (silent ones included) = the row stride of the output.
+ * d_out [n_clips][33][frames]: the kept columns at the front of every row; d_cols [n_clips] their number. */
+int64_t hpfw_gpu_mel_frames(int64_t n_samples);
+int hpfw_gpu_mel_spectrogram_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
+                                   int64_t n_clips, float *d_out, int32_t *d_cols, void *stream);
+int hpfw_gpu_mel_spectrogram_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples,
+                                        int64_t n_clips, float *out, int32_t *cols);
+
 /* ---- filter learning: ParallelCollector::preprocess + calc_filters ------------------------
  * (parallel_collector.h:82-112, hashprint_handle.h:96-112).  The handle owns accum_cov
  * (2420 x 2420, parallel_collector.h:76): per clip, the covariance of its context frames (centred

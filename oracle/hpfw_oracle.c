@@ -889,6 +889,151 @@ void hpfw_oracle_search_topk(const uint64_t *db, const int64_t *db_off, int64_t 
     for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* f3: the Mel front-end (mel.h:34-104), DESIGN.md appendix B and S11-S15                        */
+/* ------------------------------------------------------------------------------------------ */
+struct hpfw_oracle_mel {
+    float window[HPFW_O_MEL_FRAME];
+    float coeff[HPFW_O_MEL_BANDS * HPFW_O_MEL_BINS];
+    int32_t radix[HPFW_O_MAXRADIX];
+    int nr;
+    cf *tw;
+    int32_t *pos; /* digit-reversed position of output k */
+};
+
+static double hz2mel_htk(double f) { return 2595.0 * log10(1.0 + f / 700.0); }
+static double mel2hz_htk(double m) { return 700.0 * (pow(10.0, m / 2595.0) - 1.0); }
+
+hpfw_oracle_mel *hpfw_oracle_mel_create(void)
+{
+    hpfw_oracle_mel *m = (hpfw_oracle_mel *)calloc(1, sizeof(hpfw_oracle_mel));
+    const int n = HPFW_O_MEL_FRAME;
+    /* essentia Windowing: hann 0.5 - 0.5 cos(2 pi i / (size - 1)), normalized: area 1, times 2 */
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) sum += 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)(n - 1));
+    for (int i = 0; i < n; ++i)
+        m->window[i] = (float)((0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)(n - 1))) * (2.0 / sum));
+    m->nr = make_rows_radix_list(n, m->radix);
+    m->tw = make_twiddle_table(n);
+    m->pos = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    for (int k = 0; k < n; ++k) m->pos[k] = (int32_t)hpfw_oracle_digit_pos(k, n, m->radix, m->nr);
+    /* essentia MelBands(inputSize 2206, numberBands 33; defaults: 0 .. 22050 Hz, htkMel, weighting
+     * "warping", normalize "unit_sum", type "power") -> TriangularBands on 35 mel-spaced frequencies */
+    double fb[HPFW_O_MEL_BANDS + 2];
+    const double lo = hz2mel_htk(0.0), hi = hz2mel_htk(22050.0), inc = (hi - lo) / (HPFW_O_MEL_BANDS + 1);
+    for (int i = 0; i < HPFW_O_MEL_BANDS + 2; ++i) fb[i] = mel2hz_htk(lo + inc * i);
+    const double fscale = (44100.0 / 2.0) / (double)(HPFW_O_MEL_BINS - 1);
+    for (int i = 0; i < HPFW_O_MEL_BANDS; ++i) {
+        const double w0 = hz2mel_htk(fb[i]), w1 = hz2mel_htk(fb[i + 1]), w2 = hz2mel_htk(fb[i + 2]);
+        const int jb = (int)(fb[i] / fscale + 0.5), je = (int)(fb[i + 2] / fscale + 0.5);
+        double c[HPFW_O_MEL_BINS];
+        double weight = 0.0;
+        for (int j = 0; j < HPFW_O_MEL_BINS; ++j) c[j] = 0.0;
+        for (int j = jb; j <= je && j < HPFW_O_MEL_BINS; ++j) {
+            const double bf = j * fscale;
+            if (bf >= fb[i] && bf < fb[i + 1]) c[j] = (hz2mel_htk(bf) - w0) / (w1 - w0);
+            else if (bf >= fb[i + 1] && bf < fb[i + 2]) c[j] = (w2 - hz2mel_htk(bf)) / (w2 - w1);
+            weight += c[j];
+        }
+        for (int j = 0; j < HPFW_O_MEL_BINS; ++j)
+            m->coeff[i * HPFW_O_MEL_BINS + j] = (float)(weight > 0.0 ? c[j] / weight : 0.0);
+    }
+    return m;
+}
+
+void hpfw_oracle_mel_destroy(hpfw_oracle_mel *m)
+{
+    if (!m) return;
+    free(m->tw);
+    free(m->pos);
+    free(m);
+}
+
+void hpfw_oracle_mel_tables(const hpfw_oracle_mel *m, float *window, float *coeff)
+{
+    memcpy(window, m->window, sizeof(m->window));
+    memcpy(coeff, m->coeff, sizeof(m->coeff));
+}
+
+/* essentia FrameCutter(frameSize 4410, hopSize 441, startFromZero false): frame f starts at sample
+ * 441 f - 2205 (zeros outside the signal); frames are cut while the start lies inside the signal */
+int64_t hpfw_oracle_mel_frames(int64_t n)
+{
+    return n <= 0 ? 0 : (n + HPFW_O_MEL_FRAME / 2 + HPFW_O_MEL_HOP - 1) / HPFW_O_MEL_HOP;
+}
+
+void hpfw_oracle_mel_power(const hpfw_oracle_mel *m, const int16_t *pcm, int64_t n, float *power, uint8_t *keep)
+{
+    const int fs = HPFW_O_MEL_FRAME, half = fs / 2, nb = HPFW_O_MEL_BINS;
+    const int64_t nfr = hpfw_oracle_mel_frames(n);
+    cf *z = (cf *)malloc(sizeof(cf) * (size_t)fs);
+    float *pw = (float *)malloc(sizeof(float) * (size_t)(2 * nb));
+    for (int64_t f0 = 0; f0 < nfr; f0 += 2) { /* frames in pairs through one complex transform (S6) */
+        for (int w = 0; w < 2; ++w) {
+            const int64_t f = f0 + w, start = f * HPFW_O_MEL_HOP - half;
+            int64_t e = 0; /* essentia isSilent: instantPower < 1e-10  <=>  sum pcm^2 <= 473 (exact in integers) */
+            if (f < nfr)
+                for (int i = 0; i < fs; ++i) {
+                    const int64_t sidx = start + i;
+                    if (sidx >= 0 && sidx < n) e += (int64_t)pcm[sidx] * pcm[sidx];
+                }
+            if (f < nfr) keep[f] = e > 473;
+            for (int t = 0; t < fs; ++t) { /* zero-phase: transform input t is windowed sample (t + 2205) mod 4410 */
+                const int i = t < fs - half ? t + half : t - (fs - half);
+                const int64_t sidx = start + i;
+                float v = 0.0f;
+                if (f < nfr && sidx >= 0 && sidx < n) v = ((float)pcm[sidx] / 32768.0f) * m->window[i];
+                if (w == 0) z[t].r = v; else z[t].i = v;
+            }
+        }
+        fft_dif(z, fs, m->radix, m->nr, m->tw);
+        for (int k = 0; k < nb; ++k) {
+            const cf zk = z[m->pos[k]], zm = z[m->pos[k == 0 ? 0 : fs - k]];
+            const cf va = {0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
+            const cf vb = {0.5f * (zk.i + zm.i), 0.5f * (zm.r - zk.r)};
+            const float ma = sqrtf(fmaf(va.r, va.r, va.i * va.i)), mb = sqrtf(fmaf(vb.r, vb.r, vb.i * vb.i));
+            pw[k] = ma * ma;          /* essentia Spectrum gives the magnitude, MelBands (type power) squares it */
+            pw[nb + k] = mb * mb;
+        }
+        for (int w = 0; w < 2 && f0 + w < nfr; ++w)
+            for (int i = 0; i < HPFW_O_MEL_BANDS; ++i) {
+                float acc = 0.0f; /* fma chain over the bins, ascending (the MFMA order) */
+                for (int j = 0; j < nb; ++j) acc = fmaf(m->coeff[i * nb + j], pw[w * nb + j], acc);
+                power[(int64_t)i * nfr + f0 + w] = acc;
+            }
+    }
+    free(z);
+    free(pw);
+}
+
+int64_t hpfw_oracle_mel_spectrogram(const hpfw_oracle_mel *m, const int16_t *pcm, int64_t n, float *out)
+{
+    const int64_t nfr = hpfw_oracle_mel_frames(n);
+    float *power = (float *)malloc(sizeof(float) * (size_t)(HPFW_O_MEL_BANDS * (nfr > 0 ? nfr : 1)));
+    uint8_t *keep = (uint8_t *)malloc((size_t)(nfr > 0 ? nfr : 1));
+    hpfw_oracle_mel_power(m, pcm, n, power, keep);
+    int64_t c = 0;
+    for (int64_t f = 0; f < nfr; ++f)
+        if (keep[f]) {
+            for (int i = 0; i < HPFW_O_MEL_BANDS; ++i) out[(int64_t)i * nfr + c] = power[(int64_t)i * nfr + f];
+            ++c;
+        }
+    /* power_to_db (convert.h:7-16) over the kept columns */
+    float pmax = 0.0f;
+    for (int i = 0; i < HPFW_O_MEL_BANDS; ++i)
+        for (int64_t k = 0; k < c; ++k)
+            if (out[(int64_t)i * nfr + k] > pmax) pmax = out[(int64_t)i * nfr + k];
+    const float ref = db_term(pmax);
+    for (int i = 0; i < HPFW_O_MEL_BANDS; ++i)
+        for (int64_t k = 0; k < c; ++k) {
+            const float l = db_term(out[(int64_t)i * nfr + k]) - ref;
+            out[(int64_t)i * nfr + k] = l < -80.0f ? -80.0f : l;
+        }
+    free(power);
+    free(keep);
+    return c;
+}
+
 /* annoy_storage.h:41-63 with exact neighbours (see hpfw_oracle.h) */
 void hpfw_oracle_knn_windows(const uint64_t *db, const int64_t *db_off, int64_t n_clips, const uint64_t *q,
                              int64_t k, int win, int nn, uint64_t *keys)

@@ -89,6 +89,27 @@ typedef struct {
     uint32_t pad;
 } hpfw_oracle_hit;
 
+/* f3: MelSpectrogram<44100, 33, 4410, 441>::spectrogram (include/hpfw/spectrum/mel.h:34-104): essentia
+ * FrameCutter(4410, 441) -> Windowing(hann) -> Spectrum -> MelBands(33) per frame, silent frames
+ * dropped (mel.h:94-96), power_to_db over the kept columns (mel.h:103).  essentia is not vendored: the
+ * algorithms are restated in DESIGN.md appendix B and, like the constant-Q, are PARITY UNPINNED.
+ * Tables: window [4410] (hann, normalised to area 2, before the zero-phase rotation), coeff [33][2206]. */
+#define HPFW_O_MEL_BANDS 33
+#define HPFW_O_MEL_FRAME 4410
+#define HPFW_O_MEL_HOP 441
+#define HPFW_O_MEL_BINS 2206
+typedef struct hpfw_oracle_mel hpfw_oracle_mel;
+hpfw_oracle_mel *hpfw_oracle_mel_create(void);
+void hpfw_oracle_mel_destroy(hpfw_oracle_mel *m);
+void hpfw_oracle_mel_tables(const hpfw_oracle_mel *m, float *window, float *coeff);
+int64_t hpfw_oracle_mel_frames(int64_t n_samples); /* frames cut from n samples, silent ones included */
+/* band powers before the dB conversion: power [33][n_frames] (row stride n_frames), all frames;
+ * keep [n_frames] = 1 for frames that are not silent */
+void hpfw_oracle_mel_power(const hpfw_oracle_mel *m, const int16_t *pcm, int64_t n, float *power, uint8_t *keep);
+/* the spectrogram: out [33][n_frames] (row stride n_frames) with the kept columns compacted to the front;
+ * returns their number */
+int64_t hpfw_oracle_mel_spectrogram(const hpfw_oracle_mel *m, const int16_t *pcm, int64_t n, float *out);
+
 /* AnnStorage::find (annoy_storage.h:41-63) with the approximate Annoy forest replaced by the exact
  * nearest neighbours.  Items are windows of `win` (64: the reference indexes 64 consecutive uint64
  * words per item, AnnoyIndex<..., Hamming, ...>(64), annoy_storage.h:23,32) consecutive hashprints;

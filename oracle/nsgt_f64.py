@@ -104,3 +104,55 @@ def covariance(s_db):
     x = frames(s_db)
     xc = x - x.mean(axis=1, keepdims=True)
     return xc @ xc.T / (x.shape[1] - 1)
+
+
+# ---- f3: the Mel front-end (mel.h:34-104) in float64, straight from the restated essentia algorithms ----
+MEL_BANDS, MEL_FRAME, MEL_HOP = 33, 4410, 441
+
+
+def mel_filterbank():
+    """essentia MelBands(inputSize 2206, numberBands 33; 0..22050 Hz, htkMel, weighting "warping",
+    normalize "unit_sum") -> [33][2206]"""
+    hz2mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)   # noqa: E731
+    mel2hz = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)  # noqa: E731
+    nb = MEL_FRAME // 2 + 1
+    fb = mel2hz(np.linspace(hz2mel(0.0), hz2mel(22050.0), MEL_BANDS + 2))
+    fscale = 22050.0 / (nb - 1)
+    bf = np.arange(nb) * fscale
+    out = np.zeros((MEL_BANDS, nb))
+    for i in range(MEL_BANDS):
+        jb, je = int(fb[i] / fscale + 0.5), min(int(fb[i + 2] / fscale + 0.5), nb - 1)
+        j = np.arange(jb, je + 1)
+        up = (bf[j] >= fb[i]) & (bf[j] < fb[i + 1])
+        dn = (bf[j] >= fb[i + 1]) & (bf[j] < fb[i + 2])
+        c = np.where(up, (hz2mel(bf[j]) - hz2mel(fb[i])) / (hz2mel(fb[i + 1]) - hz2mel(fb[i])), 0.0)
+        c = np.where(dn, (hz2mel(fb[i + 2]) - hz2mel(bf[j])) / (hz2mel(fb[i + 2]) - hz2mel(fb[i + 1])), c)
+        out[i, j] = c / c.sum()
+    return out
+
+
+def mel_power(pcm):
+    """band powers of every frame [33][n_frames] and the keep mask (frames that are not silent)"""
+    x = np.asarray(pcm, np.float64) / 32768.0
+    n = x.size
+    nfr = (n + MEL_FRAME // 2 + MEL_HOP - 1) // MEL_HOP
+    pad = np.concatenate([np.zeros(MEL_FRAME // 2), x, np.zeros(MEL_FRAME + MEL_HOP)])
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(MEL_FRAME) / (MEL_FRAME - 1))
+    win *= 2.0 / win.sum()
+    fbk = mel_filterbank()
+    power = np.zeros((MEL_BANDS, nfr))
+    keep = np.zeros(nfr, bool)
+    for f in range(nfr):
+        fr = pad[f * MEL_HOP: f * MEL_HOP + MEL_FRAME]
+        keep[f] = (fr * fr).sum() / MEL_FRAME >= 1e-10
+        spec = np.abs(np.fft.rfft(np.roll(fr * win, -(MEL_FRAME // 2))))   # zero-phase windowing, magnitude
+        power[:, f] = fbk @ (spec * spec)
+    return power, keep
+
+
+def power_to_db(p):
+    """convert.h:7-16 in float64"""
+    p = np.asarray(p, np.float64)
+    mx = max(1e-10, float(p.max())) if p.size else 1e-10
+    log_spec = 10.0 * np.log10(np.maximum(p, 1e-10)) - 10.0 * np.log10(mx)
+    return np.maximum(log_spec, log_spec.max() - 80.0) if p.size else log_spec

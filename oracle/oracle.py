@@ -62,6 +62,14 @@ def lib():
         L.hpfw_oracle_match_clip.argtypes = [vp, i64, vp, i64, vp, vp]
         L.hpfw_oracle_search_topk.argtypes = [vp, vp, i64, vp, vp, i64, i32, vp, i32]
         L.hpfw_oracle_log10.restype = ctypes.c_double
+        L.hpfw_oracle_mel_create.restype = vp
+        L.hpfw_oracle_mel_destroy.argtypes = [vp]
+        L.hpfw_oracle_mel_tables.argtypes = [vp, vp, vp]
+        L.hpfw_oracle_mel_frames.argtypes = [i64]
+        L.hpfw_oracle_mel_frames.restype = i64
+        L.hpfw_oracle_mel_power.argtypes = [vp, vp, i64, vp, vp]
+        L.hpfw_oracle_mel_spectrogram.argtypes = [vp, vp, i64, vp]
+        L.hpfw_oracle_mel_spectrogram.restype = i64
         L.hpfw_oracle_knn_windows.argtypes = [vp, vp, i64, vp, i64, i32, i32, vp]
         L.hpfw_oracle_vote_windows.argtypes = [vp, i64, i32, vp, i64, vp]
         L.hpfw_oracle_log10.argtypes = [ctypes.c_double]
@@ -181,6 +189,45 @@ def search_topk(db_hp, db_off, q_hp, q_off, topk, n_threads=1):
     lib().hpfw_oracle_search_topk(_p(db_hp), _p(db_off), db_off.size - 1, _p(q_hp), _p(q_off), n_q,
                                   int(topk), _p(out), int(n_threads))
     return out
+
+
+class Mel:
+    """f3: MelSpectrogram<44100, 33, 4410, 441> (mel.h:34-104)"""
+
+    def __init__(self):
+        self._h = lib().hpfw_oracle_mel_create()
+
+    def __del__(self):
+        try:
+            lib().hpfw_oracle_mel_destroy(self._h)
+        except Exception:
+            pass
+
+    def tables(self):
+        w = np.zeros(4410, np.float32)
+        c = np.zeros((33, 2206), np.float32)
+        lib().hpfw_oracle_mel_tables(self._h, _p(w), _p(c))
+        return w, c
+
+    @staticmethod
+    def frames(n):
+        return int(lib().hpfw_oracle_mel_frames(int(n)))
+
+    def power(self, pcm):
+        pcm = _c(pcm, np.int16)
+        nfr = self.frames(pcm.size)
+        p = np.zeros((33, nfr), np.float32)
+        k = np.zeros(nfr, np.uint8)
+        lib().hpfw_oracle_mel_power(self._h, _p(pcm), pcm.size, _p(p), _p(k))
+        return p, k.astype(bool)
+
+    def spectrogram(self, pcm):
+        """dB-mel spectrogram [33][kept columns]"""
+        pcm = _c(pcm, np.int16)
+        nfr = self.frames(pcm.size)
+        out = np.zeros((33, nfr), np.float32)
+        c = lib().hpfw_oracle_mel_spectrogram(self._h, _p(pcm), pcm.size, _p(out))
+        return np.ascontiguousarray(out[:, :c])
 
 
 VOTE_DTYPE = np.dtype([("clip", "<i8"), ("offset", "<i8"), ("cnt", "<f4"), ("pad", "<f4")])

@@ -107,6 +107,25 @@ def test_extract_other_lengths(gpu, oracle, filters, seconds):
     assert bits_equal(d_db.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("seconds", [1.0, 3.0, 30.0])
+def test_mel_front_end(gpu, oracle, seconds):
+    """f3: the Mel front-end (mel.h:34-104): frames kept, their order and every dB value identical to the
+    oracle's (the STFT rides the forward transform's row kernel, the filterbank runs on f32 MFMA)"""
+    mel = oracle.Mel()
+    clips = np.stack([synth.gen_clip(950 + i, seconds) for i in range(3)])
+    clips[1, 5000:30000] = 0                               # silent frames in the middle of a clip
+    clips[2, -9000:] = 0                                   # ... and at its end
+    if seconds == 1.0:
+        clips[0, :] = 0                                    # an entirely silent clip: no column at all
+    got = gpu.mel_spectrogram(clips)
+    for c, g in zip(clips, got):
+        want = mel.spectrogram(c)
+        assert g.shape == want.shape
+        assert bits_equal(g, want), _report("mel", g, want)
+    odd = gpu.mel_spectrogram(clips[1, :clips.shape[1] - 12345])   # any length, not only 7-smooth ones
+    assert bits_equal(odd[0], mel.spectrogram(clips[1, :clips.shape[1] - 12345]))
+
+
 def test_rows_in_place_variant(oracle, filters):
     """HPFW_ROWS_INPLACE=1: the row transform reads the pair words straight from the PCM (no pre-pass);
     a measured-slower alternative that must give the same bits"""

@@ -202,3 +202,27 @@ def test_voting_search_oracle_against_numpy(oracle):
     got = oracle.vote_windows(keys, off)
     assert (int(got["clip"]), int(got["offset"])) == best[:2] == (3, -40) and got["cnt"] == best[2]
     assert oracle.search_votes(db, off, q[:63])["clip"] == -1      # no window fits
+
+
+def test_mel_front_end_against_float64(oracle):
+    """f3: MelSpectrogram<44100, 33, 4410, 441> (mel.h:34-104) -- the C restatement against the float64
+    statement of the same restated essentia algorithms: filterbank, frame count, silent frames, band
+    powers, dB spectrogram"""
+    from hpfw_amd import synth
+    mel = oracle.Mel()
+    win, coeff = mel.tables()
+    fb = nsgt_f64.mel_filterbank()
+    assert coeff.shape == (33, 2206) and np.abs(coeff - fb).max() < 1e-7
+    assert np.abs(coeff.sum(axis=1) - 1).max() < 1e-6 and abs(float(win.sum()) - 2.0) < 1e-5
+    clip = synth.gen_clip(5, 3.0)
+    clip[20000:40000] = 0                                  # a silent stretch: its frames are dropped
+    clip[60000:60010] = 1                                  # almost silent: sum of squares 10 <= 473
+    p, keep = mel.power(clip)
+    p64, keep64 = nsgt_f64.mel_power(clip)
+    assert p.shape == (33, oracle.Mel.frames(clip.size)) == (33, (clip.size + 2205 + 440) // 441)
+    assert np.array_equal(keep, keep64) and 0 < keep.sum() < keep.size
+    assert (np.abs(p - p64).max(axis=1) / p64.max(axis=1)).max() < 1e-5
+    s = mel.spectrogram(clip)
+    assert s.shape == (33, int(keep.sum())) and s.max() == 0.0 and s.min() >= -80.0
+    assert np.abs(s - nsgt_f64.power_to_db(p64[:, keep64])).max() < 1e-3
+    assert mel.spectrogram(np.zeros(10000, np.int16)).shape == (33, 0)      # all frames silent
