@@ -149,6 +149,40 @@ def test_cpp_live_song_identification(wav_set, filters, tmp_path):
         assert name == f"track{ci:02d}" and float(cnt) > 0 and abs(-int(off) - start / hop) <= 2
 
 
+def test_baseline_config0_plumbing(torch_cuda, tmp_path):
+    """BASELINE.json configs[0]: 10 x 30 s synthetic WAVs indexed and 10 x 5 s noisy slices queried through
+    LiveSongIdentification<GpuCollector, GpuStorage> (filters learned from the ten tracks): 10 of 10
+    right, offsets at the planted positions"""
+    exe = str(tmp_path / "live_id")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["g++", "-std=c++20", "-O1", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "live_id.cpp"), "-o", exe, "-L", libdir, "-lhpfw_gpu",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    clips = [synth.gen_clip(i, 30.0) for i in range(10)]
+    tracks, queries = [], []
+    for i, c in enumerate(clips):
+        p = str(tmp_path / f"song{i:02d}.wav")
+        synth.write_wav(p, c)
+        tracks.append(p)
+    for q in range(10):
+        pcm, ci, start = synth.gen_query(clips, q, seconds=5.0)
+        p = str(tmp_path / f"live_song{ci:02d}_{q}.wav")
+        synth.write_wav(p, pcm)
+        queries.append((p, ci, start))
+    work = tmp_path / "run"
+    os.makedirs(str(work / "cache"))
+    r = subprocess.run([exe, "--index"] + tracks + ["--search"] + [q[0] for q in queries], cwd=str(work),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("=> ")]
+    assert lines[-1] == "=> 0 1"                                           # wrong count 0, accuracy 1
+    hop = 3.0 * 1323000 / 7255                                            # samples per spectrogram column (M = 7255)
+    for k, (qp, ci, start) in enumerate(queries):
+        name, cnt, off = lines[2 * k + 1][3:].split()
+        assert name == f"song{ci:02d}" and abs(int(off) - start / hop) <= 2
+
+
 def test_index_readback_and_cached_spectrogram(torch_cuda, oracle, filters):
     g = hpfw_amd.Gpu(0)
     db = synth.random_hashprints(5, 300)
