@@ -496,22 +496,48 @@ int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_sampl
     int rc = hpfw_gpu_geometry(h, n_samples, &g);
     if (rc) return rc;
     if (n_clips == 0) return 0;
-    int16_t *d_pcm = nullptr;
+    // uploads in chunks on a copy stream, two device buffers deep, so that the PCIe transfer of chunk
+    // i + 1 runs under the kernels of chunk i (from pinned host memory; a pageable source is staged
+    // by the runtime and overlaps only partly)
+    const int64_t chunk = std::min<int64_t>(n_clips, std::max<int64_t>(1, (192ll << 20) / (n_samples * 2)));
+    int16_t *d_pcm[2] = {nullptr, nullptr};
     uint64_t *d_hp = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_pcm, (size_t)n_clips * n_samples * 2));
-    if (hipMalloc((void **)&d_hp, (size_t)n_clips * std::max<int64_t>(g.n_hp, 1) * 8) != hipSuccess) {
-        (void)hipFree(d_pcm);
-        return fail(HPFW_E_NOMEM, "hipMalloc failed");
-    }
+    hipStream_t s_copy = nullptr, s_comp = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     rc = 0;
-    if (hipMemcpy(d_pcm, pcm, (size_t)n_clips * n_samples * 2, hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(HPFW_E_HIP, "H2D copy failed");
-    if (!rc) rc = hpfw_gpu_extract_pcm16(h, d_pcm, n_samples, n_clips, d_hp, nullptr);
-    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(HPFW_E_HIP, "kernel execution failed");
+    bool ok = hipMalloc((void **)&d_hp, (size_t)n_clips * std::max<int64_t>(g.n_hp, 1) * 8) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b)
+        ok = hipMalloc((void **)&d_pcm[b], (size_t)chunk * n_samples * 2) == hipSuccess &&
+             hipEventCreateWithFlags(&copied[b], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) rc = fail(HPFW_E_NOMEM, "hipMalloc / stream creation failed");
+    int64_t ci = 0;
+    for (int64_t c0 = 0; !rc && c0 < n_clips; c0 += chunk, ++ci) {
+        const int b = (int)(ci & 1);
+        const int64_t cnt = std::min(chunk, n_clips - c0);
+        if (ci >= 2 && hipStreamWaitEvent(s_copy, consumed[b], 0) != hipSuccess) rc = fail(HPFW_E_HIP, "event wait failed");
+        if (!rc && hipMemcpyAsync(d_pcm[b], pcm + c0 * n_samples, (size_t)cnt * n_samples * 2, hipMemcpyHostToDevice,
+                                  s_copy) != hipSuccess)
+            rc = fail(HPFW_E_HIP, "H2D copy failed");
+        if (!rc && (hipEventRecord(copied[b], s_copy) != hipSuccess || hipStreamWaitEvent(s_comp, copied[b], 0) != hipSuccess))
+            rc = fail(HPFW_E_HIP, "event record failed");
+        if (!rc) rc = hpfw_gpu_extract_pcm16(h, d_pcm[b], n_samples, cnt, d_hp + c0 * g.n_hp, s_comp);
+        if (!rc && hipEventRecord(consumed[b], s_comp) != hipSuccess) rc = fail(HPFW_E_HIP, "event record failed");
+    }
+    if (s_copy && hipStreamSynchronize(s_copy) != hipSuccess && !rc) rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (s_comp && hipStreamSynchronize(s_comp) != hipSuccess && !rc) rc = fail(HPFW_E_HIP, "kernel execution failed");
     if (!rc && hipMemcpy(hp, d_hp, (size_t)n_clips * g.n_hp * 8, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(HPFW_E_HIP, "D2H copy failed");
-    (void)hipFree(d_pcm);
-    (void)hipFree(d_hp);
+    for (int b = 0; b < 2; ++b) {
+        if (d_pcm[b]) (void)hipFree(d_pcm[b]);
+        if (copied[b]) (void)hipEventDestroy(copied[b]);
+        if (consumed[b]) (void)hipEventDestroy(consumed[b]);
+    }
+    if (d_hp) (void)hipFree(d_hp);
+    if (s_copy) (void)hipStreamDestroy(s_copy);
+    if (s_comp) (void)hipStreamDestroy(s_comp);
     return rc;
 }
 
