@@ -10,12 +10,18 @@
 // other containers / rates are rejected (decode and resampling are outside the accelerated path).
 // Filters: read from / written to <cache>/filters.cereal in cereal's binary layout of an Eigen
 // matrix (reference include/hpfw/utils.h:84-90: int32 rows, int32 cols, column-major payload).
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <map>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "../../include/hpfw_gpu.h"
 
@@ -216,44 +222,211 @@ uint64_t *par_collector_calc_hashprint(hpfw_legacy_collector *c, const char *fil
 
 void calc_hashprint_result_free(uint64_t *hp) { delete[] hp; }
 
-// ParallelCollector::prepare (parallel_collector.h:48-52) with already-learned filters: per file
-// errors are skipped as the reference does (parallel_collector.h:101-103), so *got may be < n.
-// The result name is the stem of the path (parallel_collector.h:123,129).
+// ---- prepare(): files in windows, equally long clips batched through the device stages ----------
+namespace {
+
+struct Loaded {
+    std::vector<int16_t> pcm;
+    bool ok = false;
+};
+
+// the reference reads its files on a taskflow pool (parallel_collector.h:95-108); here a team of host
+// threads decodes one window of files while the device stages take whole groups of clips
+void read_window(const char **filenames, const std::vector<int> &files, size_t first, size_t last, std::vector<Loaded> &out)
+{
+    const int count = (int)(last - first);
+    out.assign((size_t)count, Loaded());
+    unsigned team = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    team = std::min<unsigned>(team, (unsigned)count);
+    std::atomic<int> next{0};
+    auto work = [&] {
+        for (int i; (i = next.fetch_add(1)) < count;) {
+            std::string why;
+            out[(size_t)i].ok = read_clip(filenames[files[first + (size_t)i]], out[(size_t)i].pcm, why);
+            if (!out[(size_t)i].ok) hpfw_internal_set_error(why.c_str()); // thread-local: informational only
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < team; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+struct DevMem {
+    void *p = nullptr;
+    DevMem() = default;
+    DevMem(const DevMem &) = delete;
+    DevMem &operator=(const DevMem &) = delete;
+    ~DevMem()
+    {
+        if (p) (void)hipFree(p);
+    }
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
+};
+
+// dB spectrograms [n][121][C] of n equally long clips of the window (device memory, caller frees)
+float *group_spectrograms(hpfw_gpu *gpu, const std::vector<Loaded> &clips, const std::vector<int> &pos, int64_t len,
+                          const hpfw_geometry &g)
+{
+    DevMem pcm;
+    float *d_db = nullptr;
+    if (!pcm.alloc(pos.size() * (size_t)len * 2) || hipMalloc((void **)&d_db, pos.size() * (size_t)121 * g.c * 4) != hipSuccess) {
+        hpfw_internal_set_error("prepare: out of device memory");
+        return nullptr;
+    }
+    bool ok = true;
+    for (size_t k = 0; k < pos.size() && ok; ++k)
+        ok = hipMemcpy((int16_t *)pcm.p + k * (size_t)len, clips[(size_t)pos[k]].pcm.data(), (size_t)len * 2, hipMemcpyHostToDevice) ==
+             hipSuccess;
+    ok = ok && hpfw_gpu_stage_spectrogram(gpu, (const int16_t *)pcm.p, len, (int64_t)pos.size(), d_db, nullptr) == 0 &&
+         hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        (void)hipFree(d_db);
+        return nullptr;
+    }
+    return d_db;
+}
+
+// hashprints of n clips from their dB spectrograms: out[k] = new uint64_t[g.n_hp]
+bool group_hashprints(hpfw_gpu *gpu, const float *d_db, size_t n, const hpfw_geometry &g, uint64_t **out)
+{
+    DevMem proj, hp;
+    if (!proj.alloc(n * 64 * (size_t)g.n_frames * 4) || !hp.alloc(n * (size_t)g.n_hp * 8)) {
+        hpfw_internal_set_error("prepare: out of device memory");
+        return false;
+    }
+    if (hpfw_gpu_stage_project(gpu, d_db, (int64_t)n, g.c, (float *)proj.p, nullptr) != 0 ||
+        hpfw_gpu_stage_pack(gpu, (const float *)proj.p, (int64_t)n, g.n_frames, (uint64_t *)hp.p, nullptr) != 0)
+        return false;
+    std::vector<uint64_t> host(n * (size_t)g.n_hp);
+    if (hipMemcpy(host.data(), hp.p, host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        hpfw_internal_set_error("prepare: D2H copy failed");
+        return false;
+    }
+    for (size_t k = 0; k < n; ++k) {
+        out[k] = new uint64_t[(size_t)g.n_hp];
+        std::memcpy(out[k], host.data() + k * (size_t)g.n_hp, (size_t)g.n_hp * 8);
+    }
+    return true;
+}
+
+struct KeptGroup {
+    std::vector<int> files; // indices into the caller's list
+    hpfw_geometry g;
+    float *d_db;
+};
+
+} // namespace
+
+// ParallelCollector::prepare (parallel_collector.h:48-52): preprocess (:82-112) adds every file's
+// frame covariance to accum_cov, takes the 64 leading eigenvectors as the new filters and saves them;
+// collect_fingerprints (:114-137) then turns the cached spectrograms into hashprints.  Here the
+// spectrograms stay in device memory between the two steps (up to HPFW_PREPARE_KEEP_GB, default 32;
+// files beyond that are read and transformed again), the files are read in windows by a team of
+// host threads, and clips of equal length go through the device stages together.  Per-file errors are
+// skipped as the reference does (:101-103), so *got may be < n; results keep the input order; the name
+// is the stem of the path (:123,129).  HPFW_PREPARE_KEEP_FILTERS=1 skips the learning step and keeps
+// the filters that load() / a previous prepare() installed.
 FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const char **filenames, int n, int *got)
 {
     if (got) *got = 0;
     if (!c || !filenames || n < 0 || !got) return nullptr;
-    // preprocess (parallel_collector.h:82-112): add every file's frame covariance to accum_cov, take the
-    // 64 leading eigenvectors as the new filters, save().  HPFW_PREPARE_KEEP_FILTERS=1 skips this step
-    // and keeps the filters that load() / a previous prepare() installed.
-    if (!(std::getenv("HPFW_PREPARE_KEEP_FILTERS") && !c->filters.empty())) {
-        int used = 0;
-        for (int i = 0; i < n; ++i) {
-            std::vector<int16_t> pcm;
-            std::string why;
-            if (!read_clip(filenames[i], pcm, why)) continue; // skipped, parallel_collector.h:101-103
-            if (hpfw_gpu_cov_accumulate_pcm16_host(c->gpu, pcm.data(), (int64_t)pcm.size(), 1) == 0) ++used;
+    const bool learn = !(std::getenv("HPFW_PREPARE_KEEP_FILTERS") && !c->filters.empty());
+    size_t keep_budget = (size_t)32 << 30;
+    if (const char *e = std::getenv("HPFW_PREPARE_KEEP_GB")) keep_budget = (size_t)std::max(0.0, std::atof(e) * 1073741824.0);
+    std::vector<uint64_t *> hp((size_t)n, nullptr);
+    std::vector<int> hp_size((size_t)n, 0);
+    std::vector<KeptGroup> kept;
+    std::vector<int> again; // files whose spectrogram could not be kept
+    size_t kept_bytes = 0;
+    int64_t used = 0;
+
+    // one pass over `files`: first = covariance (+ keep the spectrograms); otherwise hashprints at once
+    auto pass = [&](const std::vector<int> &files, bool first) {
+        size_t at = 0;
+        while (at < files.size()) {
+            size_t end = at;
+            uintmax_t bytes = 0; // a window: at most 256 files and about 1 GiB of audio
+            while (end < files.size() && end - at < 256 && (end == at || bytes < ((uintmax_t)1 << 30))) {
+                std::error_code ec;
+                const uintmax_t sz = std::filesystem::file_size(filenames[files[end]], ec);
+                if (!ec) bytes += sz;
+                ++end;
+            }
+            std::vector<Loaded> clips;
+            read_window(filenames, files, at, end, clips);
+            std::map<int64_t, std::vector<int>> by_len; // length -> positions in the window, in input order
+            for (size_t i = 0; i < clips.size(); ++i)
+                if (clips[i].ok) by_len[(int64_t)clips[i].pcm.size()].push_back((int)i);
+            for (auto &[len, pos] : by_len) {
+                hpfw_geometry g;
+                if (hpfw_gpu_geometry(c->gpu, len, &g) != 0 || g.n_frames < 2) continue; // skipped
+                float *d_db = group_spectrograms(c->gpu, clips, pos, len, g);
+                if (!d_db) continue;
+                std::vector<int> ids;
+                for (int q : pos) ids.push_back(files[at + (size_t)q]);
+                const size_t sz = pos.size() * (size_t)121 * g.c * 4;
+                if (first && learn) {
+                    if (hpfw_gpu_cov_accumulate_db(c->gpu, d_db, (int64_t)pos.size(), g.c, nullptr) == 0) used += (int64_t)pos.size();
+                    if (g.n_hp > 0 && kept_bytes + sz <= keep_budget) {
+                        kept.push_back(KeptGroup{ids, g, d_db});
+                        kept_bytes += sz;
+                        continue;
+                    }
+                    if (g.n_hp > 0) again.insert(again.end(), ids.begin(), ids.end());
+                } else if (g.n_hp > 0) {
+                    std::vector<uint64_t *> out(pos.size(), nullptr);
+                    if (group_hashprints(c->gpu, d_db, pos.size(), g, out.data()))
+                        for (size_t k = 0; k < ids.size(); ++k) {
+                            hp[(size_t)ids[k]] = out[k];
+                            hp_size[(size_t)ids[k]] = (int)g.n_hp;
+                        }
+                }
+                (void)hipDeviceSynchronize();
+                (void)hipFree(d_db);
+            }
+            at = end;
         }
+    };
+
+    std::vector<int> all((size_t)n);
+    for (int i = 0; i < n; ++i) all[(size_t)i] = i;
+    pass(all, true);
+    bool failed = false;
+    if (learn) {
         if (used > 0) {
             c->filters.assign((size_t)HPFW_FILTERS * HPFW_FRAME_SIZE, 0.0f);
             if (hpfw_gpu_learn_filters(c->gpu, c->filters.data()) != 0) {
                 c->filters.clear();
-                return nullptr;
+                failed = true;
+            } else {
+                par_collector_save(c, nullptr);
             }
-            par_collector_save(c, nullptr);
+        }
+        for (KeptGroup &k : kept) {
+            std::vector<uint64_t *> out(k.files.size(), nullptr);
+            if (!failed && group_hashprints(c->gpu, k.d_db, k.files.size(), k.g, out.data()))
+                for (size_t q = 0; q < k.files.size(); ++q) {
+                    hp[(size_t)k.files[q]] = out[q];
+                    hp_size[(size_t)k.files[q]] = (int)k.g.n_hp;
+                }
+            (void)hipFree(k.d_db);
+        }
+        if (!failed && !again.empty()) {
+            std::sort(again.begin(), again.end());
+            pass(again, false);
         }
     }
+    if (failed) return nullptr;
     auto *res = new FilenameHashprintPair[(size_t)(n > 0 ? n : 1)];
     int w = 0;
     for (int i = 0; i < n; ++i) {
-        int size = 0;
-        uint64_t *hp = par_collector_calc_hashprint(c, filenames[i], &size);
-        if (!hp) continue;
+        if (!hp[(size_t)i]) continue;
         const std::string stem = std::filesystem::path(filenames[i]).stem().string();
         res[w].filename = new char[stem.size() + 1];
         std::memcpy(res[w].filename, stem.c_str(), stem.size() + 1);
-        res[w].hashprint = hp;
-        res[w].hp_size = size;
+        res[w].hashprint = hp[(size_t)i];
+        res[w].hp_size = hp_size[(size_t)i];
         ++w;
     }
     *got = w;

@@ -95,3 +95,37 @@ def test_legacy_prepare_learns_and_persists(torch_cuda, oracle, tmp_path):
     pc2 = hpfw_amd.ParallelCollector()                       # a new process would do exactly this
     pc2.load(cache)
     assert np.array_equal(pc2.calc_hashprint(paths[2]), res[2][0])
+
+
+@pytest.mark.parametrize("keep_gb", ["32", "0"])
+def test_legacy_prepare_mixed_lengths(torch_cuda, tmp_path, keep_gb, monkeypatch):
+    """prepare() over files of several lengths with an unreadable one among them: clips of equal
+    length travel together, the results come back in input order and equal the one-file path; with
+    no room to keep spectrograms (HPFW_PREPARE_KEEP_GB=0) the second pass reads the files again"""
+    monkeypatch.setenv("HPFW_PREPARE_KEEP_GB", keep_gb)
+    secs = [3.0, 2.0, 3.0, 4.0, 2.0, 3.0, 2.5]
+    paths = []
+    for i, sec in enumerate(secs):
+        p = str(tmp_path / f"t{i}.wav")
+        synth.write_wav(p, synth.gen_clip(900 + i, sec))
+        paths.append(p)
+    paths.insert(3, str(tmp_path / "nothing_here.wav"))
+    open(str(tmp_path / "garbage.wav"), "wb").write(b"RIFF0000WAVEjunk")
+    paths.insert(6, str(tmp_path / "garbage.wav"))
+    cache = str(tmp_path / "cache") + "/"
+    pc = hpfw_amd.ParallelCollector()
+    pc.load(cache)
+    res = pc.prepare(paths)
+    assert [n for _, n in res] == [f"t{i}" for i in range(len(secs))]
+    for (hp, name) in res:
+        one = pc.calc_hashprint(str(tmp_path / f"{name}.wav"))
+        assert np.array_equal(hp, one)
+    # the covariance is the sum over the seven readable files, whatever the batching
+    rawc = np.frombuffer(open(os.path.join(cache, "accum_cov.cereal"), "rb").read()[8:], np.float32).reshape(2420, 2420)
+    g = hpfw_amd.Gpu(0)
+    for i in range(len(secs)):
+        g.cov_accumulate(synth.gen_clip(900 + i, secs[i])[None, :])
+    cov, n_files = g.cov_get()
+    g.close()
+    assert n_files == len(secs)
+    assert np.abs(cov - rawc).max() <= 2e-5 * np.abs(cov).max()
