@@ -1,6 +1,7 @@
 // live_id.cpp -- the reference's examples/cpp/live-id.cpp on the GPU path:
 //   live_id --index a.wav b.wav ... [--dump db.cereal] --search q1.wav q2.wav ...
 //   live_id --db db.cereal --search q1.wav ...
+//   ... --batch: run the queries as one batch (search_batched: same output)
 //   ... --votes: additionally print AnnStorage-style voting results ("=# <name> <cnt> <offset>")
 // index() learns the filters from the indexed tracks (or set HPFW_PREPARE_KEEP_FILTERS=1 to keep
 // those of cache/filters.cereal, which the collector's load() reads in the constructor); --dump /
@@ -17,9 +18,10 @@ int main(int argc, char **argv)
     std::vector<std::string> to_index, to_search;
     std::vector<std::string> *cur = nullptr;
     std::string dump, db;
-    bool votes = false;
+    bool votes = false, batch = false;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--votes")) votes = true;
+        else if (!std::strcmp(argv[i], "--batch")) batch = true;
         else if (!std::strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
         else if (!std::strcmp(argv[i], "--db") && i + 1 < argc) db = argv[++i];
         else if (!std::strcmp(argv[i], "--index")) cur = &to_index;
@@ -35,7 +37,10 @@ int main(int argc, char **argv)
         if (!db.empty()) liveid.get_storage().load(db);
         else liveid.index(to_index);
         if (!dump.empty()) liveid.get_storage().save(dump);
-        liveid.search(to_search);
+        if (batch)
+            liveid.search_batched(to_search);
+        else
+            liveid.search(to_search);
         if (votes)
             for (const auto &q : to_search) {
                 const auto r = liveid.get_storage().find_votes(liveid.get_collector().calc_hashprint(q));

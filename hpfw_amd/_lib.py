@@ -34,7 +34,7 @@ EXPORTS = (
     "hpfw_gpu_mel_frames", "hpfw_gpu_mel_spectrogram_pcm16", "hpfw_gpu_mel_spectrogram_pcm16_host",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
-    "par_collector_calc_hashprint", "par_collector_save", "par_collector_load",
+    "par_collector_calc_hashprint", "par_collector_calc_hashprints", "par_collector_save", "par_collector_load",
     "prepare_result_free", "calc_hashprint_result_free",
 )
 
@@ -121,6 +121,8 @@ def lib():
     L.par_collector_del.restype = None
     L.par_collector_prepare.restype = ctypes.POINTER(FilenameHashprintPair)
     L.par_collector_prepare.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32, ctypes.POINTER(i32)]
+    L.par_collector_calc_hashprints.restype = ctypes.POINTER(FilenameHashprintPair)
+    L.par_collector_calc_hashprints.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32]
     L.par_collector_calc_hashprint.restype = ctypes.POINTER(ctypes.c_uint64)
     L.par_collector_calc_hashprint.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32)]
     L.par_collector_load.argtypes = [vp, ctypes.c_char_p]

@@ -42,6 +42,23 @@ class ParallelCollector:
         self.__lib.calc_hashprint_result_free(hp)
         return a
 
+    def calc_hashprints(self, filenames) -> List[Tuple[np.ndarray, str]]:
+        """calc_hashprint for many files in one batched call (not in the reference's class): a list of
+        (uint64 array or None for a file that failed, stem), one entry per file, in input order"""
+        pyarr = [f.encode("utf-8") for f in filenames]
+        arr = (ctypes.c_char_p * len(pyarr))(*pyarr)
+        hps = self.__lib.par_collector_calc_hashprints(self.__collector, arr, len(pyarr))
+        if not hps:
+            raise _lib.HpfwError("calc_hashprints failed: " + self.__lib.hpfw_gpu_last_error().decode())
+        out = []
+        for h in range(len(pyarr)):
+            a = None
+            if hps[h].hashprint:
+                a = np.ctypeslib.as_array(hps[h].hashprint, shape=(hps[h].hp_size,)).astype(np.uint64).copy()
+            out.append((a, hps[h].filename.decode("utf-8")))
+        self.__lib.prepare_result_free(hps, len(pyarr))
+        return out
+
     def load(self, cache: str = ""):
         self.__lib.par_collector_load(self.__collector, cache.encode("utf-8"))
 

@@ -327,15 +327,13 @@ struct KeptGroup {
 // skipped as the reference does (:101-103), so *got may be < n; results keep the input order; the name
 // is the stem of the path (:123,129).  HPFW_PREPARE_KEEP_FILTERS=1 skips the learning step and keeps
 // the filters that load() / a previous prepare() installed.
-FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const char **filenames, int n, int *got)
+static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int n, bool learn, std::vector<uint64_t *> &hp,
+                          std::vector<int> &hp_size)
 {
-    if (got) *got = 0;
-    if (!c || !filenames || n < 0 || !got) return nullptr;
-    const bool learn = !(std::getenv("HPFW_PREPARE_KEEP_FILTERS") && !c->filters.empty());
     size_t keep_budget = (size_t)32 << 30;
     if (const char *e = std::getenv("HPFW_PREPARE_KEEP_GB")) keep_budget = (size_t)std::max(0.0, std::atof(e) * 1073741824.0);
-    std::vector<uint64_t *> hp((size_t)n, nullptr);
-    std::vector<int> hp_size((size_t)n, 0);
+    hp.assign((size_t)n, nullptr);
+    hp_size.assign((size_t)n, 0);
     std::vector<KeptGroup> kept;
     std::vector<int> again; // files whose spectrogram could not be kept
     size_t kept_bytes = 0;
@@ -417,7 +415,17 @@ FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const cha
             pass(again, false);
         }
     }
-    if (failed) return nullptr;
+    return !failed;
+}
+
+FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const char **filenames, int n, int *got)
+{
+    if (got) *got = 0;
+    if (!c || !filenames || n < 0 || !got) return nullptr;
+    const bool learn = !(std::getenv("HPFW_PREPARE_KEEP_FILTERS") && !c->filters.empty());
+    std::vector<uint64_t *> hp;
+    std::vector<int> hp_size;
+    if (!collect_files(c, filenames, n, learn, hp, hp_size)) return nullptr;
     auto *res = new FilenameHashprintPair[(size_t)(n > 0 ? n : 1)];
     int w = 0;
     for (int i = 0; i < n; ++i) {
@@ -430,6 +438,31 @@ FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const cha
         ++w;
     }
     *got = w;
+    return res;
+}
+
+// calc_hashprint (parallel_collector.h:54-59) for a list of files in one call, as LiveSongIdentification::search
+// needs it for its queries (live_song_id.h:37-41): the files are read and transformed in batches as in
+// prepare(), nothing is learned.  Returns n entries in input order, released with prepare_result_free(res, n);
+// an entry whose file failed has hashprint == NULL and hp_size == 0.  NULL when no filters are loaded.
+FilenameHashprintPair *par_collector_calc_hashprints(hpfw_legacy_collector *c, const char **filenames, int n)
+{
+    if (!c || !filenames || n < 0) return nullptr;
+    if (c->filters.empty()) {
+        hpfw_internal_set_error("no filters loaded: call par_collector_load or par_collector_prepare first");
+        return nullptr;
+    }
+    std::vector<uint64_t *> hp;
+    std::vector<int> hp_size;
+    if (!collect_files(c, filenames, n, false, hp, hp_size)) return nullptr;
+    auto *res = new FilenameHashprintPair[(size_t)(n > 0 ? n : 1)];
+    for (int i = 0; i < n; ++i) {
+        const std::string stem = std::filesystem::path(filenames[i]).stem().string();
+        res[i].filename = new char[stem.size() + 1];
+        std::memcpy(res[i].filename, stem.c_str(), stem.size() + 1);
+        res[i].hashprint = hp[(size_t)i];
+        res[i].hp_size = hp_size[(size_t)i];
+    }
     return res;
 }
 

@@ -69,6 +69,21 @@ public:
         return out;
     }
 
+    /// calc_hashprint for a list of files in one batched call (not in the reference): one entry per
+    /// file in input order; a file that failed yields an empty hashprint
+    auto calc_hashprints(const std::vector<std::string> &filenames) const -> std::vector<Hashprint>
+    {
+        std::vector<const char *> names;
+        for (const auto &f : filenames) names.push_back(f.c_str());
+        FilenameHashprintPair *res = par_collector_calc_hashprints(c_, names.data(), (int)names.size());
+        if (!res) throw std::runtime_error(std::string("hpfw::GpuCollector::calc_hashprints: ") + hpfw_gpu_last_error());
+        std::vector<Hashprint> out;
+        for (size_t i = 0; i < names.size(); ++i)
+            out.push_back(res[i].hashprint ? Hashprint(res[i].hashprint, res[i].hashprint + res[i].hp_size) : Hashprint());
+        prepare_result_free(res, (int)names.size());
+        return out;
+    }
+
     void save() const { par_collector_save(c_, cache_.c_str()); } // parallel_collector.h:61-66
     void load() { par_collector_load(c_, cache_.c_str()); }       // parallel_collector.h:68-73
     void set_cache_dir(const std::string &dir) { cache_ = dir; }

@@ -73,6 +73,30 @@ public:
         return out;
     }
 
+    /// find() for many queries in one scan of the database (same result per query as find();
+    /// an empty hashprint yields the empty result of storage.h:28)
+    auto find_batch(const std::vector<typename Collector::Hashprint> &hps) const -> std::vector<SearchResult>
+    {
+        const SearchResult none{"", std::numeric_limits<size_t>::max(), 0};
+        std::vector<SearchResult> out(hps.size(), none);
+        if (names_.empty()) return out;
+        std::vector<uint64_t> all;
+        std::vector<int64_t> off{0};
+        std::vector<size_t> which;
+        for (size_t i = 0; i < hps.size(); ++i) {
+            if (hps[i].empty()) continue;
+            all.insert(all.end(), hps[i].begin(), hps[i].end());
+            off.push_back((int64_t)all.size());
+            which.push_back(i);
+        }
+        if (which.empty()) return out;
+        std::vector<hpfw_hit> hits(which.size());
+        check(hpfw_gpu_search_topk(h_, all.data(), off.data(), (int64_t)which.size(), 1, hits.data()));
+        for (size_t q = 0; q < which.size(); ++q)
+            if (hits[q].clip != 0xffffffffu) out[which[q]] = {names_[hits[q].clip], (size_t)hits[q].dist, (int64_t)hits[q].offset};
+        return out;
+    }
+
     size_t size() const { return names_.size(); }
 
     /// AnnStorage<Collector>::find (reference annoy_storage.h:41-63) with exact nearest neighbours in

@@ -45,6 +45,31 @@ public:
         std::cout << "=> " << wrong << " " << 1 - wrong / float(filenames.size()) << std::endl;
     }
 
+    /// search() with the queries read, transformed and scanned as one batch (Collector::calc_hashprints,
+    /// Storage::find_batch): the same lines on stdout, printed after the batch has run
+    auto search_batched(const std::vector<std::string> &filenames)
+    {
+        uint16_t wrong = 0;
+        const auto hps = collector.calc_hashprints(filenames);
+        const auto found = storage.find_batch(hps);
+        for (size_t i = 0; i < filenames.size(); ++i) {
+            const auto &query = filenames[i];
+            std::cout << "=> Finding " << query << std::endl;
+            if (hps[i].empty()) {
+                std::cerr << "Error finding '" << query << "': no hashprint" << std::endl;
+                continue;
+            }
+            const auto &res = found[i];
+            const auto name = std::filesystem::path(res.filename).stem().string();
+            if (query.find(name) == std::string::npos) {
+                std::cerr << "Wrong result for '" << query << "': got '" << name << "'" << std::endl;
+                ++wrong;
+            }
+            std::cout << "=> " << res.filename << " " << res.cnt << " " << res.offset << std::endl << std::endl;
+        }
+        std::cout << "=> " << wrong << " " << 1 - wrong / float(filenames.size()) << std::endl;
+    }
+
     Collector &get_collector() { return collector; }
     Storage &get_storage() { return storage; }
 

@@ -241,6 +241,12 @@ uint64_t *par_collector_calc_hashprint(hpfw_legacy_collector *collector, const c
                                        int *size);                      /* wrapper.hpp:30 */
 void par_collector_save(hpfw_legacy_collector *collector, const char *cache); /* wrapper.hpp:32 */
 void par_collector_load(hpfw_legacy_collector *collector, const char *cache); /* wrapper.hpp:34 */
+/* not in the reference's FFI: calc_hashprint for a list of files in one call (batched like prepare,
+ * nothing learned) -- what LiveSongIdentification::search (live_song_id.h:37-41) does query by query.
+ * n entries in input order, release with prepare_result_free(res, n); a file that failed has
+ * hashprint == NULL and hp_size == 0; NULL when no filters are loaded */
+FilenameHashprintPair *par_collector_calc_hashprints(hpfw_legacy_collector *collector,
+                                                     const char **filenames, int n);
 void prepare_result_free(FilenameHashprintPair *res, int got);          /* wrapper.hpp:36 */
 void calc_hashprint_result_free(uint64_t *hp);                          /* wrapper.hpp:38 */
 

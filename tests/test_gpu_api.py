@@ -57,7 +57,11 @@ def test_legacy_ffi_through_python_twin(wav_set, oracle, filters):
     plan = oracle.Plan(clips[0].size)
     for (hp, _), c in zip(res, clips):
         assert hp.dtype == np.uint64 and np.array_equal(hp, plan.extract(filters, c))
+    many = pc.calc_hashprints([paths[2], str(d / "missing.wav"), qpaths[0][0], paths[0]])   # one batched call
+    assert [n for _, n in many] == ["track02", "missing", os.path.splitext(os.path.basename(qpaths[0][0]))[0], "track00"]
+    assert many[1][0] is None and np.array_equal(many[0][0], res[2][0]) and np.array_equal(many[3][0], res[0][0])
     q = pc.calc_hashprint(qpaths[0][0])
+    assert np.array_equal(many[2][0], q)
     assert np.array_equal(q, oracle.Plan(3 * 44100).extract(filters, synth.gen_query(clips, 0, seconds=3.0)[0]))
     pc.save(str(d / "cache2"))
     raw = open(str(d / "cache2" / "filters.cereal"), "rb").read()
@@ -181,6 +185,13 @@ def test_baseline_config0_plumbing(torch_cuda, tmp_path):
     for k, (qp, ci, start) in enumerate(queries):
         name, cnt, off = lines[2 * k + 1][3:].split()
         assert name == f"song{ci:02d}" and abs(int(off) - start / hop) <= 2
+    # the same queries as one batch against the same filters (read back from cache/): identical output
+    r2 = subprocess.run([exe, "--batch", "--index"] + tracks + ["--search"] + [q[0] for q in queries] + [str(tmp_path / "absent.wav")],
+                        cwd=str(work), capture_output=True, text=True, timeout=600,
+                        env=dict(os.environ, HPFW_PREPARE_KEEP_FILTERS="1"))
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    lines2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("=> ")]
+    assert lines2[:-2] == lines[:-1] and lines2[-2].startswith("=> Finding") and "absent.wav" in r2.stderr
 
 
 def test_index_readback_and_cached_spectrogram(torch_cuda, oracle, filters):
