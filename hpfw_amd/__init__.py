@@ -7,6 +7,7 @@ synthetic-audio generator used by tests and bench.py.  No CPU fallback exists.
 from ._lib import (Gpu, HpfwError, HIT_DTYPE, VOTE_DTYPE, KERNEL_KINDS, LIB_PATH, lib, merge_topk,  # noqa: F401
                    plan_checksum, supported_length)
 from .collector import ParallelCollector  # noqa: F401
+from .liveid import LiveSongIdentification  # noqa: F401
 
 __all__ = ["Gpu", "HpfwError", "HIT_DTYPE", "VOTE_DTYPE", "KERNEL_KINDS", "LIB_PATH", "lib", "merge_topk",
-           "plan_checksum", "supported_length", "ParallelCollector"]
+           "plan_checksum", "supported_length", "ParallelCollector", "LiveSongIdentification"]

@@ -3,6 +3,7 @@ the cereal filter file, the C++ LiveSongIdentification facade (config 0: a handf
 and queried end to end) and the error behaviour of the C-ABI."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -232,3 +233,38 @@ def test_c_abi_error_codes(torch_cuda):
     hp = g.extract(pcm)                                               # silence: every delta is 0 -> all ones
     assert (hp == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
     g.close()
+
+
+def test_python_liveid_and_notebook_example(wav_set, oracle, filters, tmp_path):
+    """the Python LiveSongIdentification twin and examples/liveid.py (the reference's notebook): ten best
+    tracks per query equal the oracle's scan; the dump round-trips through pickle"""
+    d, clips, paths, qpaths = wav_set
+    cache = str(tmp_path / "cache") + "/"
+    _write_filters(cache, filters)
+    os.environ["HPFW_PREPARE_KEEP_FILTERS"] = "1"
+    try:
+        lid = hpfw_amd.LiveSongIdentification(cache=cache)
+        lid.index(paths)
+        ans = lid.top([q[0] for q in qpaths] + [str(d / "missing.wav")], 10)
+        wrong, acc = lid.search([q[0] for q in qpaths])
+        lid.close()
+        dump = str(tmp_path / "dump.pkl")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "liveid.py"), "--cache", cache, "--index"] + paths +
+                           ["--dump", dump, "--search"] + [q[0] for q in qpaths], capture_output=True, text=True, timeout=300)
+    finally:
+        del os.environ["HPFW_PREPARE_KEEP_FILTERS"]
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines()[-1] == "accuracy 1.0"
+    assert (wrong, acc) == (0, 1.0) and ans[-1][1] is None
+    plan = oracle.Plan(clips[0].size)
+    db = [plan.extract(filters, c) for c in clips]
+    off = np.zeros(len(db) + 1, np.int64)
+    np.cumsum([x.size for x in db], out=off[1:])
+    for (label, top), (qp, ci, start) in zip(ans, qpaths):
+        q = oracle.Plan(3 * 44100).extract(filters, synth.gen_query(clips, qpaths.index((qp, ci, start)), seconds=3.0)[0])
+        want = oracle.search_topk(np.concatenate(db), off, q, np.array([0, q.size], np.int64), 10)[0]
+        assert [(d_, f"track{c:02d}", o) for d_, c, o in
+                [(int(h["dist"]), int(h["clip"]), int(h["offset"])) for h in want if h["clip"] != 0xFFFFFFFF]] == top
+    import pickle
+    got = pickle.load(open(dump, "rb"))
+    assert [n for _, n in got] == [f"track{i:02d}" for i in range(4)] and all(np.array_equal(a, b) for (a, _), b in zip(got, db))
