@@ -35,10 +35,13 @@ int fail(int code, const std::string &msg)
             return fail(HPFW_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
     } while (0)
 
+size_t g_uploaded = 0; // bytes uploaded by upload() since get_plan last reset it
+
 template <class T>
 int upload(const std::vector<T> &v, const T **out, std::vector<void *> &owned)
 {
     void *d = nullptr;
+    g_uploaded += v.size() * sizeof(T);
     if (v.empty()) {
         *out = nullptr;
         return 0;
@@ -66,6 +69,8 @@ struct DevPlan {
     hpfw::CqPlanDev cq;
     std::vector<hpfw::CqClassDev> cls;
     std::vector<void *> owned;
+    size_t bytes = 0;      // device memory of the tables
+    uint64_t last_use = 0; // for the least-recently-used eviction in get_plan
     ~DevPlan()
     {
         for (void *p : owned) (void)hipFree(p);
@@ -87,7 +92,9 @@ struct hpfw_gpu {
     int device = 0;
     bool has_filters = false;
     float *d_fpack = nullptr;
-    std::map<int64_t, std::unique_ptr<DevPlan>> plans;
+    std::map<int64_t, std::unique_ptr<DevPlan>> plans; // one per clip length, least recently used evicted
+    size_t plan_bytes = 0;
+    uint64_t plan_clock = 0;
     int batch = 1024; // clips per pass: ~10 GB of workspace at 30 s; every launch fills the 256 CUs many times over
     // extraction workspace
     size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
@@ -189,9 +196,11 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
 {
     auto it = h->plans.find(n);
     if (it != h->plans.end()) {
+        it->second->last_use = ++h->plan_clock;
         *out = it->second.get();
         return 0;
     }
+    g_uploaded = 0;
     auto dp = std::make_unique<DevPlan>();
     std::string why;
     if (!hpfw::build_plan(n, dp->hp, why))
@@ -263,6 +272,38 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         dp->cls.push_back(cd);
     }
     if ((size_t)p.n2 * sizeof(cf) > 150 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
+    // the tables live on the device now: drop the host copies (only the sizes are read from here on)
+    {
+        hpfw::HostPlan &hp = dp->hp;
+        std::vector<hpfw::HostCf>().swap(hp.rows_gtw);
+        std::vector<hpfw::HostCf>().swap(hp.tw_n2);
+        std::vector<hpfw::HostCf>().swap(hp.tw_n1);
+        std::vector<hpfw::HostCf>().swap(hp.tw_big);
+        std::vector<hpfw::HostCf>().swap(hp.g);
+        for (hpfw::BluesteinClass &bc : hp.classes) {
+            std::vector<hpfw::HostCf>().swap(bc.tw);
+            std::vector<hpfw::HostCf>().swap(bc.gtw);
+            std::vector<hpfw::HostCf>().swap(bc.vrev);
+        }
+    }
+    dp->bytes = g_uploaded;
+    dp->last_use = ++h->plan_clock;
+    // a corpus of files of many different lengths would otherwise keep one set of tables per length
+    // (14 MB for 30 s clips, growing with the length): bound the cache (HPFW_PLAN_CACHE_GB, default 16) by
+    // evicting the least recently used plans; work already queued may still read their tables, hence the sync
+    size_t budget = (size_t)16 << 30;
+    if (const char *e = std::getenv("HPFW_PLAN_CACHE_GB")) budget = (size_t)(std::max(0.0, std::atof(e)) * 1073741824.0);
+    if (h->plan_bytes + dp->bytes > budget && !h->plans.empty()) {
+        (void)hipDeviceSynchronize();
+        while (h->plan_bytes + dp->bytes > budget && !h->plans.empty()) {
+            auto lru = h->plans.begin();
+            for (auto q = h->plans.begin(); q != h->plans.end(); ++q)
+                if (q->second->last_use < lru->second->last_use) lru = q;
+            h->plan_bytes -= lru->second->bytes;
+            h->plans.erase(lru);
+        }
+    }
+    h->plan_bytes += dp->bytes;
     *out = dp.get();
     h->plans[n] = std::move(dp);
     return 0;
@@ -398,6 +439,7 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     h->plans.clear();
+    h->plan_bytes = 0;
     for (void *p : h->ws)
         if (p) (void)hipFree(p);
     if (h->d_fpack) (void)hipFree(h->d_fpack);

@@ -434,3 +434,16 @@ def test_golden_vectors_on_gpu(gpu, torch_cuda):
     h.index_add(s["db"], s["db_off"])
     assert np.array_equal(h.search_topk(s["q"], s["q_off"], 5), s["top5"])
     h.close()
+
+
+def test_plan_cache_eviction(torch_cuda, oracle, filters, monkeypatch):
+    """the per-length tables are cached least-recently-used under HPFW_PLAN_CACHE_GB: with room for one
+    plan only, alternating lengths rebuild the tables each time and the hashprints do not change"""
+    monkeypatch.setenv("HPFW_PLAN_CACHE_GB", "0.0005")   # 0.5 MB: below any single plan
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filters)
+    clips = {sec: synth.gen_clip(77 + i, sec) for i, sec in enumerate((2.0, 3.0, 4.0))}
+    want = {sec: oracle.Plan(c.size).extract(filters, c) for sec, c in clips.items()}
+    for sec in (2.0, 3.0, 2.0, 4.0, 3.0, 2.0):
+        assert np.array_equal(g.extract(clips[sec])[0], want[sec])
+    g.close()
