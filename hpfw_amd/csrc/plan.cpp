@@ -9,8 +9,11 @@
 // hpfw keeps ceil(M / 3) columns (cqt.h:73-81).
 #include "plan.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace hpfw {
 
@@ -198,6 +201,28 @@ bool make_radix_list(int64_t n, std::vector<int> &radix)
     return radix.size() <= 24;
 }
 
+// fn(i) for i in [0, n) on a small team of host threads: the table entries are pure functions of their
+// index, so the result does not depend on the split (a new clip length costs one table build, and a
+// corpus of full-length tracks brings a new length with almost every file)
+template <class F>
+static void parallel_rows(int64_t n, F fn)
+{
+    unsigned team = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if ((int64_t)team > n) team = (unsigned)n;
+    if (team <= 1) {
+        for (int64_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    auto work = [&] {
+        for (int64_t i; (i = next.fetch_add(1)) < n;) fn(i);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < team; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
 bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
 {
     if (n < 2) {
@@ -316,8 +341,9 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
         }
     }
     p.tw_big.resize((size_t)n1 * p.h);
-    for (int64_t a = 0; a < n1; ++a)
+    parallel_rows(n1, [&](int64_t a) {
         for (int64_t k2 = 0; k2 < p.h; ++k2) p.tw_big[(size_t)(a * p.h + k2)] = twiddle_f(a * k2, n);
+    });
     p.pos_n2.resize((size_t)n2);
     for (int64_t k = 0; k < n2; ++k) p.pos_n2[(size_t)k] = (int)digit_pos(k, n2, p.radix);
     // the last fused group (R1, R2) works on blocks of len = R1 R2 consecutive positions; block b holds
@@ -353,71 +379,85 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
         if (k == p.classes.size()) {
             BluesteinClass bc;
             bc.p = (int)ps;
-            make_radix_list(ps, bc.radix);
-            bc.tw = twiddle_table(ps);
-            // per-butterfly twiddle tables of the fused groups, in the order the kernel walks them
-            // (fft_lds.h GroupOf): pairs of passes of the list [4.., 3, 2]; the innermost group's
-            // entries do not depend on the butterfly and are stored once
-            {
-                auto next_radix = [](int64_t len) { return len % 4 == 0 ? 4 : (len % 3 == 0 ? 3 : 2); };
-                // above 16384 points: peel radix-4 passes off the front until a block fits the LDS
-                int64_t len = ps;
-                while (ps > 16384 && len > 8192) {
-                    len /= 4;
-                    ++bc.outer;
-                }
-                bc.len0 = (int)len;
-                const int64_t blk = len; // butterfly tables cover one block (the whole transform when it fits)
-                int g = 0;
-                for (;;) {
-                    const int r1 = next_radix(len);
-                    const int r2 = len / r1 > 1 ? next_radix(len / r1) : 1;
-                    if (len / (r1 * r2) == 1) {
-                        std::vector<HostCf> tmp;
-                        append_group_twiddles(bc.tw, ps, len, r1, r2, tmp, blk / (r1 * r2));
-                        const int64_t nb = blk / (r1 * r2);
-                        bc.mid_off = (int)bc.gtw.size();
-                        for (int e = 0; e < (r1 - 1) * r2; ++e) bc.gtw.push_back(tmp[(size_t)e * nb]);
-                        break;
-                    }
-                    if (g >= 4) {
-                        why = "internal: too many fused groups";
-                        return false;
-                    }
-                    bc.goff[g++] = (int)bc.gtw.size();
-                    append_group_twiddles(bc.tw, ps, len, r1, r2, bc.gtw, blk / (r1 * r2));
-                    len /= r1 * r2;
-                }
-            }
-            std::vector<double> re((size_t)ps, 0.0), im((size_t)ps, 0.0);
-            for (int64_t mm = -(ps - p.c); mm <= p.c - 1; ++mm) { // v[m mod P] = e^{-i pi 3 m^2 / M}
-                double cc, ss;
-                chirp_d(mm, big_m, cc, ss);
-                const int64_t idx = mm < 0 ? mm + ps : mm;
-                re[(size_t)idx] = cc;
-                im[(size_t)idx] = -ss;
-            }
-            dft_double(re, im);
-            bc.vrev.resize((size_t)ps);
-            for (int64_t kk = 0; kk < ps; ++kk) {
-                const int64_t pos = digit_pos(kk, ps, bc.radix);
-                bc.vrev[(size_t)pos] = {(float)re[(size_t)kk], (float)im[(size_t)kk]};
-            }
             p.classes.push_back(std::move(bc));
         }
         p.classes[k].bands.push_back(j);
-        // G_j[i] = hann_Lg[i] e^{+i pi 3 i^2 / M} / (M P)
-        const int64_t lg = p.lg[j];
         p.g_off[j] = goff;
-        const double scale = 1.0 / ((double)big_m * (double)ps);
+        goff += p.lg[j];
+    }
+    // the tables of every class (butterfly twiddles, DFT of the chirp), classes side by side
+    std::atomic<bool> bad_class{false};
+    parallel_rows((int64_t)p.classes.size(), [&](int64_t ci) {
+        BluesteinClass &bc = p.classes[(size_t)ci];
+        const int64_t ps = bc.p;
+        make_radix_list(ps, bc.radix);
+        bc.tw = twiddle_table(ps);
+        // per-butterfly twiddle tables of the fused groups, in the order the kernel walks them
+        // (fft_lds.h GroupOf): pairs of passes of the list [4.., 3, 2]; the innermost group's
+        // entries do not depend on the butterfly and are stored once
+        {
+            auto next_radix = [](int64_t len) { return len % 4 == 0 ? 4 : (len % 3 == 0 ? 3 : 2); };
+            // above 16384 points: peel radix-4 passes off the front until a block fits the LDS
+            int64_t len = ps;
+            while (ps > 16384 && len > 8192) {
+                len /= 4;
+                ++bc.outer;
+            }
+            bc.len0 = (int)len;
+            const int64_t blk = len; // butterfly tables cover one block (the whole transform when it fits)
+            int g = 0;
+            for (;;) {
+                const int r1 = next_radix(len);
+                const int r2 = len / r1 > 1 ? next_radix(len / r1) : 1;
+                if (len / (r1 * r2) == 1) {
+                    std::vector<HostCf> tmp;
+                    append_group_twiddles(bc.tw, ps, len, r1, r2, tmp, blk / (r1 * r2));
+                    const int64_t nb = blk / (r1 * r2);
+                    bc.mid_off = (int)bc.gtw.size();
+                    for (int e = 0; e < (r1 - 1) * r2; ++e) bc.gtw.push_back(tmp[(size_t)e * nb]);
+                    break;
+                }
+                if (g >= 4) {
+                    bad_class = true;
+                    return;
+                }
+                bc.goff[g++] = (int)bc.gtw.size();
+                append_group_twiddles(bc.tw, ps, len, r1, r2, bc.gtw, blk / (r1 * r2));
+                len /= r1 * r2;
+            }
+        }
+        std::vector<double> re((size_t)ps, 0.0), im((size_t)ps, 0.0);
+        for (int64_t mm = -(ps - p.c); mm <= p.c - 1; ++mm) { // v[m mod P] = e^{-i pi 3 m^2 / M}
+            double cc, ss;
+            chirp_d(mm, big_m, cc, ss);
+            const int64_t idx = mm < 0 ? mm + ps : mm;
+            re[(size_t)idx] = cc;
+            im[(size_t)idx] = -ss;
+        }
+        dft_double(re, im);
+        bc.vrev.resize((size_t)ps);
+        for (int64_t kk = 0; kk < ps; ++kk) {
+            const int64_t pos = digit_pos(kk, ps, bc.radix);
+            bc.vrev[(size_t)pos] = {(float)re[(size_t)kk], (float)im[(size_t)kk]};
+        }
+    });
+    if (bad_class) {
+        why = "internal: too many fused groups";
+        return false;
+    }
+    // G_j[i] = hann_Lg[i] e^{+i pi 3 i^2 / M} / (M P)
+    p.g.resize((size_t)goff);
+    parallel_rows(kBins, [&](int64_t j) {
+        const int64_t lg = p.lg[j];
+        const double scale = 1.0 / ((double)big_m * (double)p.psize[j]);
+        HostCf *gj = p.g.data() + p.g_off[(size_t)j];
         for (int64_t i = 0; i < lg; ++i) {
             const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / (double)(lg - 1));
             double cc, ss;
             chirp_d(i, big_m, cc, ss);
-            p.g.push_back({(float)(w * cc * scale), (float)(w * ss * scale)});
+            gj[i] = {(float)(w * cc * scale), (float)(w * ss * scale)};
         }
-        goff += lg;
-    }
+    });
     return true;
 }
 
