@@ -59,12 +59,20 @@ bool read_wav_pcm16_mono(const std::string &path, std::vector<int16_t> &out, std
             std::memcpy(&channels, b.data() + 2, 2);
             std::memcpy(&rate, b.data() + 4, 4);
             std::memcpy(&bits, b.data() + 14, 2);
+            if (fmt == 0xFFFE && sz >= 26) std::memcpy(&fmt, b.data() + 24, 2); // WAVE_FORMAT_EXTENSIBLE: the sub-format's tag
+            if (sz & 1) f.seekg(1, std::ios::cur);
             have_fmt = true;
         } else if (!std::memcmp(id, "data", 4)) {
             if (!have_fmt || fmt != 1 || bits != 16 || (channels != 1 && channels != 2) || rate != 44100) {
                 why = path + ": only PCM16 mono/stereo at 44100 Hz is supported";
                 return false;
             }
+            // a streamed file may carry 0 or 0xffffffff as the size: trust the file's length instead
+            const std::streamoff here = f.tellg();
+            f.seekg(0, std::ios::end);
+            const std::streamoff left = f.tellg() - here;
+            f.seekg(here);
+            if (sz == 0 || (std::streamoff)sz > left) sz = (uint32_t)std::min<std::streamoff>(left, 0xfffffffe);
             std::vector<int16_t> raw(sz / 2);
             f.read(reinterpret_cast<char *>(raw.data()), (std::streamsize)raw.size() * 2);
             raw.resize((size_t)f.gcount() / 2);

@@ -79,6 +79,19 @@ def test_stereo_and_unsupported_wav(wav_set, filters, tmp_path):
     mono = str(tmp_path / "mono.wav")
     synth.write_wav(mono, clips[0])
     assert np.array_equal(pc.calc_hashprint(p), pc.calc_hashprint(mono))
+    # WAVE_FORMAT_EXTENSIBLE header, a LIST chunk of odd size before the data, and a streamed file whose
+    # data size field is 0xffffffff: the same samples, the same hashprints
+    import struct
+    data = np.ascontiguousarray(clips[0], np.int16).tobytes()
+    ext = str(tmp_path / "extensible.wav")
+    fmt = struct.pack("<HHIIHHHHIH", 0xFFFE, 1, 44100, 88200, 2, 16, 22, 16, 4, 1) + bytes.fromhex("000000001000800000aa00389b71")
+    with open(ext, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + 6 + 8 + len(data)) + b"WAVE")
+        f.write(b"fmt " + struct.pack("<I", len(fmt)) + fmt)
+        f.write(b"LIST" + struct.pack("<I", 5) + b"INFOx" + b"\0")
+        f.write(b"data" + struct.pack("<I", 0xFFFFFFFF) + data)
+    assert len(fmt) == 40
+    assert np.array_equal(pc.calc_hashprint(ext), pc.calc_hashprint(mono))
     bad = str(tmp_path / "odd.wav")
     synth.write_wav(bad, clips[0][:44100 * 8 - 1])       # 352799 samples: prime factor 13 -> not a supported length
     os.environ["HPFW_STRICT_LENGTH"] = "1"
