@@ -447,3 +447,31 @@ def test_plan_cache_eviction(torch_cuda, oracle, filters, monkeypatch):
     for sec in (2.0, 3.0, 2.0, 4.0, 3.0, 2.0):
         assert np.array_equal(g.extract(clips[sec])[0], want[sec])
     g.close()
+
+
+def test_extreme_signals(torch_cuda, oracle, filters):
+    """silence, DC at full scale, the Nyquist square wave at full scale, a single impulse, white noise at
+    full scale: hashprints and dB spectrograms equal the oracle's bit for bit (the dB floor, the clip
+    maximum and the largest magnitudes the transform can meet)"""
+    torch = torch_cuda
+    n = 3 * 44100
+    rng = np.random.default_rng(5)
+    sig = np.zeros((6, n), np.int16)
+    sig[1, :] = -32768
+    sig[2, 0::2], sig[2, 1::2] = 32767, -32768
+    sig[3, n // 2] = 32767
+    sig[4, :] = rng.integers(-32768, 32768, n).astype(np.int16)
+    sig[5, :10] = 1                                            # next to silence: magnitudes near the floor
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filters)
+    plan = oracle.Plan(n)
+    hp = g.extract(sig)
+    c = int(g.geometry(n).c)
+    d_db = torch.empty((6, 121, c), dtype=torch.float32, device="cuda")
+    g.stage_spectrogram_dev(_dev(torch, sig).data_ptr(), n, 6, d_db.data_ptr())
+    torch.cuda.synchronize()
+    db = d_db.cpu().numpy()
+    for i in range(6):
+        assert np.array_equal(hp[i], plan.extract(filters, sig[i])), i
+        assert bits_equal(db[i], oracle.db(plan.cqmag(plan.spectrum(sig[i])))), i
+    g.close()
