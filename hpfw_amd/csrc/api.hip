@@ -35,7 +35,7 @@ int fail(int code, const std::string &msg)
             return fail(HPFW_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
     } while (0)
 
-size_t g_uploaded = 0; // bytes uploaded by upload() since get_plan last reset it
+thread_local size_t g_uploaded = 0; // bytes uploaded by upload() since get_plan last reset it
 
 template <class T>
 int upload(const std::vector<T> &v, const T **out, std::vector<void *> &owned)

@@ -118,13 +118,13 @@ template <int NP>
 static void launch_cq_t(const CqPlanDev &cp, const CqClassDev &cc, const cf *d_x, int n_clips, float *d_mag,
                         float *d_wavemax, bool db_term_out, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<NP, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_kernel<NP, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid(cc.n_bands, n_clips);
     const size_t lds = (size_t)Size<NP>::DATA * sizeof(cf) + cq_threads(NP) * sizeof(float);

@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void cq_big_max_kernel(const float *__restrict
 template <int LEN0>
 static void launch_local_t(const CqClassDev &cc, int n_clips, int64_t pitch, cf *d_work, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(cq_big_local_kernel<LEN0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid(cc.p / LEN0, cc.n_bands, n_clips);
     hipLaunchKernelGGL(cq_big_local_kernel<LEN0>, grid, dim3(cq_big_threads(LEN0)), (size_t)Size<LEN0>::DATA * sizeof(cf), s,

@@ -194,11 +194,11 @@ size_t fwd_rows_lds_bytes(const RowsArgs &a) { return (size_t)a.n2 * sizeof(cf);
 template <class Groups>
 static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, float *d_yp, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_rows_kernel<Groups>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid(n_clips, (a.n1 + 1) / 2);
     // pre-passed stream: [clip][pair][n2]; in place: pair p of time step t at pcm word t n1/2 + p

@@ -228,11 +228,11 @@ void launch_mel(const RowsArgs &rows, const float *d_win, const float *d_cpack, 
     float *y = d_work, *power = d_work + (size_t)n_clips * fp * 2 * kMelHpad;
     hipLaunchKernelGGL(mel_blocksum_kernel, dim3((n_blk + 3) / 4, n_clips), dim3(256), 0, s, d_pcm, n, n_blk, d_blk);
     hipLaunchKernelGGL(mel_keep_kernel, dim3(n_clips), dim3(256), 0, s, d_blk, n_blk, nf, d_pos, d_count);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(stft_rows_kernel<Groups4410>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(stft_rows_kernel<Groups4410>, dim3(fp / 2, n_clips), dim3(kMelThreads), (size_t)kMelFrame * sizeof(cf), s,
                        rows, d_pcm, n, nf, fp, d_win, y);

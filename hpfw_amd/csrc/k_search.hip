@@ -293,11 +293,11 @@ void launch_topk_two_step(const uint64_t *d_best, int n_q, int n_clips, int k, u
 template <int QT>
 static void launch_hamming_scan_t(const SearchArgs &a, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_scan_kernel<QT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     const size_t lds = ((size_t)kHsThreads + a.k_max + 4 * QT) * sizeof(uint64_t);
     dim3 grid(a.n_clips, (a.n_q + QT - 1) / QT);

@@ -451,11 +451,11 @@ size_t hamming_shift_lds_bytes(int k)
 void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_clips, int n_off_max, const uint64_t *d_q,
                           int k, uint64_t *d_best, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     SearchShiftArgs a;
     a.db = d_db;
@@ -487,13 +487,13 @@ void launch_expand_queries(const uint64_t *d_q, const int64_t *d_q_off, int n_q,
 
 static void mfma_scan_attrs()
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_mfma_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_mfma_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
 }
 

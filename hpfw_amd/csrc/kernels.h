@@ -1,6 +1,7 @@
 // kernels.h -- host-callable launchers of the gfx950 kernels (one per hot loop of the reference,
 // SURVEY.md section 2.1).  Each launcher only enqueues on `stream`.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -9,6 +10,21 @@
 #include "fft_rows.h"
 
 namespace hpfw {
+
+// "once per device" for hipFuncSetAttribute calls: a process may hold handles on several devices (one
+// handle = one device), and a launcher may be entered from several host threads
+struct PerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    static uint64_t bit()
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return 1ull << (dev & 63);
+    }
+    bool need() const { return !(done.load(std::memory_order_acquire) & bit()); }
+    void mark() { done.fetch_or(bit(), std::memory_order_release); } // after the calls: a second thread may repeat them, harmlessly
+};
+
 
 constexpr int kBins = 121;
 constexpr int kCtx = 20;
