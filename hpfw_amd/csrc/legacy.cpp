@@ -52,9 +52,9 @@ bool read_wav_pcm16_mono(const std::string &path, std::vector<int16_t> &out, std
         f.read(reinterpret_cast<char *>(&sz), 4);
         if (!f) break;
         if (!std::memcmp(id, "fmt ", 4)) {
+            if (sz < 16 || sz > 4096) break; // malformed: reported as "no data chunk" below
             std::vector<char> b(sz);
             f.read(b.data(), sz);
-            if (sz < 16) break;
             std::memcpy(&fmt, b.data(), 2);
             std::memcpy(&channels, b.data() + 2, 2);
             std::memcpy(&rate, b.data() + 4, 4);
@@ -122,6 +122,21 @@ struct hpfw_legacy_collector {
     std::string cache_dir = "cache/"; // parallel_collector.h:38
     std::vector<float> filters;
 };
+
+// the exported entry points: no exception leaves the C boundary (the reference's wrapper.cpp has no such
+// barrier); a failure that surfaces as one -- out of host memory, in practice -- becomes NULL + a message
+template <class F>
+static auto guarded(F f) -> decltype(f())
+{
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        hpfw_internal_set_error((std::string("host failure: ") + e.what()).c_str());
+    } catch (...) {
+        hpfw_internal_set_error("host failure");
+    }
+    return nullptr;
+}
 
 extern "C" {
 
@@ -196,14 +211,19 @@ void par_collector_save(hpfw_legacy_collector *c, const char *cache)
 // deviation, confined to the file entry points and switched off by HPFW_STRICT_LENGTH.
 static bool read_clip(const std::string &path, std::vector<int16_t> &pcm, std::string &why)
 {
-    if (!read_wav_pcm16_mono(path, pcm, why)) return false;
+    try { // nothing may throw through the C boundary (or out of a reader thread): e.g. bad_alloc on a huge file
+        if (!read_wav_pcm16_mono(path, pcm, why)) return false;
+    } catch (const std::exception &e) {
+        why = path + ": " + e.what();
+        return false;
+    }
     if (std::getenv("HPFW_STRICT_LENGTH")) return true;
     const int64_t want = hpfw_gpu_supported_length((int64_t)pcm.size());
     if (want > (int64_t)pcm.size()) pcm.resize((size_t)want, 0);
     return true;
 }
 
-uint64_t *par_collector_calc_hashprint(hpfw_legacy_collector *c, const char *filename, int *size)
+static uint64_t *calc_hashprint_impl(hpfw_legacy_collector *c, const char *filename, int *size)
 {
     if (size) *size = 0;
     if (!c || !filename || !size) return nullptr;
@@ -426,7 +446,7 @@ static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int 
     return !failed;
 }
 
-FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const char **filenames, int n, int *got)
+static FilenameHashprintPair *prepare_impl(hpfw_legacy_collector *c, const char **filenames, int n, int *got)
 {
     if (got) *got = 0;
     if (!c || !filenames || n < 0 || !got) return nullptr;
@@ -453,7 +473,7 @@ FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const cha
 // needs it for its queries (live_song_id.h:37-41): the files are read and transformed in batches as in
 // prepare(), nothing is learned.  Returns n entries in input order, released with prepare_result_free(res, n);
 // an entry whose file failed has hashprint == NULL and hp_size == 0.  NULL when no filters are loaded.
-FilenameHashprintPair *par_collector_calc_hashprints(hpfw_legacy_collector *c, const char **filenames, int n)
+static FilenameHashprintPair *calc_hashprints_impl(hpfw_legacy_collector *c, const char **filenames, int n)
 {
     if (!c || !filenames || n < 0) return nullptr;
     if (c->filters.empty()) {
@@ -472,6 +492,23 @@ FilenameHashprintPair *par_collector_calc_hashprints(hpfw_legacy_collector *c, c
         res[i].hp_size = hp_size[(size_t)i];
     }
     return res;
+}
+
+uint64_t *par_collector_calc_hashprint(hpfw_legacy_collector *c, const char *filename, int *size)
+{
+    return guarded([&] { return calc_hashprint_impl(c, filename, size); });
+}
+
+FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const char **filenames, int n, int *got)
+{
+    FilenameHashprintPair *res = guarded([&] { return prepare_impl(c, filenames, n, got); });
+    if (!res && got) *got = 0;
+    return res;
+}
+
+FilenameHashprintPair *par_collector_calc_hashprints(hpfw_legacy_collector *c, const char **filenames, int n)
+{
+    return guarded([&] { return calc_hashprints_impl(c, filenames, n); });
 }
 
 void prepare_result_free(FilenameHashprintPair *res, int got)
