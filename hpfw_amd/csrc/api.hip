@@ -132,6 +132,14 @@ struct hpfw_gpu {
     size_t qa_cap = 0;
     int *d_gk = nullptr;    // longest query of each group of 32
     size_t gk_cap = 0;
+    // staging of the host-buffer entry points: kept between calls (a one-file call is otherwise mostly
+    // allocation and stream set-up)
+    void *stage_pcm[2] = {nullptr, nullptr};
+    size_t stage_pcm_cap[2] = {0, 0};
+    void *stage_hp = nullptr;
+    size_t stage_hp_cap = 0;
+    hipStream_t stage_copy = nullptr, stage_comp = nullptr;
+    hipEvent_t stage_copied[2] = {nullptr, nullptr}, stage_consumed[2] = {nullptr, nullptr};
     float *d_clipmax = nullptr; // per-clip maximum magnitude (reference level of the dB conversion)
     size_t clipmax_cap = 0;
     int *d_cov_tiles = nullptr;
@@ -453,6 +461,14 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->d_qa) (void)hipFree(h->d_qa);
     if (h->d_gk) (void)hipFree(h->d_gk);
     if (h->d_clipmax) (void)hipFree(h->d_clipmax);
+    for (int b = 0; b < 2; ++b) {
+        if (h->stage_pcm[b]) (void)hipFree(h->stage_pcm[b]);
+        if (h->stage_copied[b]) (void)hipEventDestroy(h->stage_copied[b]);
+        if (h->stage_consumed[b]) (void)hipEventDestroy(h->stage_consumed[b]);
+    }
+    if (h->stage_hp) (void)hipFree(h->stage_hp);
+    if (h->stage_copy) (void)hipStreamDestroy(h->stage_copy);
+    if (h->stage_comp) (void)hipStreamDestroy(h->stage_comp);
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
     if (h->d_db) (void)hipFree(h->d_db);
     if (h->d_db_off) (void)hipFree(h->d_db_off);
@@ -542,44 +558,40 @@ int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_sampl
     // i + 1 runs under the kernels of chunk i (from pinned host memory; a pageable source is staged
     // by the runtime and overlaps only partly)
     const int64_t chunk = std::min<int64_t>(n_clips, std::max<int64_t>(1, (192ll << 20) / (n_samples * 2)));
-    int16_t *d_pcm[2] = {nullptr, nullptr};
-    uint64_t *d_hp = nullptr;
-    hipStream_t s_copy = nullptr, s_comp = nullptr;
-    hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
-    rc = 0;
-    bool ok = hipMalloc((void **)&d_hp, (size_t)n_clips * std::max<int64_t>(g.n_hp, 1) * 8) == hipSuccess;
-    for (int b = 0; b < 2 && ok; ++b)
-        ok = hipMalloc((void **)&d_pcm[b], (size_t)chunk * n_samples * 2) == hipSuccess &&
-             hipEventCreateWithFlags(&copied[b], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&s_comp, hipStreamNonBlocking) == hipSuccess;
-    if (!ok) rc = fail(HPFW_E_NOMEM, "hipMalloc / stream creation failed");
+    if ((rc = ensure(&h->stage_hp, &h->stage_hp_cap, (size_t)n_clips * std::max<int64_t>(g.n_hp, 1) * 8))) return rc;
+    for (int b = 0; b < 2; ++b) {
+        if (b == 1 && chunk >= n_clips) break; // one chunk: one buffer
+        if ((rc = ensure(&h->stage_pcm[b], &h->stage_pcm_cap[b], (size_t)chunk * n_samples * 2))) return rc;
+    }
+    if (!h->stage_copy) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stage_copy, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&h->stage_comp, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipEventCreateWithFlags(&h->stage_copied[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->stage_consumed[b], hipEventDisableTiming));
+        }
+    }
+    hipStream_t s_copy = h->stage_copy, s_comp = h->stage_comp;
+    uint64_t *d_hp = (uint64_t *)h->stage_hp;
     int64_t ci = 0;
     for (int64_t c0 = 0; !rc && c0 < n_clips; c0 += chunk, ++ci) {
         const int b = (int)(ci & 1);
         const int64_t cnt = std::min(chunk, n_clips - c0);
-        if (ci >= 2 && hipStreamWaitEvent(s_copy, consumed[b], 0) != hipSuccess) rc = fail(HPFW_E_HIP, "event wait failed");
-        if (!rc && hipMemcpyAsync(d_pcm[b], pcm + c0 * n_samples, (size_t)cnt * n_samples * 2, hipMemcpyHostToDevice,
-                                  s_copy) != hipSuccess)
+        int16_t *d_pcm = (int16_t *)h->stage_pcm[b];
+        if (ci >= 2 && hipStreamWaitEvent(s_copy, h->stage_consumed[b], 0) != hipSuccess) rc = fail(HPFW_E_HIP, "event wait failed");
+        if (!rc && hipMemcpyAsync(d_pcm, pcm + c0 * n_samples, (size_t)cnt * n_samples * 2, hipMemcpyHostToDevice, s_copy) !=
+                       hipSuccess)
             rc = fail(HPFW_E_HIP, "H2D copy failed");
-        if (!rc && (hipEventRecord(copied[b], s_copy) != hipSuccess || hipStreamWaitEvent(s_comp, copied[b], 0) != hipSuccess))
+        if (!rc && (hipEventRecord(h->stage_copied[b], s_copy) != hipSuccess ||
+                    hipStreamWaitEvent(s_comp, h->stage_copied[b], 0) != hipSuccess))
             rc = fail(HPFW_E_HIP, "event record failed");
-        if (!rc) rc = hpfw_gpu_extract_pcm16(h, d_pcm[b], n_samples, cnt, d_hp + c0 * g.n_hp, s_comp);
-        if (!rc && hipEventRecord(consumed[b], s_comp) != hipSuccess) rc = fail(HPFW_E_HIP, "event record failed");
+        if (!rc) rc = hpfw_gpu_extract_pcm16(h, d_pcm, n_samples, cnt, d_hp + c0 * g.n_hp, s_comp);
+        if (!rc && hipEventRecord(h->stage_consumed[b], s_comp) != hipSuccess) rc = fail(HPFW_E_HIP, "event record failed");
     }
-    if (s_copy && hipStreamSynchronize(s_copy) != hipSuccess && !rc) rc = fail(HPFW_E_HIP, "H2D copy failed");
-    if (s_comp && hipStreamSynchronize(s_comp) != hipSuccess && !rc) rc = fail(HPFW_E_HIP, "kernel execution failed");
-    if (!rc && hipMemcpy(hp, d_hp, (size_t)n_clips * g.n_hp * 8, hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipStreamSynchronize(s_copy) != hipSuccess && !rc) rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (!rc && hipMemcpyAsync(hp, d_hp, (size_t)n_clips * g.n_hp * 8, hipMemcpyDeviceToHost, s_comp) != hipSuccess)
         rc = fail(HPFW_E_HIP, "D2H copy failed");
-    for (int b = 0; b < 2; ++b) {
-        if (d_pcm[b]) (void)hipFree(d_pcm[b]);
-        if (copied[b]) (void)hipEventDestroy(copied[b]);
-        if (consumed[b]) (void)hipEventDestroy(consumed[b]);
-    }
-    if (d_hp) (void)hipFree(d_hp);
-    if (s_copy) (void)hipStreamDestroy(s_copy);
-    if (s_comp) (void)hipStreamDestroy(s_comp);
+    if (hipStreamSynchronize(s_comp) != hipSuccess && !rc) rc = fail(HPFW_E_HIP, "kernel execution failed");
     return rc;
 }
 
