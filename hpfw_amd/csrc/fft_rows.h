@@ -323,7 +323,7 @@ HPFW_DEVICE void rows_body_from(Lds &lds, const RowsArgs &a, int nthreads, const
     HPFW_FOR_THREADS(tid, nthreads)
     {
         // loads in batches of kLd so that their latencies overlap
-        constexpr int kLd = 9;
+        constexpr int kLd = 13;
         for (int t0 = tid; t0 < n2; t0 += kLd * nthreads) {
             decltype(load.raw(0)) p[kLd];
 #pragma unroll
