@@ -88,7 +88,8 @@ __global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, co
 //   cr <  K1 : k1 = k1lo + cr           -> X[n2 k1 + k2]
 //   cr >= K1 : k1' = n1 - 1 - k1        -> X[n2 k1 + (n2 - k2)] = conj(.)      (X[k] = conj X[N - k])
 // One wave = one tile of 32 columns x NT row tiles of 32 (16 complex rows each); no LDS, no barriers.
-constexpr int kColsStep = 16; // MFMA k-steps (residues) per register block
+// kColsStep = MFMA k-steps (residues) per register block, a template argument: the loop runs an even number
+// of blocks, so the launcher picks the step that pads n1 least (n1 = 210: 14 blocks of 15, where 16 pads to 224)
 
 // Operands come through buffer loads: lane part of the address in one VGPR that never changes, the
 // residue step in an SGPR, the row-tile step in the instruction's immediate -- no vector address
@@ -99,7 +100,7 @@ __device__ __forceinline__ float cols_ld(__amdgpu_buffer_rsrc_t r, int voff, int
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-template <int NT>
+template <int NT, int kColsStep>
 __global__ __launch_bounds__(256, 2) void fwd_cols_kernel(ColsArgs ca, int tile0, const float *__restrict__ yp,
                                                           cf *__restrict__ x)
 {
@@ -219,18 +220,33 @@ void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_src, int n_clips, float *
         launch_rows_t<RuntimeGroups>(a, d_src, n_clips, d_yp, s);
 }
 
-void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s)
+template <int STEP>
+static void launch_cols_step(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s)
 {
     dim3 grid(((ca.h + 31) / 32 + 3) / 4, n_clips);
     for (int t0 = 0; t0 < ca.n_tiles; t0 += 3) {
         const int nt = ca.n_tiles - t0 < 3 ? ca.n_tiles - t0 : 3;
         if (nt == 3)
-            hipLaunchKernelGGL(fwd_cols_kernel<3>, grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
+            hipLaunchKernelGGL((fwd_cols_kernel<3, STEP>), grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
         else if (nt == 2)
-            hipLaunchKernelGGL(fwd_cols_kernel<2>, grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
+            hipLaunchKernelGGL((fwd_cols_kernel<2, STEP>), grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
         else
-            hipLaunchKernelGGL(fwd_cols_kernel<1>, grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
+            hipLaunchKernelGGL((fwd_cols_kernel<1, STEP>), grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
     }
+}
+
+void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s)
+{
+    auto padded = [&](int step) { return ((ca.n1 + step - 1) / step + 1) / 2 * 2 * step; }; // residues the loop walks
+    int best = 16;
+    for (int step : {15, 14})
+        if (padded(step) < padded(best)) best = step;
+    if (best == 16)
+        launch_cols_step<16>(ca, d_yp, n_clips, d_x, s);
+    else if (best == 15)
+        launch_cols_step<15>(ca, d_yp, n_clips, d_x, s);
+    else
+        launch_cols_step<14>(ca, d_yp, n_clips, d_x, s);
 }
 
 // host: coefficient image of the column DFT for the MFMA A operand, [a][tile][lane]:
