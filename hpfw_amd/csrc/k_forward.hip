@@ -21,7 +21,7 @@ extern __shared__ __align__(16) unsigned char smem_raw[];
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kPairsTileMax = 64; // time steps per tile; fewer when n1 is large (the tile lives in LDS)
+constexpr int kPairsTileMax = 128; // time steps per tile; fewer when n1 is large (the tile lives in LDS)
 
 // VEC: the tile (nt * n1 samples) is copied in 16-byte pieces -- the launcher checks that every tile
 // starts 16-byte aligned and holds a multiple of 8 samples; otherwise sample by sample.
