@@ -53,33 +53,36 @@ __global__ __launch_bounds__(kPjThreads, 3) void project_kernel(const float *__r
     for (int i = 0; i < kPjTp / 2; ++i) a_cur[i] = ap[i];
 
     // S slab staging split in two (load to registers early, write to LDS late): the loads of chunk
-    // i + 1 are in flight while chunk i feeds the MFMAs, so HBM latency never stalls the matrix pipe
-    constexpr int kStage = (kPjBinsPerChunk * kPjCols + kPjThreads - 1) / kPjThreads; // 12 words per thread
+    // i + 1 are in flight while chunk i feeds the MFMAs, so HBM latency never stalls the matrix pipe.
+    // Thread t takes column t of each of the 11 bins (row base in scalar registers, t in one vector
+    // register: no per-element address arithmetic to keep alive across the chunk) and threads 0..208 one
+    // element of the 19-column tail.
+    constexpr int kTail = kPjCols - kPjTileN;             // 19
+    constexpr int kStage = kPjBinsPerChunk + 1;           // 12 words per thread
     float stage[kStage];
+    const bool main_in = n0 + tid < c;
+    const int tb = tid / kTail, tc = kPjTileN + (tid - tb * kTail); // the tail element of this thread
+    const bool tail_on = tid < kPjBinsPerChunk * kTail, tail_in = tail_on && n0 + tc < c;
     auto stage_load = [&](int chunk) {
+        const float *Sc = S + (int64_t)chunk * kPjBinsPerChunk * c + n0;
 #pragma unroll
-        for (int j = 0; j < kStage; ++j) {
-            const int i = tid + j * kPjThreads;
-            const int b = i / kPjCols;
-            const int col = i - b * kPjCols;
-            const int gc = n0 + col;
-            stage[j] = (i < kPjBinsPerChunk * kPjCols && gc < c)
-                           ? S[(int64_t)(chunk * kPjBinsPerChunk + b) * c + gc] : 0.0f;
-        }
+        for (int bb = 0; bb < kPjBinsPerChunk; ++bb) stage[bb] = main_in ? Sc[(int64_t)bb * c + tid] : 0.0f;
+        stage[kPjBinsPerChunk] = tail_in ? Sc[(int64_t)tb * c + tc] : 0.0f;
     };
     auto stage_store = [&](float *s_tile) {
+        // the dB conversion waits until here so that the loads stay in flight behind the MFMAs
+        // (columns past the clip get a meaningless value: only frames >= nf, never stored, see them)
 #pragma unroll
         for (int j = 0; j < kStage; ++j) {
-            const int i = tid + j * kPjThreads;
-            const int b = i / kPjCols;
-            // the dB conversion waits until here so that the loads stay in flight behind the MFMAs
-            // (columns past the clip get a meaningless value: only frames >= nf, never stored, see them)
             float v = stage[j];
             if (FROM_T) {
                 const float l = v - ref;
                 v = l < -80.0f ? -80.0f : l;
             }
-            if (i < kPjBinsPerChunk * kPjCols) s_tile[b * kPjRow + (i - b * kPjCols)] = v;
+            if (j < kPjBinsPerChunk)
+                s_tile[j * kPjRow + tid] = v;
+            else if (tail_on)
+                s_tile[tb * kPjRow + tc] = v;
         }
     };
     stage_load(0);
