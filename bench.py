@@ -13,6 +13,7 @@ Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through
 python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,6 +30,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3                         # MI355X_MICROARCH.md: dens
 VALU_PAIR_PEAK = 256 * 4 * 32 * 2.4e9 / 4            # xor/popcount kernel: 4 VALU lane-ops per 64-bit pair
 MFMA_FP4_PEAK_PFLOPS = 10.07                         # MI355X_MICROARCH.md: dense FP4 MFMA (32x32x64 in 32 cycles/SIMD)
 FP4_PAIR_PEAK = MFMA_FP4_PEAK_PFLOPS * 1e15 / 2 / 64 # one pair = 64 multiply-adds of +-1
+SPEC_CLIPS = 8                                       # clips per rank taken from hpfw_amd.synth.gen_clip
 
 
 def synth_clips_gpu(torch, n_clips, n_samples, seed, device, chunk=25):
@@ -73,7 +75,11 @@ def main():
     ap.add_argument("--stream-clips", type=int, default=125000, help="stream: indexed clips per GPU (1 M / 8)")
     ap.add_argument("--stream-queries", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips-per-core", type=int, default=64)
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the oracle altogether (profiling runs: nothing but the product in the process)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) section")
+    ap.add_argument("--cpu-clips-per-core", type=int, default=4,
+                    help="CPU baseline sample: clips per host thread (about 10 s of CPU work)")
     args = ap.parse_args()
 
     import torch
@@ -119,6 +125,15 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     pcm = synth_clips_gpu(torch, n_clips, n_samples, 0x68706677 + rank, device)
+    # the first clips come from the generator the tests use (hpfw_amd.synth.gen_clip);
+    # clip 0's SHA-256 is committed in tests/golden/clip0.sha256 and checked below
+    n_spec = min(SPEC_CLIPS, n_clips)
+    spec = np.stack([synth.gen_clip(rank * SPEC_CLIPS + i, args.seconds) for i in range(n_spec)])
+    pcm[:n_spec] = torch.from_numpy(spec).to(device)
+    clip0_sha = hashlib.sha256(spec[0].tobytes()).hexdigest() if rank == 0 else None
+    if rank == 0 and n_samples == 1323000:
+        committed = open(os.path.join(ROOT, "tests", "golden", "clip0.sha256")).read().split()[0]
+        assert clip0_sha == committed, "bench clip 0 is not the committed synthetic clip"
     hp = torch.empty((n_clips, geo.n_hp), dtype=torch.int64, device=device)
     torch.cuda.synchronize()
 
@@ -173,30 +188,53 @@ def main():
     split = {k: round(v[0], 3) for k, v in gpu.kernel_timing().items() if v[1]}
     gpu.set_kernel_timing(0)
 
-    # parity sample: a few clips of the batch against the oracle (checker only, outside any timing)
+    # parity and the CPU baseline (checker / reported baseline only, outside any timing): the oracle extracts a
+    # bounded sample of the same clips on the host cores and EVERY hashprint it produced is compared
     parity = None
     cpu_baseline = None
-    if rank == 0:
+    if rank == 0 and not args.no_parity:
         from oracle import oracle
         plan = oracle.Plan(n_samples)
-        idx = sorted(set([0, n_clips // 2, n_clips - 1]))
-        host = pcm[idx].cpu().numpy()
-        want = np.stack([plan.extract(filt, c) for c in host])
-        got = hp[idx].cpu().numpy().view(np.uint64)
-        parity = {"clips_checked": len(idx), "bit_identical": bool(np.array_equal(got, want))}
+        got_all = hp.cpu().numpy().view(np.uint64)
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
-            n_cpu = min(n_clips, max(cores, args.cpu_clips_per_core * cores))
+            n_cpu = min(n_clips, max(1, args.cpu_clips_per_core * cores))
             sample = pcm[:n_cpu].cpu().numpy()
             t1 = time.perf_counter()
-            plan.extract_batch(filt, sample, n_threads=cores)
+            want = plan.extract_batch(filt, sample, n_threads=cores)
             cdt = time.perf_counter() - t1
+            idx = np.arange(n_cpu)
+            # one thread, stage by stage (4 clips): where the CPU path spends its time
+            st = {"spectrum": 0.0, "cq": 0.0, "db": 0.0, "project": 0.0, "pack": 0.0}
+            n_one = min(4, n_cpu)
+            t_one = time.perf_counter()
+            for c in sample[:n_one]:
+                ta = time.perf_counter(); x = plan.spectrum(c)
+                tb = time.perf_counter(); m = plan.cqmag(x)
+                tc = time.perf_counter(); d = oracle.db(m)
+                td = time.perf_counter(); pr = oracle.project(filt, d)
+                te = time.perf_counter(); oracle.pack(pr)
+                tf = time.perf_counter()
+                for key, dtk in zip(st, (tb - ta, tc - tb, td - tc, te - td, tf - te)):
+                    st[key] += dtk
+            one_dt = time.perf_counter() - t_one
             cpu_baseline = {"value": round(n_cpu * geo.n_hp / cdt, 1), "unit": "hashprints/s", "cores": cores,
                             "kind": "port",
                             "sample": f"{n_cpu} of the same {args.seconds:g} s clips, oracle/hpfw_oracle.c "
                                       f"(own C restatement, -O3 -mfma, no FFTW/Eigen/TBB on this box), "
                                       f"{cores} threads in static chunks as flow_builder.hpp:321-325, {cdt:.1f} s",
-                            "clips_per_s": round(n_cpu / cdt, 2)}
+                            "clips_per_s": round(n_cpu / cdt, 2),
+                            "one_thread": {"clips_per_s": round(n_one / one_dt, 2), "clips": n_one,
+                                           "ms_per_clip_by_stage": {k: round(v * 1e3 / n_one, 1) for k, v in st.items()}}}
+        else:
+            idx = np.array(sorted(set([0, n_clips // 2, n_clips - 1])))
+            want = np.stack([plan.extract(filt, c) for c in pcm[idx].cpu().numpy()])
+        parity = {"clips_checked": int(len(idx)), "bit_identical": bool(np.array_equal(got_all[idx], want)),
+                  "hashprints_differing": int((got_all[idx] != want).sum())}
+
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_pcie:
+        pcie = bench_pcie(torch, gpu, pcm, n_samples, geo, hp)
 
     search = None
     if not args.no_search:
@@ -221,11 +259,15 @@ def main():
             "config": {"workload": f"configs[1]: {n_clips} x {args.seconds:g} s synthetic 44.1 kHz PCM16 clips per GPU, "
                                    "hashprint extraction only (CQT + dB + projection + bit pack), inputs resident in HBM",
                        "clips_per_gpu": n_clips, "clip_seconds": args.seconds, "hashprints_per_clip": geo.n_hp,
+                       "generator": f"clips 0..{n_spec - 1} of every rank: hpfw_amd.synth.gen_clip (the tests' generator); "
+                                    "the rest: the same recipe with the device RNG",
+                       "clip0_sha256": clip0_sha,
                        "parallelism": f"clips sharded over {world} GPU(s), no collective on this path"},
             "clips_per_s": round(value / geo.n_hp, 1),
             "event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
             "kernel_ms_one_pass": split,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "search": search,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "pcie_inclusive": pcie, "search": search,
             "stream": stream_res, "filter_learning": learn,
         }
         print(json.dumps(line), flush=True)
@@ -310,6 +352,33 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
             "scan_kernel": _scan_roofline(scan_rate)}
 
 
+def bench_pcie(torch, gpu, pcm, n_samples, geo, hp_dev, n=256):
+    """the same extraction handed HOST buffers (hpfw_gpu_extract_pcm16_host: pinned int16 in, hashprints out;
+    uploads in chunks on a copy stream under the kernels of the previous chunk).  Never `value`."""
+    n = min(n, pcm.shape[0])
+    host = torch.empty((n, n_samples), dtype=torch.int16).pin_memory()
+    host.copy_(pcm[:n])
+    out = torch.empty((n, geo.n_hp), dtype=torch.int64).pin_memory()
+    import ctypes
+    L = __import__("hpfw_amd").lib()
+
+    def run():
+        rc = L.hpfw_gpu_extract_pcm16_host(gpu._h, ctypes.c_void_p(host.data_ptr()), n_samples, n,
+                                           ctypes.c_void_p(out.data_ptr()))
+        assert rc == 0, L.hpfw_gpu_last_error()
+
+    run()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        run()
+    dt = (time.perf_counter() - t0) / reps
+    same = bool(torch.equal(out, hp_dev[:n].cpu()))
+    return {"clips_per_s": round(n / dt, 1), "hashprints_per_s": round(n * geo.n_hp / dt, 1),
+            "pcm_gb_per_s": round(n * n_samples * 2 / dt / 1e9, 2), "clips": n, "same_hashprints": same,
+            "note": "host pinned int16 PCM in, host hashprints out; bounded by the PCIe link (2.65 MB per 30 s clip)"}
+
+
 def bench_learn(torch, gpu, args, pcm, n_samples, stream, filt):
     """index()-only work: frame covariance of the first clips of the
     batch accumulated on the GPU (front end included), then the eigen-solve on the host."""
@@ -346,11 +415,35 @@ def bench_stream(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
     g = torch.Generator(device=device)
     g.manual_seed(0x57E + rank)
     db = torch.randint(-2 ** 63, 2 ** 63 - 1, (n_local, n_hp), dtype=torch.int64, generator=g, device=device)
+    # planted songs: 16 synthetic 30 s songs (the same on every rank) extracted here and stored at known global clip
+    # ids, spread over the shards; every streamed window is a noisy 5 s slice of one of them, so each round's
+    # top-1 (clip, offset) is known and checked
+    n_songs, song_samples = 16, 30 * 44100
+    songs = synth_clips_gpu(torch, n_songs, song_samples, 0x50f6, device)
+    song_hp = torch.empty((n_songs, n_hp), dtype=torch.int64, device=device)
+    gpu.extract_dev(songs.data_ptr(), song_samples, n_songs, song_hp.data_ptr(), stream)
+    total = n_local * world
+    song_clip = [(7 + i * (total // n_songs + 1)) % total for i in range(n_songs)]
+    for i, gc in enumerate(song_clip):
+        if gc // n_local == rank:
+            db[gc % n_local] = song_hp[i]
     gpu.index_clear()
     gpu.index_set_clip_base(rank * n_local)
     gpu.index_add_dev(db.data_ptr(), np.arange(0, (n_local + 1) * n_hp, n_hp, dtype=np.int64), stream)
+    torch.cuda.synchronize()
     del db
-    pcm = synth_clips_gpu(torch, n_q, q_samples, 0x57E, device)          # the same queries on every rank
+    gq = torch.Generator(device=device)
+    gq.manual_seed(0x57F)                                                 # the same windows on every rank
+    q_song = [i % n_songs for i in range(n_q)]
+    q_start = [44100 * (1 + (i * 5) % 23) for i in range(n_q)]
+    pcm = torch.empty((n_q, q_samples), dtype=torch.int16, device=device)
+    for i in range(n_q):
+        seg = 0.5 * songs[q_song[i], q_start[i]:q_start[i] + q_samples].to(torch.float32)
+        noise = torch.randn(q_samples, generator=gq, device=device) * (seg.pow(2).mean().sqrt() * 10 ** (-10 / 20))
+        pcm[i] = torch.clamp(torch.round(seg + noise), -32768, 32767).to(torch.int16)
+    hop = 1323000 / 7255 * 3                                              # samples per spectrogram column
+    want_clip = np.array([song_clip[s] for s in q_song])
+    want_off = np.array(q_start) / hop
     out = {}
     for batch in (1, 32):
         nb = n_q // batch
@@ -360,11 +453,13 @@ def bench_stream(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
                                device="cpu" if rehearse else device) if world > 1 else None
         q_off = np.arange(0, (batch + 1) * geo.n_hp, geo.n_hp, dtype=np.int64)
         lat = []
+        wrong = 0
         barrier()
         for i in range(nb + 2):
+            first = i % nb * batch
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            gpu.extract_dev(pcm[i % nb * batch].data_ptr(), q_samples, batch, d_hp.data_ptr(), stream)
+            gpu.extract_dev(pcm[first].data_ptr(), q_samples, batch, d_hp.data_ptr(), stream)
             gpu.search_topk_dev(d_hp.data_ptr(), q_off, args.topk, hits.data_ptr(), stream)
             if world > 1 and rehearse:
                 tdist.all_gather([gathered[r] for r in range(world)], hits.cpu())
@@ -374,16 +469,20 @@ def bench_stream(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
                 res = gathered.cpu().numpy()
             else:
                 res = hits.cpu().numpy()
-            if world > 1:
-                hpfw_amd.merge_topk(res.reshape(world, batch, args.topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(
-                    world, batch, args.topk), args.topk)
+            res = res.reshape(-1, batch, args.topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(-1, batch, args.topk)
+            final = hpfw_amd.merge_topk(res, args.topk) if world > 1 else res[0]
             if i >= 2:                                                       # two warm-up rounds
                 lat.append((time.perf_counter() - t0) * 1e3)
+            top = final[:, 0]                                                 # outside the timed span: check the hits
+            wrong += int(((top["clip"] != want_clip[first:first + batch]) |
+                          (np.abs(top["offset"] - want_off[first:first + batch]) > 2)).sum())
         lat = np.sort(np.array(lat))
         qps = batch * 1e3 / float(lat.mean())
         out[f"batch_{batch}"] = {"latency_ms_p50": round(float(np.percentile(lat, 50)), 3),
                                  "latency_ms_p99": round(float(np.percentile(lat, 99)), 3),
-                                 "queries_per_s": round(qps, 1), "realtime_5s_streams": int(qps * 5), "rounds": int(lat.size)}
+                                 "queries_per_s": round(qps, 1), "realtime_5s_streams": int(qps * 5), "rounds": int(lat.size),
+                                 "windows_checked": int((nb + 2) * batch), "wrong_hits": wrong}
+    out["planted_windows_found"] = all(v["wrong_hits"] == 0 for v in out.values() if isinstance(v, dict))
     out["workload"] = (f"configs[4] per GPU: {n_local}-clip index shard ({n_local * n_hp * 8 / 1e9:.2f} GB of hashprints) "
                        f"in HBM, 5 s PCM windows -> extraction -> top-{args.topk} scan"
                        + (f" -> all-gather over {world} ranks + merge" if world > 1 else "") + " -> host, measured on rank 0")

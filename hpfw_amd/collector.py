@@ -16,12 +16,24 @@ class ParallelCollector:
         if not self.__collector:
             raise _lib.HpfwError("par_collector_new failed: " + self.__lib.hpfw_gpu_last_error().decode())
 
+    @staticmethod
+    def _c_strings(filenames):
+        """a C array of NUL-terminated UTF-8 paths"""
+        raw = [str(f).encode("utf-8") for f in filenames]
+        return (ctypes.c_char_p * len(raw))(*raw)
+
     def prepare(self, filenames) -> List[Tuple[np.ndarray, str]]:
         """pyhpfw.py:46-61: list of (uint64 array, stem) -- array first, as the reference returns."""
-        pyarr = [f.encode("utf-8") for f in filenames]
-        arr = (ctypes.c_char_p * len(pyarr))(*pyarr)
-        got = ctypes.c_int(0)
-        hps = self.__lib.par_collector_prepare(self.__collector, arr, len(pyarr), ctypes.byref(got))
+        names = self._c_strings(filenames)
+        n_got = ctypes.c_int(0)
+        hps = self.__lib.par_collector_prepare(self.__collector, names, len(names), ctypes.byref(n_got))
+        if not hps or (n_got.value == 0 and len(names)):
+            # eigen-solve failure, out of memory, or every file unreadable: the C++ facade throws here too
+            why = self.__lib.hpfw_gpu_last_error().decode()
+            if hps:
+                self.__lib.prepare_result_free(hps, 0)
+            raise _lib.HpfwError("prepare failed: " + why)
+        got = n_got
         out = []
         for h in range(got.value):
             n = hps[h].hp_size
@@ -45,9 +57,8 @@ class ParallelCollector:
     def calc_hashprints(self, filenames) -> List[Tuple[np.ndarray, str]]:
         """calc_hashprint for many files in one batched call (not in the reference's class): a list of
         (uint64 array or None for a file that failed, stem), one entry per file, in input order"""
-        pyarr = [f.encode("utf-8") for f in filenames]
-        arr = (ctypes.c_char_p * len(pyarr))(*pyarr)
-        hps = self.__lib.par_collector_calc_hashprints(self.__collector, arr, len(pyarr))
+        pyarr = self._c_strings(filenames)
+        hps = self.__lib.par_collector_calc_hashprints(self.__collector, pyarr, len(pyarr))
         if not hps:
             raise _lib.HpfwError("calc_hashprints failed: " + self.__lib.hpfw_gpu_last_error().decode())
         out = []

@@ -144,6 +144,10 @@ struct hpfw_gpu {
     size_t clipmax_cap = 0;
     int *d_cov_tiles = nullptr;
     int64_t cov_files = 0;
+    // ordering of consecutive entry points that were handed different streams (the workspaces are shared)
+    hipEvent_t order_ev = nullptr;
+    hipStream_t order_stream = nullptr;
+    bool order_valid = false;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned timing_mask = 0;
@@ -165,6 +169,27 @@ int ensure(void **p, size_t *cap, size_t need)
     *cap = need;
     return 0;
 }
+
+// Every entry point of a handle works in the handle's shared workspaces (ws[], d_clipmax, d_best, d_qa, the
+// index itself ...) and only enqueues on the caller's stream.  Two calls on different streams (a torch
+// side stream and the null stream, or the private non-blocking streams of the *_host entry points) would
+// otherwise overlap on those buffers: each call first makes its stream wait for the event the previous
+// call recorded, and records its own when it has enqueued its work.
+struct Ordered {
+    hpfw_gpu *h;
+    hipStream_t s;
+    Ordered(hpfw_gpu *h_, hipStream_t s_) : h(h_), s(s_)
+    {
+        if (h->order_valid && h->order_stream != s) (void)hipStreamWaitEvent(s, h->order_ev, 0);
+    }
+    ~Ordered()
+    {
+        if (hipEventRecord(h->order_ev, s) == hipSuccess) {
+            h->order_valid = true;
+            h->order_stream = s;
+        }
+    }
+};
 
 struct Timed {
     hpfw_gpu *h;
@@ -433,7 +458,8 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     HIP_TRY(hipSetDevice(device));
     auto *h = new hpfw_gpu();
     h->device = device;
-    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) != hipSuccess) {
         delete h;
         return fail(HPFW_E_HIP, "hipEventCreate failed");
     }
@@ -484,6 +510,7 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     }
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     delete h;
 }
 
@@ -529,6 +556,7 @@ int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
     if (rc) return rc;
     if (dp->hp.n_hp <= 0) return fail(HPFW_E_UNSUPPORTED, "clip too short to yield a hashprint");
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     const int nbmax = pass_clips(h, dp, n_clips);
     const int nsmax = (int)std::min<int64_t>(std::max(kBackBatch, nbmax), std::max<int64_t>(n_clips, 1));
     if ((rc = ensure_ws(h, dp, nbmax, nsmax))) return rc;
@@ -605,6 +633,7 @@ int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples
     int rc = get_plan(h, n_samples, &dp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     const int nbmax = pass_clips(h, dp, n_clips);
     if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
@@ -633,6 +662,7 @@ int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64
     int rc = get_plan(h, n_samples, &dp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     const int nbmax = pass_clips(h, dp, n_clips);
     if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
@@ -656,6 +686,7 @@ int hpfw_gpu_stage_db(hpfw_gpu *h, const float *d_mag, int64_t n_clips, int64_t 
     if (!h || !d_mag || !d_db || c <= 0) return fail(HPFW_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     int rc;
     const int64_t per = 121 * c;
     const int nbmax = 1024;
@@ -677,6 +708,7 @@ int hpfw_gpu_stage_project(hpfw_gpu *h, const float *d_db, int64_t n_clips, int6
     if (!h->has_filters) return fail(HPFW_E_NOFILTERS, "no filters loaded: call hpfw_gpu_set_filters first");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     const int64_t nf = c - (hpfw::kCtx - 1);
     for (int64_t c0 = 0; c0 < n_clips; c0 += 16384) {
         const int nb = (int)std::min<int64_t>(16384, n_clips - c0);
@@ -692,6 +724,7 @@ int hpfw_gpu_stage_pack(hpfw_gpu *h, const float *d_proj, int64_t n_clips, int64
     if (!h || !d_proj || !d_hp || n_frames <= hpfw::kLag) return fail(HPFW_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     for (int64_t c0 = 0; c0 < n_clips; c0 += 16384) {
         const int nb = (int)std::min<int64_t>(16384, n_clips - c0);
         hpfw::launch_pack(d_proj + c0 * 64 * n_frames, nb, (int)n_frames, d_hp + c0 * (n_frames - hpfw::kLag), s);
@@ -776,6 +809,7 @@ int hpfw_gpu_mel_spectrogram_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_
     int rc = mel_prepare(h);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     const int nf = hpfw::mel_frames(n_samples), n_blk = (int)((n_samples + hpfw::kMelHop - 1) / hpfw::kMelHop);
     // clips per pass: the split spectra take 2 * 2208 floats per frame
     const int64_t per_clip = (int64_t)hpfw::mel_work_bytes(n_samples, 1);
@@ -852,6 +886,7 @@ int hpfw_gpu_cov_accumulate_db(hpfw_gpu *h, const float *d_db, int64_t n_clips, 
     if (!h || !d_db || n_clips < 0 || c < hpfw::kCtx + 1) return fail(HPFW_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     int rc = cov_prepare(h, s);
     if (rc) return rc;
     const int64_t chunk = 128; // clips per pass: bounds the workspace (Z, correction vectors, partial sums)
@@ -876,6 +911,7 @@ int hpfw_gpu_stage_spectrogram(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samp
     int rc = get_plan(h, n_samples, &dp);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     const int nbmax = pass_clips(h, dp, n_clips);
     if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     const size_t per = (size_t)121 * dp->hp.c;
@@ -897,6 +933,7 @@ int hpfw_gpu_cov_accumulate_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_s
     if (rc) return rc;
     if (dp->hp.n_frames < 2) return fail(HPFW_E_UNSUPPORTED, "clip too short for a covariance");
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     const int nbmax = pass_clips(h, dp, n_clips);
     if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
@@ -993,11 +1030,15 @@ static int index_add_impl(hpfw_gpu *h, const uint64_t *hp, const int64_t *offset
         if (offsets[i + 1] < offsets[i]) return fail(HPFW_E_INVALID, "offsets must be non-decreasing");
     const int64_t add = offsets[n_clips] - offsets[0];
     const int64_t have = h->db_off.back();
+    Ordered ordered(h, s);
     if ((size_t)(have + add) > h->db_cap) {
         size_t ncap = std::max<size_t>((size_t)(have + add), h->db_cap * 2);
         ncap = std::max<size_t>(ncap, 1 << 16);
         uint64_t *nd = nullptr;
         HIP_TRY(hipMalloc((void **)&nd, ncap * 8));
+        // earlier appends may still be in flight on a non-blocking stream the null-stream copy below would
+        // not wait for, and scans may still be reading the old buffer: growing is rare (capacity doubles)
+        HIP_TRY(hipDeviceSynchronize());
         if (have) HIP_TRY(hipMemcpy(nd, h->d_db, (size_t)have * 8, hipMemcpyDeviceToDevice));
         if (h->d_db) HIP_TRY(hipFree(h->d_db));
         h->d_db = nd;
@@ -1057,6 +1098,7 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
     if (!h || !q_off || !d_out || n_q < 0 || k < 1 || k > 64) return fail(HPFW_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
     if (n_q == 0) return 0;
     if (!d_q_hp) return fail(HPFW_E_INVALID, "null queries");
     const int64_t n_clips = (int64_t)h->db_off.size() - 1;
@@ -1082,6 +1124,7 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
     // queries are processed in groups so the (query, clip) table stays below 1 GiB
     int64_t qgroup = std::max<int64_t>(32, ((int64_t)1 << 27) / n_clips / 32 * 32);
     qgroup = std::min<int64_t>(qgroup, (n_q + 31) / 32 * 32);
+    qgroup = std::min<int64_t>(qgroup, (int64_t)65535 * 8 / 32 * 32); // the scans put groups of 8 / 32 queries along gridDim.y
     if ((rc = ensure((void **)&h->d_best, &h->best_cap, (size_t)qgroup * n_clips * 8))) return rc;
     // The scan runs on the matrix cores (k_search_mfma.hip) unless the window does not fit the LDS
     // (queries of several thousand hashprints) or HPFW_SEARCH_POPC asks for the xor/popcount kernel; fewer than
@@ -1160,6 +1203,7 @@ int hpfw_gpu_search_topk(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off
                          hpfw_hit *out)
 {
     if (!h || !q_off || !out || n_q < 0) return fail(HPFW_E_INVALID, "bad argument");
+    if (k < 1 || k > 64) return fail(HPFW_E_INVALID, "k must be in 1..64");
     HIP_TRY(hipSetDevice(h->device));
     if (n_q == 0) return 0;
     const int64_t total = q_off[n_q] - q_off[0];
@@ -1207,8 +1251,10 @@ int knn_windows_impl(hpfw_gpu *h, const uint64_t *q_hp, const int64_t *q_off, in
     int64_t n_max = 0;
     for (int64_t i = 0; i < n_clips; ++i) n_max = std::max(n_max, h->db_off[i + 1] - h->db_off[i]);
     if (n_win == 0 || n_max < kVoteWin) return 0;
-    if (n_win > (int64_t)1 << 24) return fail(HPFW_E_UNSUPPORTED, "too many query windows in one call");
+    // one launch: groups of 32 windows along gridDim.y (at most 65535)
+    if (n_win > (int64_t)65535 * 32) return fail(HPFW_E_UNSUPPORTED, "too many query windows in one call (limit 2097120)");
     int rc;
+    Ordered ordered(h, nullptr);
     if (h->db_off_dirty) {
         if ((rc = ensure((void **)&h->d_db_off, &h->db_off_cap, h->db_off.size() * 8))) return rc;
         HIP_TRY(hipMemcpy(h->d_db_off, h->db_off.data(), h->db_off.size() * 8, hipMemcpyHostToDevice));

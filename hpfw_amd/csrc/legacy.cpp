@@ -17,6 +17,7 @@
 #include <filesystem>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -262,6 +263,8 @@ struct Loaded {
 // threads decodes one window of files while the device stages take whole groups of clips
 void read_window(const char **filenames, const std::vector<int> &files, size_t first, size_t last, std::vector<Loaded> &out)
 {
+    std::mutex why_mtx;
+    std::string first_why; // the reader threads' messages are thread-local: keep the first failure for the caller
     const int count = (int)(last - first);
     out.assign((size_t)count, Loaded());
     unsigned team = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -271,13 +274,17 @@ void read_window(const char **filenames, const std::vector<int> &files, size_t f
         for (int i; (i = next.fetch_add(1)) < count;) {
             std::string why;
             out[(size_t)i].ok = read_clip(filenames[files[first + (size_t)i]], out[(size_t)i].pcm, why);
-            if (!out[(size_t)i].ok) hpfw_internal_set_error(why.c_str()); // thread-local: informational only
+            if (!out[(size_t)i].ok) {
+                std::scoped_lock lock(why_mtx);
+                if (first_why.empty()) first_why = why;
+            }
         }
     };
     std::vector<std::thread> th;
     for (unsigned t = 1; t < team; ++t) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+    if (!first_why.empty()) hpfw_internal_set_error(first_why.c_str()); // skipped files (parallel_collector.h:101-103): the message survives
 }
 
 struct DevMem {

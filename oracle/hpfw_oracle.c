@@ -821,48 +821,41 @@ void hpfw_oracle_match_clip(const uint64_t *q, int64_t k, const uint64_t *r, int
     *best_off = boff;
 }
 
+/* Two steps so that every host thread has work whatever the shape (many queries x few clips, or a handful of
+ * queries against 10^5 clips): (1) the per-(query, clip) table of storage.h:33-54 results, work items claimed in
+ * blocks from a shared counter; (2) per query, the top-k of its row. */
 typedef struct {
     const uint64_t *db;
     const int64_t *db_off;
     int64_t n_clips;
     const uint64_t *q;
     const int64_t *q_off;
-    int topk;
-    hpfw_oracle_hit *out;
-    int64_t lo, hi;
+    int64_t n_q;
+    uint32_t *t_dist; /* [n_q][n_clips]; 0xffffffff = the pair was skipped (empty clip or query) */
+    int32_t *t_off;
+    int64_t next;     /* shared work counter (blocks of 16 pairs) */
 } search_job;
 
 static void *search_worker(void *arg)
 {
     search_job *s = (search_job *)arg;
-    for (int64_t qi = s->lo; qi < s->hi; ++qi) {
-        hpfw_oracle_hit *top = s->out + qi * s->topk;
-        int have = 0;
-        for (int t = 0; t < s->topk; ++t) {
-            top[t].dist = 0xffffffffu;
-            top[t].clip = 0xffffffffu;
-            top[t].offset = 0;
-            top[t].pad = 0;
-        }
-        for (int64_t cidx = 0; cidx < s->n_clips; ++cidx) {
+    const int64_t total = s->n_q * s->n_clips, blk = 16;
+    for (;;) {
+        int64_t lo = __atomic_fetch_add(&s->next, blk, __ATOMIC_RELAXED);
+        if (lo >= total) break;
+        int64_t hi = lo + blk > total ? total : lo + blk;
+        for (int64_t w = lo; w < hi; ++w) {
+            int64_t qi = w / s->n_clips, cidx = w % s->n_clips;
             int64_t n = s->db_off[cidx + 1] - s->db_off[cidx];
             int64_t k = s->q_off[qi + 1] - s->q_off[qi];
+            s->t_dist[w] = 0xffffffffu;
+            s->t_off[w] = 0;
             if (n <= 0 || k <= 0) continue;
             uint64_t d;
             int64_t off;
             hpfw_oracle_match_clip(s->q + s->q_off[qi], k, s->db + s->db_off[cidx], n, &d, &off);
-            /* insertion by ascending (dist, clip): clips arrive in ascending id, so a strict
-             * comparison on dist keeps the earlier clip first (storage.h:56) */
-            int pos = have;
-            while (pos > 0 && top[pos - 1].dist > d) --pos;
-            if (pos >= s->topk) continue;
-            int last = have < s->topk ? have : s->topk - 1;
-            for (int t = last; t > pos; --t) top[t] = top[t - 1];
-            top[pos].dist = (uint32_t)d;
-            top[pos].clip = (uint32_t)cidx;
-            top[pos].offset = (int32_t)off;
-            top[pos].pad = 0;
-            if (have < s->topk) ++have;
+            s->t_dist[w] = (uint32_t)d;
+            s->t_off[w] = (int32_t)off;
         }
     }
     return NULL;
@@ -874,19 +867,48 @@ void hpfw_oracle_search_topk(const uint64_t *db, const int64_t *db_off, int64_t 
 {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
+    const int64_t total = n_q * n_clips;
+    search_job job = {db, db_off, n_clips, q, q_off, n_q, NULL, NULL, 0};
+    job.t_dist = (uint32_t *)malloc((size_t)(total > 0 ? total : 1) * sizeof(uint32_t));
+    job.t_off = (int32_t *)malloc((size_t)(total > 0 ? total : 1) * sizeof(int32_t));
     pthread_t th[256];
-    search_job jobs[256];
-    int64_t chunk = (n_q + n_threads - 1) / n_threads;
     int used = 0;
-    for (int t = 0; t < n_threads; ++t) {
-        int64_t lo = t * chunk, hi = lo + chunk > n_q ? n_q : lo + chunk;
-        if (lo >= hi) break;
-        search_job jb = {db, db_off, n_clips, q, q_off, topk, out, lo, hi};
-        jobs[used] = jb;
-        pthread_create(&th[used], NULL, search_worker, &jobs[used]);
-        ++used;
+    if (n_threads > 1 && total > 16) {
+        for (int t = 0; t < n_threads && (int64_t)t * 16 < total; ++t)
+            if (pthread_create(&th[used], NULL, search_worker, &job) == 0) ++used;
     }
+    search_worker(&job);
     for (int t = 0; t < used; ++t) pthread_join(th[t], NULL);
+    for (int64_t qi = 0; qi < n_q; ++qi) {
+        hpfw_oracle_hit *top = out + qi * topk;
+        int have = 0;
+        for (int t = 0; t < topk; ++t) {
+            top[t].dist = 0xffffffffu;
+            top[t].clip = 0xffffffffu;
+            top[t].offset = 0;
+            top[t].pad = 0;
+        }
+        for (int64_t cidx = 0; cidx < n_clips; ++cidx) {
+            int64_t n = db_off[cidx + 1] - db_off[cidx];
+            int64_t k = q_off[qi + 1] - q_off[qi];
+            if (n <= 0 || k <= 0) continue;
+            const uint32_t d = job.t_dist[qi * n_clips + cidx];
+            /* insertion by ascending (dist, clip): clips arrive in ascending id, so a strict
+             * comparison on dist keeps the earlier clip first (storage.h:56) */
+            int pos = have;
+            while (pos > 0 && top[pos - 1].dist > d) --pos;
+            if (pos >= topk) continue;
+            int last = have < topk ? have : topk - 1;
+            for (int t = last; t > pos; --t) top[t] = top[t - 1];
+            top[pos].dist = d;
+            top[pos].clip = (uint32_t)cidx;
+            top[pos].offset = job.t_off[qi * n_clips + cidx];
+            top[pos].pad = 0;
+            if (have < topk) ++have;
+        }
+    }
+    free(job.t_dist);
+    free(job.t_off);
 }
 
 /* ------------------------------------------------------------------------------------------ */

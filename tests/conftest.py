@@ -46,6 +46,17 @@ def gpu(torch_cuda, filters):
     g.close()
 
 
+@pytest.fixture(params=["mfma", "shift", "popcount"])
+def scan_path(request):
+    """the three scan kernels: the fp4 matrix-core contraction over groups of 32 queries (default), its
+    one-query variant with shifted rows (default below 8 queries) and the xor/popcount kernel"""
+    import os
+    var = {"mfma": "HPFW_SEARCH_MFMA", "shift": "HPFW_SEARCH_SHIFT", "popcount": "HPFW_SEARCH_POPC"}[request.param]
+    os.environ[var] = "1"
+    yield request.param
+    os.environ.pop(var, None)
+
+
 def bits_equal(a, b):
     """bitwise equality of two float32 arrays, +0 == -0 excluded on purpose"""
     a = np.ascontiguousarray(a, np.float32).view(np.uint32)

@@ -281,3 +281,50 @@ def test_python_liveid_and_notebook_example(wav_set, oracle, filters, tmp_path):
     import pickle
     got = pickle.load(open(dump, "rb"))
     assert [n for _, n in got] == [f"track{i:02d}" for i in range(4)] and all(np.array_equal(a, b) for (a, _), b in zip(got, db))
+
+
+def test_streams_mixed_without_sync(torch_cuda, oracle, filters):
+    """One handle, three streams, no synchronisation by the caller: a device call on a non-blocking side
+    stream, the host entry point (its own private streams), a device call on the null stream and an index
+    that grows while appends are in flight.  The handle orders the calls itself (they share its workspaces):
+    every result equals the oracle's."""
+    torch = torch_cuda
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filters)
+    a = np.stack([synth.gen_clip(610 + i, 5.0) for i in range(6)])
+    b = np.stack([synth.gen_clip(620 + i, 3.0) for i in range(5)])
+    plan_a, plan_b = oracle.Plan(a.shape[1]), oracle.Plan(b.shape[1])
+    want_a = plan_a.extract_batch(filters, a, n_threads=6)
+    want_b = plan_b.extract_batch(filters, b, n_threads=5)
+    g.extract(a[:1]), g.extract(b[:1])                       # plans and workspaces exist before the mixing starts
+    side = torch.cuda.Stream()                               # torch side streams do not sync with the null stream
+    d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    hp_a = torch.zeros((6, plan_a.n_hp), dtype=torch.int64, device="cuda")
+    hp_b = torch.zeros((5, plan_b.n_hp), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        g.extract_dev(d_a.data_ptr(), a.shape[1], 6, hp_a.data_ptr(), side.cuda_stream)   # enqueued, not waited for
+        host_b = g.extract(b)                                                              # private streams
+        g.extract_dev(d_b.data_ptr(), b.shape[1], 5, hp_b.data_ptr(), 0)                   # null stream
+        host_a = g.extract(a)
+        torch.cuda.synchronize()
+        assert np.array_equal(host_a, want_a) and np.array_equal(host_b, want_b)
+        assert np.array_equal(hp_a.cpu().numpy().view(np.uint64), want_a)
+        assert np.array_equal(hp_b.cpu().numpy().view(np.uint64), want_b)
+        hp_a.zero_(), hp_b.zero_()
+        torch.cuda.synchronize()
+    # index appends on the side stream while the capacity doubles (the grow-copy must see them), then a
+    # search on the null stream
+    rng = np.random.default_rng(3)
+    n, per = 40, 3000                                        # 40 appends of 3000 hashprints: several doublings of 65536
+    clips = torch.from_numpy(rng.integers(-2 ** 63, 2 ** 63 - 1, size=(n, per), dtype=np.int64)).cuda()
+    torch.cuda.synchronize()
+    g.index_clear()
+    for i in range(n):
+        g.index_add_dev(clips[i].data_ptr(), np.array([0, per], np.int64), side.cuda_stream)
+    q = clips[31, 100:400].cpu().numpy().view(np.uint64)
+    hits = g.search_topk(q, np.array([0, q.size], np.int64), 2)
+    assert hits[0, 0]["clip"] == 31 and hits[0, 0]["offset"] == 100 and hits[0, 0]["dist"] == 0
+    hp, off = g.index_get()
+    assert np.array_equal(hp.view(np.int64).reshape(n, per), clips.cpu().numpy())
+    g.close()

@@ -191,17 +191,6 @@ def _ragged(rng, lens):
     return (np.concatenate(hp) if hp else np.zeros(0, np.uint64)), off
 
 
-@pytest.fixture(params=["mfma", "shift", "popcount"])
-def scan_path(request):
-    """the three scan kernels: the fp4 matrix-core contraction over groups of 32 queries (default), its
-    one-query variant with shifted rows (default below 8 queries) and the xor/popcount kernel"""
-    import os
-    var = {"mfma": "HPFW_SEARCH_MFMA", "shift": "HPFW_SEARCH_SHIFT", "popcount": "HPFW_SEARCH_POPC"}[request.param]
-    os.environ[var] = "1"
-    yield request.param
-    os.environ.pop(var, None)
-
-
 def test_search_matches_oracle(gpu, oracle, scan_path):
     rng = np.random.default_rng(11)
     db_lens = [2320, 305, 40, 1000, 2320, 1, 700, 305, 2320, 64, 333, 2000, 5]

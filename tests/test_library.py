@@ -134,3 +134,11 @@ def test_cpp_facade_compiles_and_links(tmp_path):
            "-Wl,-rpath-link,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_committed_sha_of_synthetic_clip_zero():
+    """bench.py and the tests draw clip 0 from the same generator: its SHA-256 is committed"""
+    import hashlib
+    from hpfw_amd import synth
+    want = open(os.path.join(ROOT, "tests", "golden", "clip0.sha256")).read().split()[0]
+    assert hashlib.sha256(synth.gen_clip(0, 30.0).tobytes()).hexdigest() == want
