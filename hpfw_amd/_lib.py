@@ -26,6 +26,7 @@ EXPORTS = (
     "hpfw_gpu_cov_reset", "hpfw_gpu_cov_accumulate_pcm16", "hpfw_gpu_cov_accumulate_pcm16_host",
     "hpfw_gpu_cov_accumulate_db", "hpfw_gpu_cov_get",
     "hpfw_gpu_cov_set", "hpfw_gpu_learn_filters", "hpfw_gpu_host_top_eigenvectors",
+    "hpfw_gpu_cov_device", "hpfw_gpu_cov_files", "hpfw_gpu_cov_set_files",
     "hpfw_gpu_index_clear", "hpfw_gpu_index_add", "hpfw_gpu_index_add_device",
     "hpfw_gpu_index_size", "hpfw_gpu_index_set_clip_base", "hpfw_gpu_search_topk_device",
     "hpfw_gpu_search_topk", "hpfw_gpu_merge_topk", "hpfw_gpu_timer_start", "hpfw_gpu_timer_stop",

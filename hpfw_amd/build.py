@@ -13,4 +13,6 @@ def build(force=False, jobs=6):
     so = os.path.join(_HERE, "lib", "libhpfw_gpu.so")
     if not os.path.exists(so):
         raise RuntimeError("hipcc produced no libhpfw_gpu.so")
+    if not os.path.exists(os.path.join(_HERE, "lib", "libhpfw_gpu_multi.so")):
+        raise RuntimeError("no libhpfw_gpu_multi.so (the multi-GPU host path: multi.cpp + librccl)")
     return so

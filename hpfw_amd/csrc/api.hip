@@ -991,6 +991,26 @@ int hpfw_gpu_cov_set(hpfw_gpu *h, const float *cov, int64_t n_files)
     return 0;
 }
 
+int hpfw_gpu_cov_device(hpfw_gpu *h, float **d_cov)
+{
+    if (!h || !d_cov) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = cov_prepare(h, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    *d_cov = h->d_cov;
+    return 0;
+}
+
+int64_t hpfw_gpu_cov_files(hpfw_gpu *h) { return h ? h->cov_files : 0; }
+
+int hpfw_gpu_cov_set_files(hpfw_gpu *h, int64_t n_files)
+{
+    if (!h || n_files < 0) return fail(HPFW_E_INVALID, "bad argument");
+    h->cov_files = n_files;
+    return 0;
+}
+
 // calc_filters (hashprint_handle.h:105-112): eigenvectors of the accumulated covariance by descending
 // eigenvalue, the first 64 as rows; they become the handle's filters.  filters_out (optional) receives
 // them in the reference's column-major layout.

@@ -116,6 +116,56 @@ bool save_filters_cereal(const std::string &path, const std::vector<float> &f)
     return (bool)os;
 }
 
+// cache/spectros/<stem> (cache.h:30-33): cereal's binary image of Spectrogram = Eigen::Matrix<float, 121, Dynamic>
+// (utils.h:84-90: int32 rows, int32 cols, column-major payload: element (b, c) at b + 121 c).  The device
+// layout is bin-major [121][C]: transposed on the way out and in.
+bool save_spectro_cereal(const std::string &path, const float *binmajor, int32_t cols)
+{
+    std::vector<float> cm((size_t)HPFW_BINS * cols);
+    for (int32_t b = 0; b < HPFW_BINS; ++b)
+        for (int32_t c = 0; c < cols; ++c) cm[(size_t)c * HPFW_BINS + b] = binmajor[(size_t)b * cols + c];
+    std::ofstream os(path, std::ios::binary);
+    if (!os) return false;
+    const int32_t rows = HPFW_BINS;
+    os.write(reinterpret_cast<const char *>(&rows), 4);
+    os.write(reinterpret_cast<const char *>(&cols), 4);
+    os.write(reinterpret_cast<const char *>(cm.data()), (std::streamsize)cm.size() * 4);
+    return (bool)os;
+}
+
+// the matrix as stored (column-major); false when the file is not a 121-row float matrix of that size
+bool load_spectro_cereal(const std::string &path, std::vector<float> &colmajor, int32_t &cols)
+{
+    std::ifstream is(path, std::ios::binary);
+    if (!is) return false;
+    int32_t rows = 0;
+    cols = 0;
+    is.read(reinterpret_cast<char *>(&rows), 4);
+    is.read(reinterpret_cast<char *>(&cols), 4);
+    if (!is || rows != HPFW_BINS || cols < 0 || cols > (1 << 24)) return false;
+    std::error_code ec;
+    if (std::filesystem::file_size(path, ec) != (uintmax_t)8 + (uintmax_t)rows * cols * 4 || ec) return false;
+    colmajor.resize((size_t)rows * cols);
+    is.read(reinterpret_cast<char *>(colmajor.data()), (std::streamsize)colmajor.size() * 4);
+    return (bool)is;
+}
+
+// fn(i) for i in [0, n) on a small team of host threads
+template <class F>
+void host_team(int n, F fn)
+{
+    unsigned team = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    team = std::min<unsigned>(team, (unsigned)std::max(n, 1));
+    std::atomic<int> next{0};
+    auto work = [&] {
+        for (int i; (i = next.fetch_add(1)) < n;) fn(i);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < team; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
 } // namespace
 
 struct hpfw_legacy_collector {
@@ -362,9 +412,14 @@ struct KeptGroup {
 // skipped as the reference does (:101-103), so *got may be < n; results keep the input order; the name
 // is the stem of the path (:123,129).  HPFW_PREPARE_KEEP_FILTERS=1 skips the learning step and keeps
 // the filters that load() / a previous prepare() installed.
-static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int n, bool learn, std::vector<uint64_t *> &hp,
-                          std::vector<int> &hp_size)
+static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int n, bool learn, bool cache_spectros,
+                          std::vector<uint64_t *> &hp, std::vector<int> &hp_size)
 {
+    const std::string spectro_dir = c->cache_dir + "spectros/";
+    if (cache_spectros) {
+        std::error_code ec;
+        std::filesystem::create_directories(spectro_dir, ec);
+    }
     size_t keep_budget = (size_t)32 << 30;
     if (const char *e = std::getenv("HPFW_PREPARE_KEEP_GB")) keep_budget = (size_t)std::max(0.0, std::atof(e) * 1073741824.0);
     hp.assign((size_t)n, nullptr);
@@ -399,6 +454,16 @@ static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int 
                 std::vector<int> ids;
                 for (int q : pos) ids.push_back(files[at + (size_t)q]);
                 const size_t sz = pos.size() * (size_t)121 * g.c * 4;
+                if (first && cache_spectros) {
+                    // cache.set_spectro(filename, spectro) (parallel_collector.h:98-100): "it will also be needed
+                    // when adding new tracks" -- a later prepare() recomputes every cached track's hashprints
+                    std::vector<float> host(sz / 4);
+                    if (hipMemcpy(host.data(), d_db, sz, hipMemcpyDeviceToHost) == hipSuccess)
+                        host_team((int)ids.size(), [&](int k) {
+                            const std::string stem = std::filesystem::path(filenames[ids[(size_t)k]]).stem().string();
+                            (void)save_spectro_cereal(spectro_dir + stem, host.data() + (size_t)k * 121 * g.c, (int32_t)g.c);
+                        });
+                }
                 if (first && learn) {
                     if (hpfw_gpu_cov_accumulate_db(c->gpu, d_db, (int64_t)pos.size(), g.c, nullptr) == 0) used += (int64_t)pos.size();
                     if (g.n_hp > 0 && kept_bytes + sz <= keep_budget) {
@@ -453,26 +518,92 @@ static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int 
     return !failed;
 }
 
+// collect_fingerprints (parallel_collector.h:114-137) walks EVERY spectrogram under cache/spectros/, not only
+// the files of this call: tracks indexed by an earlier run come back with hashprints under the filters just
+// learned.  The files of this call are already done (their spectrograms never left the device); this adds the
+// others: read by a team of host threads, grouped by width, projected and packed on the GPU.
+static void collect_cached(hpfw_legacy_collector *c, const std::vector<std::string> &done_stems,
+                           std::vector<std::string> &stems, std::vector<uint64_t *> &hp, std::vector<int> &hp_size)
+{
+    std::error_code ec;
+    std::vector<std::string> paths;
+    for (const auto &e : std::filesystem::directory_iterator(c->cache_dir + "spectros/", ec)) {
+        if (!e.is_regular_file(ec)) continue;
+        const std::string stem = e.path().filename().string(); // the cache names its files by stem, without extension
+        if (std::find(done_stems.begin(), done_stems.end(), stem) == done_stems.end()) paths.push_back(e.path().string());
+    }
+    std::sort(paths.begin(), paths.end()); // the reference's order is the directory's (and racy, :129): sorted here
+    for (size_t at = 0; at < paths.size();) {
+        const size_t end = std::min(paths.size(), at + 256);
+        struct Item {
+            std::vector<float> cm;
+            int32_t cols = 0;
+            bool ok = false;
+        };
+        std::vector<Item> items(end - at);
+        host_team((int)items.size(), [&](int i) { items[(size_t)i].ok = load_spectro_cereal(paths[at + (size_t)i], items[(size_t)i].cm, items[(size_t)i].cols); });
+        std::map<int32_t, std::vector<int>> by_cols;
+        for (size_t i = 0; i < items.size(); ++i)
+            if (items[i].ok && items[i].cols >= HPFW_CONTEXT + HPFW_LAG) by_cols[items[i].cols].push_back((int)i);
+        for (auto &kv : by_cols) {
+            const int32_t cols = kv.first;
+            const std::vector<int> &pos = kv.second;
+            hpfw_geometry g{};
+            g.c = cols;
+            g.n_frames = cols - (HPFW_CONTEXT - 1);
+            g.n_hp = g.n_frames - HPFW_LAG;
+            std::vector<float> bm(pos.size() * (size_t)HPFW_BINS * cols);
+            host_team((int)pos.size(), [&](int k) {
+                const float *cm = items[(size_t)pos[(size_t)k]].cm.data();
+                float *out = bm.data() + (size_t)k * HPFW_BINS * cols;
+                for (int32_t col = 0; col < cols; ++col)
+                    for (int32_t b = 0; b < HPFW_BINS; ++b) out[(size_t)b * cols + col] = cm[(size_t)col * HPFW_BINS + b];
+            });
+            DevMem d_db;
+            std::vector<uint64_t *> out(pos.size(), nullptr);
+            if (!d_db.alloc(bm.size() * 4) || hipMemcpy(d_db.p, bm.data(), bm.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                !group_hashprints(c->gpu, (const float *)d_db.p, pos.size(), g, out.data()))
+                continue;
+            for (size_t k = 0; k < pos.size(); ++k) {
+                stems.push_back(std::filesystem::path(paths[at + (size_t)pos[k]]).filename().string());
+                hp.push_back(out[k]);
+                hp_size.push_back((int)g.n_hp);
+            }
+        }
+        at = end;
+    }
+}
+
 static FilenameHashprintPair *prepare_impl(hpfw_legacy_collector *c, const char **filenames, int n, int *got)
 {
     if (got) *got = 0;
     if (!c || !filenames || n < 0 || !got) return nullptr;
     const bool learn = !(std::getenv("HPFW_PREPARE_KEEP_FILTERS") && !c->filters.empty());
+    const bool cache_spectros = !std::getenv("HPFW_NO_SPECTRO_CACHE");
     std::vector<uint64_t *> hp;
     std::vector<int> hp_size;
-    if (!collect_files(c, filenames, n, learn, hp, hp_size)) return nullptr;
-    auto *res = new FilenameHashprintPair[(size_t)(n > 0 ? n : 1)];
-    int w = 0;
+    if (!collect_files(c, filenames, n, learn, cache_spectros, hp, hp_size)) return nullptr;
+    std::vector<std::string> stems;
+    std::vector<uint64_t *> r_hp;
+    std::vector<int> r_size;
     for (int i = 0; i < n; ++i) {
         if (!hp[(size_t)i]) continue;
-        const std::string stem = std::filesystem::path(filenames[i]).stem().string();
-        res[w].filename = new char[stem.size() + 1];
-        std::memcpy(res[w].filename, stem.c_str(), stem.size() + 1);
-        res[w].hashprint = hp[(size_t)i];
-        res[w].hp_size = hp_size[(size_t)i];
-        ++w;
+        stems.push_back(std::filesystem::path(filenames[i]).stem().string());
+        r_hp.push_back(hp[(size_t)i]);
+        r_size.push_back(hp_size[(size_t)i]);
     }
-    *got = w;
+    if (cache_spectros) {
+        const std::vector<std::string> done = stems;
+        collect_cached(c, done, stems, r_hp, r_size);
+    }
+    auto *res = new FilenameHashprintPair[std::max<size_t>(stems.size(), 1)];
+    for (size_t w = 0; w < stems.size(); ++w) {
+        res[w].filename = new char[stems[w].size() + 1];
+        std::memcpy(res[w].filename, stems[w].c_str(), stems[w].size() + 1);
+        res[w].hashprint = r_hp[w];
+        res[w].hp_size = r_size[w];
+    }
+    *got = (int)stems.size();
     return res;
 }
 
@@ -489,7 +620,7 @@ static FilenameHashprintPair *calc_hashprints_impl(hpfw_legacy_collector *c, con
     }
     std::vector<uint64_t *> hp;
     std::vector<int> hp_size;
-    if (!collect_files(c, filenames, n, false, hp, hp_size)) return nullptr;
+    if (!collect_files(c, filenames, n, false, false, hp, hp_size)) return nullptr;
     auto *res = new FilenameHashprintPair[(size_t)(n > 0 ? n : 1)];
     for (int i = 0; i < n; ++i) {
         const std::string stem = std::filesystem::path(filenames[i]).stem().string();

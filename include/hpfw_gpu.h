@@ -151,6 +151,12 @@ int hpfw_gpu_cov_get(hpfw_gpu *h, float *cov, int64_t *n_files);
 int hpfw_gpu_cov_set(hpfw_gpu *h, const float *cov, int64_t n_files);
 /* filters_colmajor_out may be NULL; layout as hpfw_gpu_set_filters */
 int hpfw_gpu_learn_filters(hpfw_gpu *h, float *filters_colmajor_out);
+/* accum_cov where it lives: DEVICE pointer to 2420 x 2420 floats (allocated and zeroed on first use; the tiles
+ * of 128 x 128 on or above the diagonal are maintained, the rest stays zero) and the number of files added --
+ * what a multi-GPU host sums with one ncclAllReduce (include/hpfw_gpu_multi.h) */
+int hpfw_gpu_cov_device(hpfw_gpu *h, float **d_cov);
+int64_t hpfw_gpu_cov_files(hpfw_gpu *h);
+int hpfw_gpu_cov_set_files(hpfw_gpu *h, int64_t n_files);
 /* host-only: unit eigenvectors of the m largest eigenvalues of a symmetric n x n float matrix */
 int hpfw_gpu_host_top_eigenvectors(const float *cov, int n, int m, float *out, double *evals);
 

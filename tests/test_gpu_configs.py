@@ -17,7 +17,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import hpfw_amd  # noqa: E402
-from hpfw_amd import synth  # noqa: E402
+from hpfw_amd import dist as hdist, synth  # noqa: E402
 
 N_HP = 2320
 THREADS = min(os.cpu_count() or 8, 64)
@@ -76,7 +76,7 @@ def _sharded(gpu, db, db_off, q, q_off, k, n_shards):
     n_clips = db.shape[0]
     per = []
     for r in range(n_shards):
-        lo, hi = hpfw_amd.dist.shard_range(n_clips, r, n_shards)
+        lo, hi = hdist.shard_range(n_clips, r, n_shards)
         gpu.index_clear()
         gpu.index_set_clip_base(lo)
         gpu.index_add(db[lo:hi].ravel(), db_off[lo:hi + 1] - db_off[lo])
@@ -109,7 +109,7 @@ def test_config3_shards_of_12500(gpu, oracle):
     whole = gpu.search_topk(q, q_off, 10)
     assert np.array_equal(whole, want)
     per = _sharded(gpu, db, db_off, q, q_off, 10, 8)
-    assert per.shape == (8, 16, 10) and hpfw_amd.dist.shard_range(n_clips, 1, 8) == (12500, 25000)
+    assert per.shape == (8, 16, 10) and hdist.shard_range(n_clips, 1, 8) == (12500, 25000)
     assert np.array_equal(hpfw_amd.merge_topk(per, 10), want)
     assert [int(x) for x in want[15]["clip"][:2]] == [3, 99999]          # a tie across the first and the last shard
     for qi in range(15):

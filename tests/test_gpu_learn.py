@@ -129,3 +129,66 @@ def test_legacy_prepare_mixed_lengths(torch_cuda, tmp_path, keep_gb, monkeypatch
     g.close()
     assert n_files == len(secs)
     assert np.abs(cov - rawc).max() <= 2e-5 * np.abs(cov).max()
+
+
+def test_spectrogram_cache_and_incremental_indexing(torch_cuda, oracle, tmp_path):
+    """f2: cache/spectros/<stem> (cache.h:30-33, utils.h:77-106) is written by prepare(), and a later prepare()
+    -- a new collector, as a new process would hold -- returns hashprints for EVERY cached track under the
+    filters it has just learned (collect_fingerprints walks the whole cache, parallel_collector.h:114-137:
+    "needed when adding new tracks")."""
+    torch = torch_cuda
+    secs = [3.0, 4.0, 3.0, 3.0, 5.0]
+    clips = [synth.gen_clip(760 + i, s) for i, s in enumerate(secs)]
+    paths = []
+    for i, c in enumerate(clips):
+        p = str(tmp_path / f"trk{i}.wav")
+        synth.write_wav(p, c)
+        paths.append(p)
+    cache = str(tmp_path / "cache") + "/"
+    pc = hpfw_amd.ParallelCollector()
+    pc.load(cache)
+    first = pc.prepare(paths[:3])
+    assert [n for _, n in first] == ["trk0", "trk1", "trk2"]
+    del pc
+    # the files are the reference's cereal image of Matrix<float, 121, Dynamic>: int32 rows, int32 cols, column-major
+    g = hpfw_amd.Gpu(0)
+    for i in range(3):
+        raw = open(os.path.join(cache, "spectros", f"trk{i}"), "rb").read()
+        rows, cols = np.frombuffer(raw[:8], np.int32)
+        plan = oracle.Plan(clips[i].size)
+        assert (rows, cols) == (121, plan.c) and len(raw) == 8 + 4 * 121 * plan.c
+        s_file = np.frombuffer(raw[8:], np.float32).reshape(cols, 121)          # [col][bin]: element (b, c) at b + 121 c
+        want = oracle.db(plan.cqmag(plan.spectrum(clips[i])))                   # [bin][col]
+        assert np.array_equal(s_file.T.view(np.uint32), want.view(np.uint32))
+    # a track cached by somebody else (e.g. the reference itself, which allocates one more column when 3 | M)
+    rng = np.random.default_rng(9)
+    foreign = rng.uniform(-80, 0, (260, 121)).astype(np.float32)
+    with open(os.path.join(cache, "spectros", "foreign"), "wb") as f:
+        f.write(np.array([121, 260], np.int32).tobytes() + foreign.tobytes())
+    open(os.path.join(cache, "spectros", "broken"), "wb").write(b"\\x79\\x00\\x00\\x00junk")   # skipped
+    pc2 = hpfw_amd.ParallelCollector()                       # "a new process": loads accum_cov + filters, adds two tracks
+    pc2.load(cache)
+    second = pc2.prepare(paths[3:])
+    names = [n for _, n in second]
+    assert names == ["trk3", "trk4", "foreign", "trk0", "trk1", "trk2"]        # this call's files, then the cache, sorted
+    filt = np.frombuffer(open(os.path.join(cache, "filters.cereal"), "rb").read()[8:], np.float32)
+    g.set_filters(filt)
+    by_name = {n: hp for hp, n in second}
+    for i, c in enumerate(clips):                            # == extracting all five with those filters
+        assert np.array_equal(by_name[f"trk{i}"], oracle.Plan(c.size).extract(filt, c)), i
+    assert np.array_equal(by_name["foreign"], g.extract_db(foreign))
+    assert np.array_equal(by_name["foreign"], oracle.pack(oracle.project(filt, np.ascontiguousarray(foreign.T))))
+    # the covariance kept accumulating across the two runs (parallel_collector.h:93-97 + load())
+    rawc = np.frombuffer(open(os.path.join(cache, "accum_cov.cereal"), "rb").read()[8:], np.float32).reshape(2420, 2420)
+    for c in clips:
+        g.cov_accumulate(c[None, :])
+    cov, _ = g.cov_get()
+    assert np.abs(cov - rawc).max() <= 2e-5 * np.abs(cov).max()
+    g.close()
+    # HPFW_NO_SPECTRO_CACHE=1: nothing written, nothing picked up
+    os.environ["HPFW_NO_SPECTRO_CACHE"] = "1"
+    try:
+        third = pc2.prepare(paths[:1])
+    finally:
+        del os.environ["HPFW_NO_SPECTRO_CACHE"]
+    assert [n for _, n in third] == ["trk0"]

@@ -1,0 +1,123 @@
+"""The native multi-GPU host path (include/hpfw_gpu_multi.h, libhpfw_gpu_multi.so: C++ over the C-ABI + RCCL)
+on the one GPU this box has: a group of one shard (ncclCommInitAll of world size 1, a real ncclAllGather /
+ncclAllReduce) and groups of several shards placed on device 0 (their lists travel in one all-gather of the
+device's send buffer).  Sharded results must equal the unsharded ones and the oracle's
+(identical at any number of shards)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import hpfw_amd  # noqa: E402
+from hpfw_amd import _lib, multi, synth  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ragged(rng, lens):
+    hp = [rng.integers(0, 2 ** 64, size=n, dtype=np.uint64) for n in lens]
+    return np.concatenate(hp), np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]])
+def test_group_search_equals_unsharded_and_oracle(torch_cuda, gpu, oracle, devices):
+    rng = np.random.default_rng(31)
+    lens = [int(x) for x in rng.integers(1, 900, 203)] + [2320, 0, 5]
+    db, db_off = _ragged(rng, lens)
+    db[db_off[200]:db_off[200] + min(lens[200], lens[3])] = db[db_off[3]:db_off[3] + min(lens[200], lens[3])]
+    qs = []
+    for i in range(45):
+        c = (i * 17) % len(lens)
+        k = min(lens[c], int(rng.integers(1, 400)))
+        if k and i % 4:
+            o = int(rng.integers(0, lens[c] - k + 1))
+            seg = db[db_off[c] + o: db_off[c] + o + k].copy()
+            seg ^= np.uint64(1) << rng.integers(0, 64, size=k, dtype=np.uint64)
+        else:
+            seg = rng.integers(0, 2 ** 64, size=max(k, 1), dtype=np.uint64)
+        qs.append(seg)
+    q_off = np.concatenate([[0], np.cumsum([x.size for x in qs])]).astype(np.int64)
+    q = np.concatenate(qs)
+    want = oracle.search_topk(db, db_off, q, q_off, 10, n_threads=8)
+    gpu.index_clear()
+    gpu.index_set_clip_base(0)
+    gpu.index_add(db, db_off)
+    assert np.array_equal(gpu.search_topk(q, q_off, 10), want)
+    g = multi.GpuGroup(devices)
+    assert g.shards == len(devices) and g.exchange == ("rccl" if len(devices) == 1 else "rccl+local")
+    g.index_build(db, db_off)
+    for k in (1, 10):
+        assert np.array_equal(g.search_topk(q, q_off, k), want[:, :k])
+    # one query, and a rebuild with fewer clips than shards (some shards empty)
+    assert np.array_equal(g.search_topk(qs[1], np.array([0, qs[1].size], np.int64), 10), want[1:2])
+    g.index_build(db[:db_off[3]], db_off[:4])
+    small = oracle.search_topk(db[:db_off[3]], db_off[:4], q, q_off, 4, n_threads=8)
+    assert np.array_equal(g.search_topk(q, q_off, 4), small)
+    g.close()
+
+
+def test_group_extraction_and_learning(torch_cuda, oracle, filters):
+    clips = np.stack([synth.gen_clip(810 + i, 3.0) for i in range(7)])
+    plan = oracle.Plan(clips.shape[1])
+    want = plan.extract_batch(filters, clips, n_threads=7)
+    one = hpfw_amd.Gpu(0)
+    one.cov_accumulate(clips)
+    f_one = one.learn_filters()
+    cov_one, n_one = one.cov_get()
+    for devices in ([0], [0, 0, 0]):
+        g = multi.GpuGroup(devices)
+        g.set_filters(filters)
+        assert np.array_equal(g.extract(clips, plan.n_hp), want)          # clips sharded, order kept
+        g.cov_reset()
+        g.cov_accumulate(clips)                                           # every shard: the covariance of its block
+        f = g.learn_filters()                                             # all-reduce (or host sum), solve, install
+        if len(devices) == 1:
+            assert np.array_equal(f, f_one)                               # a sum of one: the same bits
+        rows = f.reshape(2420, 64).T.astype(np.float64)
+        w = np.linalg.eigvalsh(cov_one.astype(np.float64))[::-1]
+        ray = np.einsum("rk,kl,rl->r", rows, cov_one.astype(np.float64), rows)
+        assert np.abs(ray - w[:64]).max() / w[0] < 1e-4
+        assert np.abs(rows @ rows.T - np.eye(64)).max() < 1e-4
+        got = g.extract(clips, plan.n_hp)                                 # the learned filters are installed everywhere
+        assert np.array_equal(got, plan.extract_batch(f, clips, n_threads=7))
+        g.close()
+    one.close()
+
+
+def test_cpp_sharded_live_song_identification(torch_cuda, filters, tmp_path):
+    """LiveSongIdentification<GpuCollector, ShardedGpuStorage>: the same stdout as the single-GPU storage"""
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exes = {}
+    for name, libs in (("live_id", ["-lhpfw_gpu"]), ("live_id_multi", ["-lhpfw_gpu_multi", "-lhpfw_gpu"])):
+        exes[name] = str(tmp_path / name)
+        r = subprocess.run(["g++", "-std=c++20", "-O1", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", name + ".cpp"), "-o", exes[name], "-L", libdir] + libs +
+                           ["-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    clips = [synth.gen_clip(830 + i, 8.0) for i in range(5)]
+    tracks, queries = [], []
+    for i, c in enumerate(clips):
+        p = str(tmp_path / f"tune{i}.wav")
+        synth.write_wav(p, c)
+        tracks.append(p)
+    for qi in range(4):
+        pcm, ci, start = synth.gen_query(clips, qi, seconds=3.0)
+        p = str(tmp_path / f"live_tune{ci}_{qi}.wav")
+        synth.write_wav(p, pcm)
+        queries.append(p)
+    outs = {}
+    for name, env in (("live_id", {}), ("live_id_multi", {"HPFW_GPU_DEVICES": "0,0,0"})):
+        work = tmp_path / ("run_" + name)
+        os.makedirs(str(work / "cache"))
+        with open(str(work / "cache" / "filters.cereal"), "wb") as f:
+            f.write(np.array([64, 2420], np.int32).tobytes() + np.ascontiguousarray(filters, np.float32).tobytes())
+        r = subprocess.run([exes[name], "--index"] + tracks + ["--search"] + queries, cwd=str(work), capture_output=True,
+                           text=True, timeout=300, env=dict(os.environ, HPFW_PREPARE_KEEP_FILTERS="1", **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("=> ")]
+        if name == "live_id_multi":
+            assert "shards: 3" in r.stderr
+    assert outs["live_id"] == outs["live_id_multi"] and outs["live_id"][-1] == "=> 0 1"

@@ -142,3 +142,21 @@ def test_committed_sha_of_synthetic_clip_zero():
     from hpfw_amd import synth
     want = open(os.path.join(ROOT, "tests", "golden", "clip0.sha256")).read().split()[0]
     assert hashlib.sha256(synth.gen_clip(0, 30.0).tobytes()).hexdigest() == want
+
+
+def test_multi_library_exports_every_declared_symbol():
+    """libhpfw_gpu_multi.so (include/hpfw_gpu_multi.h): loads, links librccl, exports what the header declares;
+    the shard arithmetic is the one hpfw_amd.dist uses for the one-process-per-GPU launch"""
+    from hpfw_amd import dist as hdist, multi
+    header = open(os.path.join(ROOT, "include", "hpfw_gpu_multi.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(hpfw_gpu_(?:group|shard)_\w+)\s*\(", header))
+    assert declared == set(multi.EXPORTS) and len(declared) == 15
+    L = multi.lib()
+    assert not [s for s in sorted(declared) if not hasattr(L, s)]
+    out = subprocess.run(["ldd", multi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl.so" in out and "libhpfw_gpu.so" in out
+    for n in (0, 1, 7, 100000, 12345):
+        for world in (1, 3, 8):
+            for r in range(world):
+                assert multi.shard_range(n, r, world) == hdist.shard_range(n, r, world)
