@@ -66,6 +66,7 @@ struct DevPlan {
     hpfw::HostPlan hp;
     hpfw::ColsArgs cols;
     hpfw::RowsArgs rows;
+    hpfw::BzArgs bz; // clip lengths with a prime factor above 7 (hp.bluestein)
     hpfw::CqPlanDev cq;
     std::vector<hpfw::CqClassDev> cls;
     std::vector<void *> owned;
@@ -97,8 +98,9 @@ struct hpfw_gpu {
     uint64_t plan_clock = 0;
     int batch = 1024; // clips per pass: ~10 GB of workspace at 30 s; every launch fills the 256 CUs many times over
     // extraction workspace
-    size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
-    void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // yp, x, mag, proj, wave maxima [clip][121][16], pairs
+    size_t ws_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
+    // yp, x, mag, proj, wave maxima [clip][121][16], pairs, second planar buffer of the chirp-z forward transform
+    void *ws[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // index
     uint64_t *d_db = nullptr;
     size_t db_cap = 0;
@@ -236,7 +238,8 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     g_uploaded = 0;
     auto dp = std::make_unique<DevPlan>();
     std::string why;
-    if (!hpfw::build_plan(n, dp->hp, why))
+    // HPFW_FORCE_BLUESTEIN=1 (tests): the chirp-z forward transform for 7-smooth lengths too
+    if (!hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr))
         return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n) + ": " + why);
     const hpfw::HostPlan &p = dp->hp;
     using hpfw::cf;
@@ -250,7 +253,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     ra.hpad = (p.h + 31) / 32 * 32;
     // The pcm_pairs pre-pass (coalesced stream) measured faster than reading the aligned 4-byte pair
     // words in place (6.4 vs 7.1 ms per 1000 clips); HPFW_ROWS_INPLACE=1 selects the latter (n1 even).
-    ra.pair_stride = (p.n1 % 2 == 0 && std::getenv("HPFW_ROWS_INPLACE")) ? p.n1 / 2 : 1;
+    ra.pair_stride = (p.n1 % 2 == 0 && !p.bluestein && std::getenv("HPFW_ROWS_INPLACE")) ? p.n1 / 2 : 1;
     ra.groups.n = (int)p.groups.size();
     for (size_t g = 0; g < p.groups.size(); ++g) {
         ra.groups.r1[g] = p.groups[g].first;
@@ -262,6 +265,23 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     if ((rc = upload(p.pos_n2, &ra.pos_n2, dp->owned))) return rc;
     if ((rc = upload(p.kb_last, &ra.kb_last, dp->owned))) return rc;
     if (hpfw::fwd_rows_lds_bytes(ra) > 160 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
+    hpfw::BzArgs &bz = dp->bz;
+    std::memset(&bz, 0, sizeof(bz));
+    if (p.bluestein) {
+        bz.n1 = p.n1;
+        bz.n2 = p.n2;
+        bz.n2pad = (p.n2 + 31) / 32 * 32;
+        bz.kmin = p.kmin;
+        bz.kmax = p.kmax;
+        bz.n_tiles = ((2 * p.n1 + 31) / 32 + 2) / 3 * 3;
+        if ((rc = upload(p.bz_w, reinterpret_cast<const hpfw::HostCf **>(&bz.w), dp->owned))) return rc;
+        if ((rc = upload(p.bz_tl, reinterpret_cast<const hpfw::HostCf **>(&bz.tl), dp->owned))) return rc;
+        if ((rc = upload(p.bz_bhat, reinterpret_cast<const hpfw::HostCf **>(&bz.bhat), dp->owned))) return rc;
+        if ((rc = upload(p.bz_wk, reinterpret_cast<const hpfw::HostCf **>(&bz.wk), dp->owned))) return rc;
+        std::vector<float> apack((size_t)p.n1 * bz.n_tiles * 64);
+        hpfw::pack_bz_coefficients(p.n1, reinterpret_cast<const float *>(p.tw_n1.data()), bz.n_tiles, apack.data());
+        if ((rc = upload(apack, &bz.apack, dp->owned))) return rc;
+    }
     // column DFT: coefficient image for the MFMA A operand
     hpfw::ColsArgs &ca = dp->cols;
     std::memset(&ca, 0, sizeof(ca));
@@ -274,7 +294,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     ca.k1lo = p.k1lo;
     ca.k1n = p.k1hi - p.k1lo + 1;
     ca.n_tiles = (2 * ca.k1n + 15) / 16;
-    {
+    if (!p.bluestein) {
         std::vector<float> apack((size_t)p.n1 * ca.n_tiles * 64);
         hpfw::pack_cols_coefficients(p.n1, ca.k1lo, ca.k1n, reinterpret_cast<const float *>(p.tw_n1.data()),
                                      ca.n_tiles, apack.data());
@@ -313,6 +333,10 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         std::vector<hpfw::HostCf>().swap(hp.tw_n1);
         std::vector<hpfw::HostCf>().swap(hp.tw_big);
         std::vector<hpfw::HostCf>().swap(hp.g);
+        std::vector<hpfw::HostCf>().swap(hp.bz_w);
+        std::vector<hpfw::HostCf>().swap(hp.bz_tl);
+        std::vector<hpfw::HostCf>().swap(hp.bz_bhat);
+        std::vector<hpfw::HostCf>().swap(hp.bz_wk);
         for (hpfw::BluesteinClass &bc : hp.classes) {
             std::vector<hpfw::HostCf>().swap(bc.tw);
             std::vector<hpfw::HostCf>().swap(bc.gtw);
@@ -349,6 +373,7 @@ int pass_clips(hpfw_gpu *h, const DevPlan *dp, int64_t n_clips)
     const hpfw::HostPlan &p = dp->hp;
     size_t per_clip = (size_t)2 * p.n1 * ((p.h + 31) / 32 * 32) * 4 + (size_t)(p.kmax - p.kmin) * 8 + (size_t)121 * p.c * 4 +
                       (size_t)64 * std::max(p.n_frames, 1) * 4 + (size_t)((p.n1 + 1) / 2) * p.n2 * 4;
+    if (p.bluestein) per_clip += 2 * hpfw::bz_plane_bytes(dp->bz, 1);
     size_t work = 0;
     for (const hpfw::CqClassDev &cd : dp->cls) work = std::max(work, hpfw::cq_big_work_bytes(cd, 1));
     per_clip += work;
@@ -365,28 +390,43 @@ int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
         int rc = ensure(&h->d_cqwork, &h->cqwork_cap, work);
         if (rc) return rc;
     }
-    const size_t need[6] = {(size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4, (size_t)nb * (p.kmax - p.kmin) * 8,
+    const size_t planar = p.bluestein ? hpfw::bz_plane_bytes(dp->bz, nb) : 0;
+    const size_t need[7] = {p.bluestein ? planar : (size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4,
+                            (size_t)nb * (p.kmax - p.kmin) * 8,
                             (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4,
-                            (size_t)ns * 121 * hpfw::kCqMaxWaves * 4, (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4};
-    for (int i = 0; i < 6; ++i) {
+                            (size_t)ns * 121 * hpfw::kCqMaxWaves * 4, (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4, planar};
+    for (int i = 0; i < 7; ++i) {
         int rc = ensure(&h->ws[i], &h->ws_bytes[i], need[i]);
         if (rc) return rc;
     }
     return ensure((void **)&h->d_clipmax, &h->clipmax_cap, (size_t)ns * 4);
 }
 
-// front end for nb clips: PCM -> dB terms t (and their per-clip maximum in d_clipmax) at clip slot
-// `slot` of the S workspace; finish_db: also turn them into the dB spectrogram S = max(t - t_max, -80)
-// in place (the projection does that itself while staging, the covariance wants S)
-int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, bool finish_db, hipStream_t s)
+// a1 + the forward transform for nb clips: PCM -> bins [kmin, kmax) in x
+int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf *x, hipStream_t s)
 {
-    using hpfw::cf;
     const hpfw::HostPlan &p = dp->hp;
     float *yp = (float *)h->ws[0];
-    cf *x = (cf *)h->ws[1];
-    float *mag = (float *)h->ws[2] + (size_t)slot * 121 * p.c;
-    float *mm = (float *)h->ws[4] + (size_t)slot * 121 * hpfw::kCqMaxWaves; // this pass's wave maxima
     int rc;
+    if (p.bluestein) { // S15: the clip length has a prime factor above 7
+        {
+            Timed t(h, K_ROWS, s);
+            hpfw::launch_pcm_pairs(p.n, p.n1, p.n2, d_pcm, nb, (hpfw::i16x2 *)h->ws[5], s);
+            hpfw::launch_bz_rows_first(dp->rows, dp->bz, (const hpfw::i16x2 *)h->ws[5], nb, yp, s);
+        }
+        if ((rc = check_launch("bz_rows"))) return rc;
+        {
+            Timed t(h, K_COLS, s);
+            hpfw::launch_bz_cols(dp->bz, 0, yp, (float *)h->ws[6], nb, s);
+            hpfw::launch_bz_cols(dp->bz, 1, (const float *)h->ws[6], yp, nb, s);
+        }
+        if ((rc = check_launch("bz_cols"))) return rc;
+        {
+            Timed t(h, K_ROWS, s);
+            hpfw::launch_bz_rows_last(dp->rows, dp->bz, yp, nb, x, s);
+        }
+        return check_launch("bz_rows");
+    }
     {
         Timed t(h, K_ROWS, s);
         if (dp->rows.pair_stride == 1) {
@@ -401,7 +441,21 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
         Timed t(h, K_COLS, s);
         hpfw::launch_fwd_cols(dp->cols, yp, nb, x, s);
     }
-    if ((rc = check_launch("fwd_cols"))) return rc;
+    return check_launch("fwd_cols");
+}
+
+// front end for nb clips: PCM -> dB terms t (and their per-clip maximum in d_clipmax) at clip slot
+// `slot` of the S workspace; finish_db: also turn them into the dB spectrogram S = max(t - t_max, -80)
+// in place (the projection does that itself while staging, the covariance wants S)
+int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, bool finish_db, hipStream_t s)
+{
+    using hpfw::cf;
+    const hpfw::HostPlan &p = dp->hp;
+    cf *x = (cf *)h->ws[1];
+    float *mag = (float *)h->ws[2] + (size_t)slot * 121 * p.c;
+    float *mm = (float *)h->ws[4] + (size_t)slot * 121 * hpfw::kCqMaxWaves; // this pass's wave maxima
+    int rc;
+    if ((rc = run_forward(h, dp, d_pcm, nb, x, s))) return rc;
     for (const hpfw::CqClassDev &cd : dp->cls) {
         Timed t(h, K_CQ, s);
         if (cd.outer)
@@ -639,16 +693,7 @@ int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        if (dp->rows.pair_stride == 1) {
-            hpfw::launch_pcm_pairs(dp->hp.n, dp->hp.n1, dp->hp.n2, d_pcm + c0 * n_samples, nb, (hpfw::i16x2 *)h->ws[5], s);
-            hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, (float *)h->ws[0], s);
-        } else {
-            hpfw::launch_fwd_rows(dp->rows, reinterpret_cast<const hpfw::i16x2 *>(d_pcm + c0 * n_samples), nb,
-                                  (float *)h->ws[0], s);
-        }
-        if ((rc = check_launch("fwd_rows"))) return rc;
-        hpfw::launch_fwd_cols(dp->cols, (const float *)h->ws[0], nb, (hpfw::cf *)d_x + c0 * nk, s);
-        if ((rc = check_launch("fwd_cols"))) return rc;
+        if ((rc = run_forward(h, dp, d_pcm + c0 * n_samples, nb, (hpfw::cf *)d_x + c0 * nk, s))) return rc;
     }
     return 0;
 }

@@ -1,0 +1,254 @@
+// k_bluestein.hip -- the forward DFT bins [kmin, kmax) of a clip whose length N has a prime factor above 7
+// (DESIGN.md S15): essentia hands the file's exact sample count to FFTW (reference
+// include/hpfw/spectrum/cqt.h:54-55, inputSize = audioBuffer.size()), so N is whatever the file holds.
+//
+//   X[k] = w[k] sum_n (x[n] w[n]) conj(w[k - n]),  w[n] = e^{-i pi n^2 / N}         (Bluestein / chirp-z)
+//
+// as a cyclic convolution of length L = n1 * n2 >= N + (kmax - kmin) - 1 with n2 = 6300 (the row transform
+// of the 7-smooth path, fft_rows.h, pass order [7,3,5,3,5,4]) and any n1 (the transform across residues is a
+// dense DFT on the matrix cores and does not care about n1's factors):
+//   pcm_pairs    (k_forward.hip) PCM -> residue streams, zeros beyond N
+//   bz_rows<0>   per residue r: a[r + n1 t] = x w, FFT_n2 in LDS, times T_L[r k2]           -> Y'  planar
+//   bz_cols<0>   A[n2 k1 + k2] = sum_r T_n1[r k1] Y'[r][k2] (f32 MFMA), C = conj(A Bhat)     -> C   planar
+//   bz_cols<1>   D[k1][j2] = sum_j1 T_n1[j1 k1] C[j1][j2] (f32 MFMA), times T_L[j2 k1]       -> E   planar
+//   bz_rows<1>   per k1: FFT_n2 over j2 in LDS: F[k1 + n1 k2]; X[k] = conj(F[k]) w[k] / L for the consumed bins
+// The second transform runs columns first so that the first one's output tile (k1 rows, k2 columns) is its
+// input tile as it stands: no transposition between the two.  Arithmetic order = the oracle's, bit for bit:
+// MFMA chains its k index (Re then Im part of each residue) in ascending order (S6).
+#include "kernels.h"
+
+namespace hpfw {
+
+extern __shared__ __align__(16) unsigned char smem_raw[];
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBzThreads = 512;
+
+// MODE 0: first transform's rows; MODE 1: second transform's rows
+template <int MODE>
+__global__ __launch_bounds__(kBzThreads, 4) void bz_rows_kernel(RowsArgs a, BzArgs bz, const i16x2 *__restrict__ pairs,
+                                                                const float *__restrict__ in, float *__restrict__ out,
+                                                                cf *__restrict__ x)
+{
+    cf *lds = reinterpret_cast<cf *>(smem_raw);
+    const int row = blockIdx.y; // residue r (MODE 0) or output residue k1 (MODE 1)
+    const int clip = blockIdx.x;
+    const int n2 = a.n2, nthreads = kBzThreads, tid = threadIdx.x;
+    const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad; // floats per clip of a planar buffer
+    if (MODE == 0) {
+        const i16x2 *__restrict__ src = pairs + ((int64_t)clip * ((bz.n1 + 1) / 2) + (row >> 1)) * n2;
+        const cf *__restrict__ w = bz.w + (int64_t)row * n2;
+        const bool odd = row & 1;
+        constexpr int kLd = 13;
+        for (int t0 = tid; t0 < n2; t0 += kLd * nthreads) {
+            i16x2 p[kLd];
+            cf ww[kLd];
+#pragma unroll
+            for (int e = 0; e < kLd; ++e) {
+                const int t = t0 + e * nthreads;
+                p[e] = src[t < n2 ? t : 0];
+                ww[e] = w[t < n2 ? t : 0];
+            }
+#pragma unroll
+            for (int e = 0; e < kLd; ++e) {
+                const int t = t0 + e * nthreads;
+                if (t < n2) {
+                    const float xs = (float)(odd ? p[e].y : p[e].x) / 32768.0f;
+                    lds[t] = {xs * ww[e].r, xs * ww[e].i};
+                }
+            }
+        }
+    } else {
+        const float *__restrict__ re = in + clip * plane + (int64_t)2 * row * bz.n2pad;
+        const float *__restrict__ im = re + bz.n2pad;
+        for (int t = tid; t < n2; t += nthreads) lds[t] = {re[t], im[t]};
+    }
+    __syncthreads();
+    Groups6300::run(lds, a, nthreads); // outputs in natural order
+    if (MODE == 0) {
+        const cf *__restrict__ tl = bz.tl + (int64_t)row * n2;
+        float *__restrict__ ore = out + clip * plane + (int64_t)2 * row * bz.n2pad;
+        float *__restrict__ oim = ore + bz.n2pad;
+        for (int k2 = tid; k2 < n2; k2 += nthreads) {
+            const cf o = c_mul(lds[k2], tl[k2]);
+            ore[k2] = o.r;
+            oim[k2] = o.i;
+        }
+    } else {
+        // bins k = row + n1 k2 inside [kmin, kmax)
+        const int lo = bz.kmin > row ? (bz.kmin - row + bz.n1 - 1) / bz.n1 : 0;
+        const int hi = bz.kmax > row ? (bz.kmax - 1 - row) / bz.n1 : -1; // inclusive
+        cf *__restrict__ xo = x + (int64_t)clip * (bz.kmax - bz.kmin);
+        for (int k2 = lo + tid; k2 <= hi && k2 < n2; k2 += nthreads) {
+            const int k = row + bz.n1 * k2;
+            const cf f = lds[k2];
+            xo[k - bz.kmin] = c_mul(cf{f.r, -f.i}, bz.wk[k - bz.kmin]);
+        }
+    }
+}
+
+__device__ __forceinline__ float bz_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// D[row][col] = sum_k A[row][k] B[k][col], k = 2 r + part: B = a planar buffer (row 2r = Re, 2r + 1 = Im of
+// residue r, n2pad columns), A = the DFT coefficients of ALL n1 output rows (Re / Im row pairs), packed by
+// pack_bz_coefficients.  One wave = 32 columns x 3 row tiles of 32 (16 complex rows each); blockIdx.z = the
+// group of 3 row tiles.  Same register-blocked operand stream as fwd_cols_kernel (k_forward.hip).
+// MODE 0: out = conj(D Bhat[k1][k2]); MODE 1: out = D T_L[k1][k2].
+template <int MODE, int kStep>
+__global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float *__restrict__ in, float *__restrict__ out)
+{
+    constexpr int NT = 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ctile = blockIdx.x * 4 + wave;
+    const int clip = blockIdx.y;
+    const int tile0 = blockIdx.z * NT;
+    if (ctile * 32 >= bz.n2) return;
+    const int hb = lane >> 5, j = lane & 31;
+    const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad;
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in + clip * plane), (short)0, (int)(plane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(bz.apack), (short)0, bz.n1 * bz.n_tiles * 256, 0x00020000); // [r][tile][lane]
+    const int vb = (hb * bz.n2pad + ctile * 32 + j) * 4;
+    const int va = (tile0 * 64 + lane) * 4;
+    const int sb = 2 * bz.n2pad * 4; // bytes per residue in the planar buffer
+    const int sa = bz.n_tiles * 256; // bytes per residue in the coefficient image
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
+    float a0[kStep][NT], b0[kStep], a1[kStep][NT], b1[kStep];
+    const int nblocks = (bz.n1 + kStep - 1) / kStep;
+#pragma unroll
+    for (int s = 0; s < kStep; ++s) {
+        b0[s] = bz_ld(rb, vb, s * sb);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a0[s][t] = bz_ld(ra, va + t * 256, s * sa);
+    }
+#pragma unroll 1
+    for (int blk = 0; blk < nblocks; blk += 2) {
+        const int r1 = (blk + 1) * kStep, r2 = (blk + 2) * kStep;
+#pragma unroll
+        for (int s = 0; s < kStep; ++s) {
+            b1[s] = bz_ld(rb, vb, (r1 + s) * sb);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a1[s][t] = bz_ld(ra, va + t * 256, (r1 + s) * sa);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s][t], b0[s], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < kStep; ++s) {
+            b0[s] = bz_ld(rb, vb, (r2 + s) * sb);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a0[s][t] = bz_ld(ra, va + t * 256, (r2 + s) * sa);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][t], b1[s], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // D layout: column = lane & 31; registers (2q, 2q+1) of a tile = Re / Im of complex row
+    // tile * 16 + (q & 1) + 4 (q >> 1) + 2 (lane >> 5)
+    const int k2 = ctile * 32 + j;
+    if (k2 >= bz.n2) return;
+    const cf *__restrict__ tab = MODE == 0 ? bz.bhat : bz.tl;
+    float *__restrict__ o = out + clip * plane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k1 = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
+            if (k1 < bz.n1) {
+                const cf v = c_mul(cf{acc[t][2 * q], acc[t][2 * q + 1]}, tab[(int64_t)k1 * bz.n2 + k2]);
+                o[(int64_t)2 * k1 * bz.n2pad + k2] = v.r;
+                o[(int64_t)(2 * k1 + 1) * bz.n2pad + k2] = MODE == 0 ? -v.i : v.i;
+            }
+        }
+    }
+}
+
+// host: coefficient image [r][tile][lane] of the full length-n1 DFT for the MFMA A operand: lane l supplies
+// A[row = 32 tile + (l & 31)][k = 2 r + (l >> 5)]; row 2 k1 = Re row (dr, -di), 2 k1 + 1 = Im row (di, dr);
+// n_tiles is a multiple of 3, rows past 2 n1 are zero
+void pack_bz_coefficients(int n1, const float *tw_n1_ri, int n_tiles, float *apack)
+{
+    for (int r = 0; r < n1; ++r)
+        for (int t = 0; t < n_tiles; ++t)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 32 * t + (l & 31), k1 = row >> 1, part = l >> 5;
+                float v = 0.0f;
+                if (k1 < n1) {
+                    const int64_t idx = ((int64_t)r * k1) % n1;
+                    const float dr = tw_n1_ri[2 * idx], di = tw_n1_ri[2 * idx + 1];
+                    if ((row & 1) == 0) v = part == 0 ? dr : -di;
+                    else v = part == 0 ? di : dr;
+                }
+                apack[((size_t)r * n_tiles + t) * 64 + l] = v;
+            }
+}
+
+size_t bz_plane_bytes(const BzArgs &bz, int n_clips) { return (size_t)n_clips * 2 * bz.n1 * bz.n2pad * sizeof(float); }
+
+template <int MODE, int STEP>
+static void launch_bz_cols_step(const BzArgs &bz, const float *in, float *out, int n_clips, hipStream_t s)
+{
+    dim3 grid(((bz.n2 + 31) / 32 + 3) / 4, n_clips, bz.n_tiles / 3);
+    hipLaunchKernelGGL((bz_cols_kernel<MODE, STEP>), grid, dim3(256), 0, s, bz, in, out);
+}
+
+template <int MODE>
+static void launch_bz_cols(const BzArgs &bz, const float *in, float *out, int n_clips, hipStream_t s)
+{
+    auto padded = [&](int step) { return ((bz.n1 + step - 1) / step + 1) / 2 * 2 * step; }; // residues the loop walks
+    int best = 16;
+    for (int step : {15, 14})
+        if (padded(step) < padded(best)) best = step;
+    if (best == 16)
+        launch_bz_cols_step<MODE, 16>(bz, in, out, n_clips, s);
+    else if (best == 15)
+        launch_bz_cols_step<MODE, 15>(bz, in, out, n_clips, s);
+    else
+        launch_bz_cols_step<MODE, 14>(bz, in, out, n_clips, s);
+}
+
+static void bz_rows_attr()
+{
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bz_rows_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bz_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set.mark();
+    }
+}
+
+// d_pairs: pcm_pairs output for the [n2][n1] matrix padded with zeros -> planar Y' (bz_plane_bytes)
+void launch_bz_rows_first(const RowsArgs &rows, const BzArgs &bz, const i16x2 *d_pairs, int n_clips, float *d_out, hipStream_t s)
+{
+    bz_rows_attr();
+    hipLaunchKernelGGL(bz_rows_kernel<0>, dim3(n_clips, bz.n1), dim3(kBzThreads), (size_t)rows.n2 * sizeof(cf), s, rows, bz,
+                       d_pairs, (const float *)nullptr, d_out, (cf *)nullptr);
+}
+
+// mode 0: Y' -> C = conj(A Bhat); mode 1: C -> E = D T_L; both planar, in and out distinct
+void launch_bz_cols(const BzArgs &bz, int mode, const float *d_in, float *d_out, int n_clips, hipStream_t s)
+{
+    if (mode == 0)
+        launch_bz_cols<0>(bz, d_in, d_out, n_clips, s);
+    else
+        launch_bz_cols<1>(bz, d_in, d_out, n_clips, s);
+}
+
+// planar E -> x [n_clips][kmax - kmin]
+void launch_bz_rows_last(const RowsArgs &rows, const BzArgs &bz, const float *d_in, int n_clips, cf *d_x, hipStream_t s)
+{
+    bz_rows_attr();
+    hipLaunchKernelGGL(bz_rows_kernel<1>, dim3(n_clips, bz.n1), dim3(kBzThreads), (size_t)rows.n2 * sizeof(cf), s, rows, bz,
+                       (const i16x2 *)nullptr, d_in, (float *)nullptr, d_x);
+}
+
+} // namespace hpfw

@@ -25,8 +25,10 @@ constexpr int kPairsTileMax = 128; // time steps per tile; fewer when n1 is larg
 
 // VEC: the tile (nt * n1 samples) is copied in 16-byte pieces -- the launcher checks that every tile
 // starts 16-byte aligned and holds a multiple of 8 samples; otherwise sample by sample.
+// n: samples between consecutive clips; n_valid: samples of a clip that exist (the chirp-z transform pads the
+// [n2][n1] matrix with zeros beyond them: n_valid < n1 n2)
 template <bool VEC>
-__global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n2, int kPairsTile,
+__global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int64_t n_valid, int n1, int n2, int kPairsTile,
                                                         const int16_t *__restrict__ pcm, i16x2 *__restrict__ pairs)
 {
     int16_t *tile = reinterpret_cast<int16_t *>(smem_raw); // [kPairsTile][n1]
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int n1, int n
         uint4 *t4 = reinterpret_cast<uint4 *>(tile);
         for (int i = tid; i < nt * n1 / 8; i += 256) t4[i] = s4[i];
     } else {
-        for (int i = tid; i < nt * n1; i += 256) tile[i] = src[i];
+        const int64_t left = n_valid - (int64_t)t0 * n1; // samples of this tile that exist
+        for (int i = tid; i < nt * n1; i += 256) tile[i] = i < left ? src[i] : (int16_t)0;
     }
     __syncthreads();
     i16x2 *dst = pairs + (int64_t)clip * np * n2 + t0;
@@ -177,6 +180,14 @@ __global__ __launch_bounds__(256, 2) void fwd_cols_kernel(ColsArgs ca, int tile0
 
 void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s)
 {
+    if (n != (int64_t)n1 * n2) { // a clip shorter than the matrix (chirp-z path): bounds-checked copy
+        int tile = kPairsTileMax;
+        while (tile > 1 && (size_t)tile * n1 * sizeof(int16_t) > 60 * 1024) tile /= 2;
+        dim3 grid((n2 + tile - 1) / tile, n_clips);
+        const size_t lds = ((size_t)tile * n1 * sizeof(int16_t) + 15) / 16 * 16;
+        hipLaunchKernelGGL(pcm_pairs_kernel<false>, grid, dim3(256), lds, s, n, n, n1, n2, tile, d_pcm, d_pairs);
+        return;
+    }
     int kPairsTile = kPairsTileMax;
     while (kPairsTile > 1 && (size_t)kPairsTile * n1 * sizeof(int16_t) > 60 * 1024) kPairsTile /= 2;
     dim3 grid((n2 + kPairsTile - 1) / kPairsTile, n_clips);
@@ -185,9 +196,9 @@ void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_cli
                      (tail * n1 % 8 == 0);
     const size_t lds = ((size_t)kPairsTile * n1 * sizeof(int16_t) + 15) / 16 * 16;
     if (vec)
-        hipLaunchKernelGGL(pcm_pairs_kernel<true>, grid, dim3(256), lds, s, n, n1, n2, kPairsTile, d_pcm, d_pairs);
+        hipLaunchKernelGGL(pcm_pairs_kernel<true>, grid, dim3(256), lds, s, n, n, n1, n2, kPairsTile, d_pcm, d_pairs);
     else
-        hipLaunchKernelGGL(pcm_pairs_kernel<false>, grid, dim3(256), lds, s, n, n1, n2, kPairsTile, d_pcm, d_pairs);
+        hipLaunchKernelGGL(pcm_pairs_kernel<false>, grid, dim3(256), lds, s, n, n, n1, n2, kPairsTile, d_pcm, d_pairs);
 }
 
 size_t fwd_rows_lds_bytes(const RowsArgs &a) { return (size_t)a.n2 * sizeof(cf); }

@@ -257,21 +257,16 @@ void par_collector_save(hpfw_legacy_collector *c, const char *cache)
     }
 }
 
-// A file of any length: the PCM is padded with zeros up to the next supported (7-smooth) length --
-// at most 0.8 % more samples; the reference transforms the exact length with FFTW, so this is a
-// deviation, confined to the file entry points and switched off by HPFW_STRICT_LENGTH.
+// A file of any length: the reference hands the exact sample count to NSGConstantQ (cqt.h:54-55) and so does
+// this -- lengths with a prime factor above 7 take the chirp-z forward transform (k_bluestein.hip); nothing is padded.
 static bool read_clip(const std::string &path, std::vector<int16_t> &pcm, std::string &why)
 {
     try { // nothing may throw through the C boundary (or out of a reader thread): e.g. bad_alloc on a huge file
-        if (!read_wav_pcm16_mono(path, pcm, why)) return false;
+        return read_wav_pcm16_mono(path, pcm, why);
     } catch (const std::exception &e) {
         why = path + ": " + e.what();
         return false;
     }
-    if (std::getenv("HPFW_STRICT_LENGTH")) return true;
-    const int64_t want = hpfw_gpu_supported_length((int64_t)pcm.size());
-    if (want > (int64_t)pcm.size()) pcm.resize((size_t)want, 0);
-    return true;
 }
 
 static uint64_t *calc_hashprint_impl(hpfw_legacy_collector *c, const char *filename, int *size)
@@ -542,6 +537,8 @@ static void collect_cached(hpfw_legacy_collector *c, const std::vector<std::stri
         };
         std::vector<Item> items(end - at);
         host_team((int)items.size(), [&](int i) { items[(size_t)i].ok = load_spectro_cereal(paths[at + (size_t)i], items[(size_t)i].cm, items[(size_t)i].cols); });
+        std::vector<uint64_t *> win_hp(items.size(), nullptr);
+        std::vector<int> win_size(items.size(), 0);
         std::map<int32_t, std::vector<int>> by_cols;
         for (size_t i = 0; i < items.size(); ++i)
             if (items[i].ok && items[i].cols >= HPFW_CONTEXT + HPFW_LAG) by_cols[items[i].cols].push_back((int)i);
@@ -565,10 +562,15 @@ static void collect_cached(hpfw_legacy_collector *c, const std::vector<std::stri
                 !group_hashprints(c->gpu, (const float *)d_db.p, pos.size(), g, out.data()))
                 continue;
             for (size_t k = 0; k < pos.size(); ++k) {
-                stems.push_back(std::filesystem::path(paths[at + (size_t)pos[k]]).filename().string());
-                hp.push_back(out[k]);
-                hp_size.push_back((int)g.n_hp);
+                win_hp[(size_t)pos[k]] = out[k];
+                win_size[(size_t)pos[k]] = (int)g.n_hp;
             }
+        }
+        for (size_t i = 0; i < items.size(); ++i) { // groups ran by width; the results keep the sorted order
+            if (!win_hp[i]) continue;
+            stems.push_back(std::filesystem::path(paths[at + i]).filename().string());
+            hp.push_back(win_hp[i]);
+            hp_size.push_back(win_size[i]);
         }
         at = end;
     }

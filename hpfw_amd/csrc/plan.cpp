@@ -223,7 +223,155 @@ static void parallel_rows(int64_t n, F fn)
     for (auto &t : th) t.join();
 }
 
-bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
+// ---- S16: the double-precision DFT behind the Bluestein tables ------------------------------------
+namespace {
+int smallest_prime_factor(int64_t n)
+{
+    for (int64_t f = 2; f * f <= n; ++f)
+        if (n % f == 0) return (int)f;
+    return (int)n;
+}
+
+int largest_prime_factor(int64_t n)
+{
+    int l = 1;
+    while (n > 1) {
+        const int f = smallest_prime_factor(n);
+        l = std::max(l, f);
+        n /= f;
+    }
+    return l;
+}
+
+// levels of the recursion for one length, with the twiddle table T_n' of every level (read-only afterwards,
+// so that many host threads can transform their own sequences at once)
+struct DftPlanD {
+    std::vector<int64_t> ns;
+    std::vector<int> ps;
+    std::vector<std::vector<double>> twr, twi;
+    explicit DftPlanD(int64_t n)
+    {
+        while (n > 1) {
+            const int p = smallest_prime_factor(n);
+            ns.push_back(n);
+            ps.push_back(p);
+            std::vector<double> r((size_t)n), i((size_t)n);
+            for (int64_t j = 0; j < n; ++j) twiddle_d(j, n, r[(size_t)j], i[(size_t)j]);
+            twr.push_back(std::move(r));
+            twi.push_back(std::move(i));
+            n /= p;
+        }
+    }
+    // out-of-place: in (stride `st`) -> out[0..n), tmp[0..n) is scratch
+    void rec(size_t level, const double *ir, const double *ii, int64_t st, double *outr, double *outi, double *tr, double *ti) const
+    {
+        if (level == ns.size()) {
+            outr[0] = ir[0];
+            outi[0] = ii[0];
+            return;
+        }
+        const int64_t n = ns[level], m = n / ps[level];
+        const int p = ps[level];
+        for (int q = 0; q < p; ++q)
+            rec(level + 1, ir + q * st, ii + q * st, st * p, tr + q * m, ti + q * m, outr + q * m, outi + q * m);
+        const double *wr = twr[level].data(), *wi = twi[level].data();
+        for (int64_t k = 0; k < n; ++k) {
+            const int64_t km = k % m;
+            double ar = tr[km], ai = ti[km];
+            for (int q = 1; q < p; ++q) {
+                const int64_t j = (q * k) % n;
+                const double fr = tr[q * m + km], fi = ti[q * m + km];
+                ar = ar + (wr[j] * fr - wi[j] * fi);
+                ai = ai + (wr[j] * fi + wi[j] * fr);
+            }
+            outr[k] = ar;
+            outi[k] = ai;
+        }
+    }
+    // in place on re / im [n]; scratch: 2 n doubles each
+    void run(double *re, double *im, std::vector<double> &scratch) const
+    {
+        const int64_t n = ns.empty() ? 1 : ns[0];
+        scratch.resize((size_t)(4 * n));
+        double *outr = scratch.data(), *outi = outr + n, *tr = outi + n, *ti = tr + n;
+        rec(0, re, im, 1, outr, outi, tr, ti);
+        std::memcpy(re, outr, sizeof(double) * (size_t)n);
+        std::memcpy(im, outi, sizeof(double) * (size_t)n);
+    }
+};
+} // namespace
+
+void dft_generic_d(double *re, double *im, int64_t n)
+{
+    DftPlanD plan(n);
+    std::vector<double> scratch;
+    plan.run(re, im, scratch);
+}
+
+// S15: tables of the chirp-z forward transform (see build_plan)
+static void build_bluestein_tables(HostPlan &p)
+{
+    const int64_t n = p.n, n1 = p.n1, n2 = p.n2, big_l = p.bz_l, nk = p.kmax - p.kmin;
+    auto chirp = [&](int64_t m, double &re, double &im) { // w[m] = e^{-i pi m^2 / N} = T_{2N}[m^2 mod 2N]
+        const int64_t mm = m < 0 ? -m : m;
+        twiddle_d((int64_t)(((__int128)mm * mm) % (2 * n)), 2 * n, re, im);
+    };
+    p.bz_w.assign((size_t)big_l, HostCf{0.0f, 0.0f});
+    p.bz_tl.resize((size_t)big_l);
+    parallel_rows(n1, [&](int64_t r) {
+        for (int64_t t = 0; t < n2; ++t) {
+            const int64_t idx = r + n1 * t;
+            if (idx < n) {
+                double c, s;
+                chirp(idx, c, s);
+                p.bz_w[(size_t)(r * n2 + t)] = {(float)c, (float)s};
+            }
+            p.bz_tl[(size_t)(r * n2 + t)] = twiddle_f(r * t, big_l);
+        }
+    });
+    p.bz_wk.resize((size_t)nk);
+    for (int64_t k = p.kmin; k < p.kmax; ++k) {
+        double c, s;
+        chirp(k, c, s);
+        p.bz_wk[(size_t)(k - p.kmin)] = {(float)(c / (double)big_l), (float)(s / (double)big_l)};
+    }
+    // Bhat = DFT_L(b), b[m mod L] = conj(w[m]) for the lags m in [kmin - (N - 1), kmax - 1], in double:
+    // rows (length n2 over t for every residue r), times W_L^{r k2}, columns (length n1 over r for every k2)
+    std::vector<double> yr((size_t)big_l, 0.0), yi((size_t)big_l, 0.0); // [r][t], then [r][k2]
+    const int64_t mlo = p.kmin - (n - 1), mhi = p.kmax - 1;
+    for (int64_t m = mlo; m <= mhi; ++m) {
+        const int64_t idx = ((m % big_l) + big_l) % big_l;
+        double c, s;
+        chirp(m, c, s);
+        yr[(size_t)((idx % n1) * n2 + idx / n1)] = c;
+        yi[(size_t)((idx % n1) * n2 + idx / n1)] = -s;
+    }
+    const DftPlanD rows_plan(n2), cols_plan(n1);
+    parallel_rows(n1, [&](int64_t r) {
+        std::vector<double> scratch;
+        double *re = yr.data() + r * n2, *im = yi.data() + r * n2;
+        rows_plan.run(re, im, scratch);
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            double wr, wi;
+            twiddle_d((r * k2) % big_l, big_l, wr, wi);
+            const double gr = re[k2], gi = im[k2];
+            re[k2] = gr * wr - gi * wi;
+            im[k2] = gr * wi + gi * wr;
+        }
+    });
+    p.bz_bhat.resize((size_t)big_l);
+    parallel_rows(n2, [&](int64_t k2) {
+        std::vector<double> scratch, cr((size_t)n1), ci((size_t)n1);
+        for (int64_t r = 0; r < n1; ++r) {
+            cr[(size_t)r] = yr[(size_t)(r * n2 + k2)];
+            ci[(size_t)r] = yi[(size_t)(r * n2 + k2)];
+        }
+        cols_plan.run(cr.data(), ci.data(), scratch);
+        for (int64_t k1 = 0; k1 < n1; ++k1) p.bz_bhat[(size_t)(k1 * n2 + k2)] = {(float)cr[(size_t)k1], (float)ci[(size_t)k1]};
+    });
+}
+
+bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bool force_bluestein)
 {
     if (n < 2) {
         why = "clip too short";
@@ -274,7 +422,22 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
     // smallest n1
     int64_t n1 = 0, d0 = 0;
     int best_odd = 2, best_groups = 1 << 30;
-    for (int64_t d = 1; d <= n; ++d) {
+    {
+        int64_t rest = n;
+        for (int f : {2, 3, 5, 7})
+            while (rest % f == 0) rest /= f;
+        p.bluestein = force_bluestein || rest != 1;
+    }
+    if (p.bluestein) {
+        // S15: a chirp-z convolution of length L = n1 * 6300 >= N + (kmax - kmin) - 1; the column DFT over the
+        // n1 residues is dense (matrix cores), so n1 only has to keep the host's table DFT cheap: its prime
+        // factors stay at or below 31
+        const int64_t need = n + (kmax - kmin) - 1;
+        n1 = (need + 6299) / 6300;
+        while (largest_prime_factor(n1) > 31) ++n1;
+        p.bz_l = n1 * 6300;
+    }
+    for (int64_t d = 1; !p.bluestein && d <= n; ++d) {
         if (n % d || n / d > kN2Max) continue;
         if (d0 == 0) d0 = d;
         if (4 * d > 5 * d0) break;
@@ -291,10 +454,10 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
         why = "clip length has a prime factor other than 2, 3, 5, 7";
         return false;
     }
-    const int64_t n2 = n / n1;
+    const int64_t n2 = p.bluestein ? 6300 : n / n1;
     std::vector<int> tmp;
     std::vector<int> desc;
-    if (!make_radix_list(n2, desc) || !make_radix_list(n1, tmp)) {
+    if (!make_radix_list(n2, desc) || (!p.bluestein && !make_radix_list(n1, tmp))) {
         why = "clip length has a prime factor other than 2, 3, 5, 7";
         return false;
     }
@@ -340,10 +503,14 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only)
             len /= g.first * g.second;
         }
     }
-    p.tw_big.resize((size_t)n1 * p.h);
-    parallel_rows(n1, [&](int64_t a) {
-        for (int64_t k2 = 0; k2 < p.h; ++k2) p.tw_big[(size_t)(a * p.h + k2)] = twiddle_f(a * k2, n);
-    });
+    if (p.bluestein) {
+        build_bluestein_tables(p);
+    } else {
+        p.tw_big.resize((size_t)n1 * p.h);
+        parallel_rows(n1, [&](int64_t a) {
+            for (int64_t k2 = 0; k2 < p.h; ++k2) p.tw_big[(size_t)(a * p.h + k2)] = twiddle_f(a * k2, n);
+        });
+    }
     p.pos_n2.resize((size_t)n2);
     for (int64_t k = 0; k < n2; ++k) p.pos_n2[(size_t)k] = (int)digit_pos(k, n2, p.radix);
     // the last fused group (R1, R2) works on blocks of len = R1 R2 consecutive positions; block b holds
@@ -569,14 +736,12 @@ void mel_tables(std::vector<float> &window, std::vector<float> &cpack)
 
 } // namespace hpfw
 
-// the smallest supported clip length >= n_samples (include/hpfw_gpu.h), or -1
+// the smallest supported clip length >= n_samples (include/hpfw_gpu.h), or -1: every length from the
+// shortest clip that yields a hashprint up to the longest the tables allow is supported (lengths with prime
+// factors above 7 take the chirp-z forward transform), so this is n_samples itself inside that range
 extern "C" int64_t hpfw_gpu_supported_length(int64_t n_samples)
 {
     for (int64_t n = n_samples > 2 ? n_samples : 2; n <= (int64_t)44100 * 1600; ++n) {
-        int64_t m = n;
-        for (int f : {2, 3, 5, 7})
-            while (m % f == 0) m /= f;
-        if (m != 1) continue;
         hpfw::HostPlan hp;
         std::string why;
         if (hpfw::build_plan(n, hp, why, true)) {
@@ -592,10 +757,18 @@ extern "C" int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8)
 {
     hpfw::HostPlan p;
     std::string why;
-    if (!out8 || !hpfw::build_plan(n_samples, p, why)) return -2;
+    const bool force = n_samples < 0; // negative length: the chirp-z tables of |n_samples| even when it is 7-smooth
+    if (force) n_samples = -n_samples;
+    if (!out8 || !hpfw::build_plan(n_samples, p, why, false, force)) return -2;
     out8[0] = fnv1a(p.tw_n2.data(), p.tw_n2.size() * 8);
     out8[1] = fnv1a(p.tw_n1.data(), p.tw_n1.size() * 8);
     out8[2] = fnv1a(p.tw_big.data(), p.tw_big.size() * 8);
+    if (p.bluestein) { // the chirp-z tables stand where T_N stands for 7-smooth lengths
+        uint64_t hb = fnv1a(p.bz_w.data(), p.bz_w.size() * 8);
+        hb = fnv1a(p.bz_tl.data(), p.bz_tl.size() * 8, hb);
+        hb = fnv1a(p.bz_bhat.data(), p.bz_bhat.size() * 8, hb);
+        out8[2] = fnv1a(p.bz_wk.data(), p.bz_wk.size() * 8, hb);
+    }
     out8[3] = fnv1a(p.pos_n2.data(), p.pos_n2.size() * 4);
     uint64_t h = fnv1a(p.start, sizeof(p.start));
     h = fnv1a(p.lg, sizeof(p.lg), h);

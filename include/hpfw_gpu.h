@@ -45,7 +45,7 @@ extern "C" {
 typedef enum {
     HPFW_OK = 0,
     HPFW_E_INVALID = -1,     /* bad argument                                       */
-    HPFW_E_UNSUPPORTED = -2, /* clip length not 7-smooth / too short / too long    */
+    HPFW_E_UNSUPPORTED = -2, /* clip too short (below ~1.3 s) or too long (~18 min) */
     HPFW_E_NOFILTERS = -3,   /* extraction before hpfw_gpu_set_filters             */
     HPFW_E_HIP = -4,         /* a HIP runtime call failed (message has the detail) */
     HPFW_E_NOMEM = -5,
@@ -94,10 +94,11 @@ int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_sampl
 /* clips processed per internal pass (workspace = ~9.5 MB per clip at 30 s); 0 = default (1024) */
 int hpfw_gpu_set_batch(hpfw_gpu *h, int clips_per_pass);
 
-/* The smallest supported clip length >= n_samples (lengths must be 7-smooth), or
- * -1 beyond the longest supported clip.  Host-only.  The file entry points (par_collector_*) pad a
- * file with zeros up to it -- at most 0.8 % more samples -- unless HPFW_STRICT_LENGTH is set; the
- * PCM entry points never alter their input and reject other lengths. */
+/* The smallest supported clip length >= n_samples, or -1 beyond the longest supported clip.  Host-only.
+ * Any length between the shortest clip that yields a hashprint (54 254 samples, 1.23 s) and the longest the
+ * tables allow is supported as it is -- the reference hands the file's exact sample count to NSGConstantQ
+ * (cqt.h:54-55): 7-smooth lengths (every multiple of 1/7 s at 44.1 kHz among them) take the mixed-radix forward
+ * transform, all others the chirp-z (Bluestein) one, about three times slower.  Nothing is padded. */
 int64_t hpfw_gpu_supported_length(int64_t n_samples);
 
 /* ---- per-stage entry points (parity checkpoints; same kernels the full chain runs) ------- */

@@ -322,6 +322,13 @@ struct hpfw_oracle_plan {
     cf *g[HPFW_O_BINS]; /* window * chirp / (M * P), length lg[j]  */
     int n_cls;
     bluestein_class bc[8];
+    /* S15: forward DFT of a clip whose length has a prime factor above 7, as a chirp-z convolution */
+    int bluestein;
+    int64_t bz_l;    /* L = n1 * n2 >= N + (kmax - kmin) - 1, n2 = 6300 */
+    cf *bz_w;        /* [n1][n2]: w[r + n1 t] = e^{-i pi n^2 / N}, 0 from n = N on */
+    cf *bz_tl;       /* [n1][n2]: T_L[r k2]                                          */
+    cf *bz_bhat;     /* [n1][n2]: DFT_L(conj chirp)[n2 k1 + k2]                      */
+    cf *bz_wk;       /* [kmax - kmin]: w[k] / L                                      */
 };
 
 /* essentia NSGConstantQ::designWindow as configured at cqt.h:54-61: band centres
@@ -494,11 +501,226 @@ static int make_bluestein(hpfw_oracle_plan *p)
     return 0;
 }
 
-hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n)
+/* ------------------------------------------------------------------------------------------ */
+/* S16: DFT of length n in double (prime factors of n at most 31), used only to build tables:    */
+/* recursive decimation in time by the smallest prime factor p (m = n / p):                       */
+/*   X[k] = F_0[k mod m] + sum_{q=1}^{p-1} W_n^{q k} F_q[k mod m],  F_q = DFT_m(x[q + p t]),     */
+/* the sum in ascending q, every product as (wr fr - wi fi, wr fi + wi fr), W from twiddle_d.     */
+/* ------------------------------------------------------------------------------------------ */
+static int smallest_prime_factor(int64_t n)
+{
+    for (int64_t f = 2; f * f <= n; ++f)
+        if (n % f == 0) return (int)f;
+    return (int)n;
+}
+
+typedef struct {
+    int levels;
+    int64_t n[64];
+    int p[64];
+    double *wr[64], *wi[64];
+} dftd_plan;
+
+static void dftd_init(dftd_plan *d, int64_t n)
+{
+    d->levels = 0;
+    while (n > 1) {
+        int p = smallest_prime_factor(n), l = d->levels++;
+        d->n[l] = n;
+        d->p[l] = p;
+        d->wr[l] = (double *)malloc(sizeof(double) * (size_t)n);
+        d->wi[l] = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int64_t j = 0; j < n; ++j) twiddle_d(j, n, &d->wr[l][j], &d->wi[l][j]);
+        n /= p;
+    }
+}
+
+static void dftd_free(dftd_plan *d)
+{
+    for (int l = 0; l < d->levels; ++l) {
+        free(d->wr[l]);
+        free(d->wi[l]);
+    }
+}
+
+/* in (stride st) -> out[0..n); tmp[0..n) scratch */
+static void dftd_rec(const dftd_plan *d, int level, const double *ir, const double *ii, int64_t st, double *outr,
+                     double *outi, double *tr, double *ti)
+{
+    if (level == d->levels) {
+        outr[0] = ir[0];
+        outi[0] = ii[0];
+        return;
+    }
+    int64_t n = d->n[level];
+    int p = d->p[level];
+    int64_t m = n / p;
+    for (int q = 0; q < p; ++q)
+        dftd_rec(d, level + 1, ir + q * st, ii + q * st, st * p, tr + q * m, ti + q * m, outr + q * m, outi + q * m);
+    const double *wr = d->wr[level], *wi = d->wi[level];
+    for (int64_t k = 0; k < n; ++k) {
+        int64_t km = k % m;
+        double ar = tr[km], ai = ti[km];
+        for (int q = 1; q < p; ++q) {
+            int64_t j = (q * k) % n;
+            double fr = tr[q * m + km], fi = ti[q * m + km];
+            ar = ar + (wr[j] * fr - wi[j] * fi);
+            ai = ai + (wr[j] * fi + wi[j] * fr);
+        }
+        outr[k] = ar;
+        outi[k] = ai;
+    }
+}
+
+/* in place on re / im [n]; scratch holds 4 n doubles */
+static void dftd_run(const dftd_plan *d, double *re, double *im, double *scratch)
+{
+    int64_t n = d->levels ? d->n[0] : 1;
+    double *outr = scratch, *outi = outr + n, *tr = outi + n, *ti = tr + n;
+    dftd_rec(d, 0, re, im, 1, outr, outi, tr, ti);
+    memcpy(re, outr, sizeof(double) * (size_t)n);
+    memcpy(im, outi, sizeof(double) * (size_t)n);
+}
+
+void hpfw_oracle_dft_double(double *re, double *im, int64_t n)
+{
+    dftd_plan d;
+    dftd_init(&d, n);
+    double *scratch = (double *)malloc(sizeof(double) * (size_t)(4 * n));
+    dftd_run(&d, re, im, scratch);
+    free(scratch);
+    dftd_free(&d);
+}
+
+/* w[m] = e^{-i pi m^2 / N} = T_{2N}[m^2 mod 2N] in double */
+static void bz_chirp_d(int64_t m, int64_t n, double *re, double *im)
+{
+    int64_t mm = m < 0 ? -m : m;
+    twiddle_d((int64_t)(((__int128)mm * mm) % (2 * n)), 2 * n, re, im);
+}
+
+/* S15 tables.  X[k] = w[k] sum_n (x[n] w[n]) conj(w[k - n]): a convolution with the lags
+ * m = k - n in [kmin - (N - 1), kmax - 1], evaluated cyclically at length L >= N + (kmax - kmin) - 1. */
+static void make_forward_bluestein(hpfw_oracle_plan *p)
+{
+    const int64_t n = p->info.n_samples, n1 = p->info.n1, n2 = p->info.n2, big_l = p->bz_l;
+    const int64_t nk = p->info.kmax - p->info.kmin;
+    p->bz_w = (cf *)calloc((size_t)big_l, sizeof(cf));
+    p->bz_tl = (cf *)malloc(sizeof(cf) * (size_t)big_l);
+    for (int64_t r = 0; r < n1; ++r)
+        for (int64_t t = 0; t < n2; ++t) {
+            int64_t idx = r + n1 * t;
+            if (idx < n) {
+                double c, s2;
+                bz_chirp_d(idx, n, &c, &s2);
+                p->bz_w[r * n2 + t].r = (float)c;
+                p->bz_w[r * n2 + t].i = (float)s2;
+            }
+            hpfw_oracle_twiddle(r * t, big_l, &p->bz_tl[r * n2 + t].r, &p->bz_tl[r * n2 + t].i);
+        }
+    p->bz_wk = (cf *)malloc(sizeof(cf) * (size_t)nk);
+    for (int64_t k = p->info.kmin; k < p->info.kmax; ++k) {
+        double c, s2;
+        bz_chirp_d(k, n, &c, &s2);
+        p->bz_wk[k - p->info.kmin].r = (float)(c / (double)big_l);
+        p->bz_wk[k - p->info.kmin].i = (float)(s2 / (double)big_l);
+    }
+    double *yr = (double *)calloc((size_t)big_l, sizeof(double)), *yi = (double *)calloc((size_t)big_l, sizeof(double));
+    for (int64_t m = p->info.kmin - (n - 1); m <= p->info.kmax - 1; ++m) {
+        int64_t idx = ((m % big_l) + big_l) % big_l;
+        double c, s2;
+        bz_chirp_d(m, n, &c, &s2);
+        yr[(idx % n1) * n2 + idx / n1] = c;
+        yi[(idx % n1) * n2 + idx / n1] = -s2;
+    }
+    dftd_plan rows, cols;
+    dftd_init(&rows, n2);
+    dftd_init(&cols, n1);
+    int64_t big = n1 > n2 ? n1 : n2;
+    double *scratch = (double *)malloc(sizeof(double) * (size_t)(4 * big));
+    for (int64_t r = 0; r < n1; ++r) {
+        double *re = yr + r * n2, *im = yi + r * n2;
+        dftd_run(&rows, re, im, scratch);
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            double wr, wi;
+            twiddle_d((r * k2) % big_l, big_l, &wr, &wi);
+            double gr = re[k2], gi = im[k2];
+            re[k2] = gr * wr - gi * wi;
+            im[k2] = gr * wi + gi * wr;
+        }
+    }
+    p->bz_bhat = (cf *)malloc(sizeof(cf) * (size_t)big_l);
+    double *cr = (double *)malloc(sizeof(double) * (size_t)n1), *ci = (double *)malloc(sizeof(double) * (size_t)n1);
+    for (int64_t k2 = 0; k2 < n2; ++k2) {
+        for (int64_t r = 0; r < n1; ++r) {
+            cr[r] = yr[r * n2 + k2];
+            ci[r] = yi[r * n2 + k2];
+        }
+        dftd_run(&cols, cr, ci, scratch);
+        for (int64_t k1 = 0; k1 < n1; ++k1) {
+            p->bz_bhat[k1 * n2 + k2].r = (float)cr[k1];
+            p->bz_bhat[k1 * n2 + k2].i = (float)ci[k1];
+        }
+    }
+    free(cr);
+    free(ci);
+    free(scratch);
+    dftd_free(&rows);
+    dftd_free(&cols);
+    free(yr);
+    free(yi);
+}
+
+hpfw_oracle_plan *hpfw_oracle_plan_create2(int64_t n, int force_bluestein)
 {
     if (n < 2) return NULL;
     hpfw_oracle_plan *p = (hpfw_oracle_plan *)calloc(1, sizeof(*p));
     p->info.n_samples = n;
+    {
+        int64_t rest = n;
+        while (rest % 2 == 0) rest /= 2;
+        while (rest % 3 == 0) rest /= 3;
+        while (rest % 5 == 0) rest /= 5;
+        while (rest % 7 == 0) rest /= 7;
+        p->bluestein = force_bluestein || rest != 1;
+    }
+    if (p->bluestein) {
+        if (make_bands(p) != 0) {
+            free(p);
+            return NULL;
+        }
+        /* n2 = 6300; n1 = the smallest integer >= (N + nk - 1) / 6300 whose prime factors are <= 31 */
+        int64_t need = n + (p->info.kmax - p->info.kmin) - 1, n1 = (need + 6299) / 6300;
+        for (;; ++n1) {
+            int64_t r = n1, big = 1;
+            while (r > 1) {
+                int f = smallest_prime_factor(r);
+                if (f > big) big = f;
+                r /= f;
+            }
+            if (big <= 31) break;
+        }
+        if (n1 > 8192) {
+            free(p);
+            return NULL;
+        }
+        p->info.n1 = n1;
+        p->info.n2 = 6300;
+        p->info.h = 6300 / 2 + 1;
+        p->bz_l = n1 * 6300;
+        p->info.n_radix = make_rows_radix_list(6300, p->info.radix);
+        p->tw_n2 = make_twiddle_table(6300);
+        p->tw_n1 = make_twiddle_table(n1);
+        p->pos_n2 = (int32_t *)malloc(sizeof(int32_t) * 6300);
+        for (int64_t k = 0; k < 6300; ++k)
+            p->pos_n2[k] = (int32_t)hpfw_oracle_digit_pos(k, 6300, p->info.radix, p->info.n_radix);
+        make_forward_bluestein(p);
+        if (make_bluestein(p) != 0) {
+            hpfw_oracle_plan_destroy(p);
+            return NULL;
+        }
+        return p;
+    }
     /* N = n1 * n2 with n2 <= N2_MAX: d0 = the smallest divisor that fits; among the divisors in
      * [d0, 5 d0 / 4] prefer an even n2 (its twiddle table halves exactly), then the fewest pairs of
      * radix passes, then the smallest n1 */
@@ -553,6 +775,8 @@ hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n)
     return p;
 }
 
+hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n) { return hpfw_oracle_plan_create2(n, 0); }
+
 void hpfw_oracle_plan_destroy(hpfw_oracle_plan *p)
 {
     if (!p) return;
@@ -560,6 +784,10 @@ void hpfw_oracle_plan_destroy(hpfw_oracle_plan *p)
     free(p->tw_n1);
     free(p->tw_big);
     free(p->pos_n2);
+    free(p->bz_w);
+    free(p->bz_tl);
+    free(p->bz_bhat);
+    free(p->bz_wk);
     for (int j = 0; j < HPFW_O_BINS; ++j) free(p->g[j]);
     for (int k = 0; k < p->n_cls; ++k) {
         free(p->bc[k].tw);
@@ -583,8 +811,80 @@ void hpfw_oracle_plan_bands(const hpfw_oracle_plan *p, int32_t *start, int32_t *
 /*   residues n = a + n1 * n2', pairs of residues packed into one complex length-n2 FFT,         */
 /*   Hermitian split, twiddle T_N[a k2], then a length-n1 DFT as an fma chain over a.           */
 /* ------------------------------------------------------------------------------------------ */
+/* S15: the same bins when N has a prime factor above 7.  a[n] = x[n] w[n]; A = DFT_L(a) by rows (length n2
+ * over t for every residue r), T_L[r k2], columns (fma chain over r, as above); C = conj(A Bhat);
+ * F = DFT_L(C) by columns first (fma chain over j1 for every j2), T_L[j2 k1], rows (length n2 over j2):
+ * F[k1 + n1 k2]; X[k] = conj(F[k]) w[k] / L. */
+static void spectrum_bluestein(const hpfw_oracle_plan *p, const int16_t *pcm, float *x_ri)
+{
+    const int64_t n = p->info.n_samples, n1 = p->info.n1, n2 = p->info.n2;
+    cf *ya = (cf *)malloc(sizeof(cf) * (size_t)(n1 * n2)), *yb = (cf *)malloc(sizeof(cf) * (size_t)(n1 * n2));
+    cf *z = (cf *)malloc(sizeof(cf) * (size_t)n2);
+    for (int64_t r = 0; r < n1; ++r) {
+        for (int64_t t = 0; t < n2; ++t) {
+            int64_t idx = r + n1 * t;
+            float x = idx < n ? (float)pcm[idx] / 32768.0f : 0.0f;
+            cf w = p->bz_w[r * n2 + t];
+            z[t].r = x * w.r;
+            z[t].i = x * w.i;
+        }
+        fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
+        for (int64_t k2 = 0; k2 < n2; ++k2) ya[r * n2 + k2] = c_mul(z[p->pos_n2[k2]], p->bz_tl[r * n2 + k2]);
+    }
+    for (int64_t k1 = 0; k1 < n1; ++k1)
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            float ar = 0.0f, ai = 0.0f;
+            for (int64_t r = 0; r < n1; ++r) {
+                cf d = p->tw_n1[(r * k1) % n1];
+                cf y = ya[r * n2 + k2];
+                ar = fmaf(d.r, y.r, ar);
+                ar = fmaf(-d.i, y.i, ar);
+                ai = fmaf(d.i, y.r, ai);
+                ai = fmaf(d.r, y.i, ai);
+            }
+            cf acc = {ar, ai};
+            cf v = c_mul(acc, p->bz_bhat[k1 * n2 + k2]);
+            yb[k1 * n2 + k2].r = v.r;
+            yb[k1 * n2 + k2].i = -v.i;
+        }
+    for (int64_t k1 = 0; k1 < n1; ++k1)
+        for (int64_t j2 = 0; j2 < n2; ++j2) {
+            float ar = 0.0f, ai = 0.0f;
+            for (int64_t j1 = 0; j1 < n1; ++j1) {
+                cf d = p->tw_n1[(j1 * k1) % n1];
+                cf y = yb[j1 * n2 + j2];
+                ar = fmaf(d.r, y.r, ar);
+                ar = fmaf(-d.i, y.i, ar);
+                ai = fmaf(d.i, y.r, ai);
+                ai = fmaf(d.r, y.i, ai);
+            }
+            cf acc = {ar, ai};
+            ya[k1 * n2 + j2] = c_mul(acc, p->bz_tl[k1 * n2 + j2]);
+        }
+    for (int64_t k1 = 0; k1 < n1; ++k1) {
+        memcpy(z, ya + k1 * n2, sizeof(cf) * (size_t)n2);
+        fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            int64_t k = k1 + n1 * k2;
+            if (k < p->info.kmin || k >= p->info.kmax) continue;
+            cf f = z[p->pos_n2[k2]];
+            cf fc = {f.r, -f.i};
+            cf v = c_mul(fc, p->bz_wk[k - p->info.kmin]);
+            x_ri[2 * (k - p->info.kmin)] = v.r;
+            x_ri[2 * (k - p->info.kmin) + 1] = v.i;
+        }
+    }
+    free(z);
+    free(ya);
+    free(yb);
+}
+
 void hpfw_oracle_spectrum(const hpfw_oracle_plan *p, const int16_t *pcm, float *x_ri)
 {
+    if (p->bluestein) {
+        spectrum_bluestein(p, pcm, x_ri);
+        return;
+    }
     const int64_t n1 = p->info.n1, n2 = p->info.n2, h = p->info.h;
     cf *yp = (cf *)malloc(sizeof(cf) * (size_t)(n1 * h));
     cf *z = (cf *)malloc(sizeof(cf) * (size_t)n2);
@@ -1141,7 +1441,13 @@ void hpfw_oracle_plan_checksum(const hpfw_oracle_plan *p, uint64_t *out8)
     const uint64_t seed = 1469598103934665603ULL;
     out8[0] = fnv1a(p->tw_n2, (size_t)p->info.n2 * 8, seed);
     out8[1] = fnv1a(p->tw_n1, (size_t)p->info.n1 * 8, seed);
-    out8[2] = fnv1a(p->tw_big, (size_t)(p->info.n1 * p->info.h) * 8, seed);
+    out8[2] = p->tw_big ? fnv1a(p->tw_big, (size_t)(p->info.n1 * p->info.h) * 8, seed) : seed;
+    if (p->bluestein) { /* the chirp-z tables stand where T_N stands for 7-smooth lengths */
+        uint64_t hb = fnv1a(p->bz_w, (size_t)p->bz_l * 8, seed);
+        hb = fnv1a(p->bz_tl, (size_t)p->bz_l * 8, hb);
+        hb = fnv1a(p->bz_bhat, (size_t)p->bz_l * 8, hb);
+        out8[2] = fnv1a(p->bz_wk, (size_t)(p->info.kmax - p->info.kmin) * 8, hb);
+    }
     out8[3] = fnv1a(p->pos_n2, (size_t)p->info.n2 * 4, seed);
     uint64_t h = fnv1a(p->start, sizeof(p->start), seed);
     h = fnv1a(p->lg, sizeof(p->lg), h);

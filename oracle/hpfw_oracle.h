@@ -51,7 +51,12 @@ typedef struct {
 } hpfw_oracle_plan_info;
 
 /* ---- geometry: essentia NSGConstantQ as configured at cqt.h:54-61 ---- */
-hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n_samples); /* NULL when N is not 7-smooth */
+hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n_samples); /* NULL when the clip is too short or too long */
+/* force_bluestein: take the chirp-z forward transform (the path of lengths with a prime factor
+ * above 7) even when N is 7-smooth */
+hpfw_oracle_plan *hpfw_oracle_plan_create2(int64_t n_samples, int force_bluestein);
+/* S16: the double-precision DFT the chirp-z tables are built with, in place */
+void hpfw_oracle_dft_double(double *re, double *im, int64_t n);
 void hpfw_oracle_plan_destroy(hpfw_oracle_plan *p);
 void hpfw_oracle_plan_get_info(const hpfw_oracle_plan *p, hpfw_oracle_plan_info *out);
 /* per band j = 0..120: slice start in the forward DFT, window length Lg_j, Bluestein size P_j */

@@ -47,6 +47,9 @@ def lib():
         vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         L.hpfw_oracle_plan_create.restype = vp
         L.hpfw_oracle_plan_create.argtypes = [i64]
+        L.hpfw_oracle_plan_create2.restype = vp
+        L.hpfw_oracle_plan_create2.argtypes = [i64, i32]
+        L.hpfw_oracle_dft_double.argtypes = [vp, vp, i64]
         L.hpfw_oracle_plan_destroy.argtypes = [vp]
         L.hpfw_oracle_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
         L.hpfw_oracle_plan_bands.argtypes = [vp, vp, vp, vp]
@@ -94,10 +97,10 @@ def _c(a, dtype):
 class Plan:
     """Geometry + tables for clips of n_samples samples (essentia NSGConstantQ, cqt.h:54-61)."""
 
-    def __init__(self, n_samples):
-        self._h = lib().hpfw_oracle_plan_create(int(n_samples))
+    def __init__(self, n_samples, force_bluestein=False):
+        self._h = lib().hpfw_oracle_plan_create2(int(n_samples), int(bool(force_bluestein)))
         if not self._h:
-            raise ValueError(f"unsupported clip length {n_samples} (not 7-smooth, or too short)")
+            raise ValueError(f"unsupported clip length {n_samples} (too short or too long)")
         info = PlanInfo()
         lib().hpfw_oracle_plan_get_info(self._h, ctypes.byref(info))
         for name, _ in PlanInfo._fields_:
@@ -258,6 +261,14 @@ def vote_windows(keys, db_off):
 
 def search_votes(db_hp, db_off, q_hp, win=64, nn=5):
     return vote_windows(knn_windows(db_hp, db_off, q_hp, win, nn), db_off)
+
+
+def dft_double(x):
+    """S16: the table-building DFT in double"""
+    x = np.asarray(x, np.complex128)
+    re, im = np.ascontiguousarray(x.real), np.ascontiguousarray(x.imag)
+    lib().hpfw_oracle_dft_double(_p(re), _p(im), x.size)
+    return re + 1j * im
 
 
 def log10(x):

@@ -92,21 +92,12 @@ def test_stereo_and_unsupported_wav(wav_set, filters, tmp_path):
         f.write(b"data" + struct.pack("<I", 0xFFFFFFFF) + data)
     assert len(fmt) == 40
     assert np.array_equal(pc.calc_hashprint(ext), pc.calc_hashprint(mono))
-    bad = str(tmp_path / "odd.wav")
-    synth.write_wav(bad, clips[0][:44100 * 8 - 1])       # 352799 samples: prime factor 13 -> not a supported length
-    os.environ["HPFW_STRICT_LENGTH"] = "1"
-    try:
-        with pytest.raises(hpfw_amd.HpfwError) as e:
-            pc.calc_hashprint(bad)
-        assert "prime factor" in str(e.value)
-    finally:
-        del os.environ["HPFW_STRICT_LENGTH"]
-    # by default a file is padded with zeros to the next supported length (here one sample)
-    assert hpfw_amd.supported_length(44100 * 8 - 1) == 44100 * 8
-    padded = np.concatenate([clips[0][:44100 * 8 - 1], np.zeros(1, np.int16)])
+    odd = str(tmp_path / "odd.wav")
+    synth.write_wav(odd, clips[0][:44100 * 8 - 1])       # 352799 samples = 13 * 27138...: exactly that length goes in
+    assert hpfw_amd.supported_length(44100 * 8 - 1) == 44100 * 8 - 1
     g = hpfw_amd.Gpu(0)
     g.set_filters(filters)
-    assert np.array_equal(pc.calc_hashprint(bad), g.extract(padded)[0])
+    assert np.array_equal(pc.calc_hashprint(odd), g.extract(clips[0][:44100 * 8 - 1])[0])
     g.close()
     with pytest.raises(hpfw_amd.HpfwError):
         pc.calc_hashprint(str(tmp_path / "nope.wav"))

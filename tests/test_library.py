@@ -46,27 +46,31 @@ def test_plan_tables_identical_to_oracle(oracle, n):
     assert np.array_equal(hpfw_amd.plan_checksum(n), want)
 
 
+@pytest.mark.parametrize("n", [1323001, 352799, 99991, -220500])
+def test_chirpz_plan_tables_identical_to_oracle(oracle, n):
+    """lengths with a prime factor above 7 (and, negative, a 7-smooth length forced down the same path): chirp,
+    T_L, the double-precision DFT of the conjugate chirp and w[k] / L are built independently by plan.cpp and
+    the oracle; FNV-1a checksums agree"""
+    want = np.zeros(8, np.uint64)
+    plan = oracle.Plan(abs(n), force_bluestein=n < 0)
+    oracle.lib().hpfw_oracle_plan_checksum.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    oracle.lib().hpfw_oracle_plan_checksum(plan._h, want.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(hpfw_amd.plan_checksum(n), want)
+
+
 def test_unsupported_lengths_fail_loudly():
-    for n in (1323001, 4410, 1, 44100 * 3600):     # prime factor 11 ..., too short, chirp-z length above 2^19
+    for n in (4410, 1, 44100 * 3600):              # too short, too short, chirp-z length above 2^19
         with pytest.raises(hpfw_amd.HpfwError):
             hpfw_amd.plan_checksum(n)
 
 
 def test_supported_length():
-    """lengths are 7-smooth: the next one above a given length, as the file entry points pad to"""
-    assert hpfw_amd.supported_length(1323000) == 1323000
-    assert hpfw_amd.supported_length(1323001) == 1327104        # 2^14 * 3^4
-    for n in (220501, 352799, 5000000, 12345678):
-        m = hpfw_amd.supported_length(n)
-        assert m >= n and (m - n) / n < 0.016
-        k = m
-        for f in (2, 3, 5, 7):
-            while k % f == 0:
-                k //= f
-        assert k == 1
-        hpfw_amd.plan_checksum(m) if m < 2000000 else None     # the plan exists
+    """every length between the shortest clip that yields a hashprint and the longest the tables allow is
+    supported as it is: nothing is padded (the reference transforms the exact length, cqt.h:54-55)"""
+    for n in (1323000, 1323001, 220501, 352799, 99991):
+        assert hpfw_amd.supported_length(n) == n
     assert hpfw_amd.supported_length(44100 * 3600) == -1
-    assert hpfw_amd.supported_length(10) == 54432                 # the shortest clip that yields a hashprint (1.23 s)
+    assert hpfw_amd.supported_length(10) == 54254                 # the shortest clip that yields a hashprint (1.23 s)
 
 
 def test_merge_topk_host():

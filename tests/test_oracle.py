@@ -25,8 +25,8 @@ def test_geometry_of_baseline_configs(oracle):
     assert q.lg.min() == 96                                  # minimumWindow clamp, cqt.h:58
     posit, lg = nsgt_f64.bands(1323000)
     assert np.array_equal(lg, p.lg) and np.array_equal(posit - lg // 2, p.start)
-    with pytest.raises(ValueError):
-        oracle.Plan(1323001)                                 # 11 * 120273: not 7-smooth
+    r = oracle.Plan(1323001)                                 # 11 * 120273: the chirp-z forward transform (S15)
+    assert (r.n2, r.n1) == (6300, 230) and (r.m, r.c) == (7255, 2419)
     with pytest.raises(ValueError):
         oracle.Plan(4410)                                    # bands leave the half spectrum
 
@@ -226,3 +226,42 @@ def test_mel_front_end_against_float64(oracle):
     assert s.shape == (33, int(keep.sum())) and s.max() == 0.0 and s.min() >= -80.0
     assert np.abs(s - nsgt_f64.power_to_db(p64[:, keep64])).max() < 1e-3
     assert mel.spectrogram(np.zeros(10000, np.int16)).shape == (33, 0)      # all frames silent
+
+
+def test_table_dft_in_double_against_numpy(oracle):
+    """S16: the double-precision DFT the chirp-z tables are built with (any length with prime factors <= 31)"""
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 23, 230, 6300, 31 * 29 * 3):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        ref = np.fft.fft(x)
+        assert np.abs(oracle.dft_double(x) - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n", [132301, 88211, 99991, 132300])
+def test_forward_bins_of_any_length_against_numpy(oracle, n):
+    """S15: clip lengths with a prime factor above 7 (11 | 132301, 88211 = 17 * 5189, 99991 prime) and a 7-smooth
+    one forced down the same path: the consumed forward bins against numpy's float64 FFT of the exact length"""
+    from hpfw_amd import synth
+    pcm = synth.gen_clip(31, 3.5)[:n]
+    plan = oracle.Plan(n, force_bluestein=True)
+    assert plan.n2 == 6300 and plan.n1 * plan.n2 >= n + (plan.kmax - plan.kmin) - 1
+    x = plan.spectrum(pcm)
+    ref = np.fft.fft(pcm.astype(np.float64) / 32768.0)[plan.kmin:plan.kmax]
+    err = np.abs((x[:, 0] + 1j * x[:, 1]) - ref)
+    assert err.max() < 2e-6 * np.abs(ref).max()
+    if n == 132300:                                          # the mixed-radix transform of the same clip agrees
+        y = oracle.Plan(n).spectrum(pcm)
+        assert np.abs(x - y).max() < 2e-6 * np.abs(ref).max()
+
+
+def test_any_length_extraction_against_float64(oracle):
+    """a clip of 132301 samples end to end: |CQ| within 1e-4 of every band's maximum against the float64
+    definition evaluated at the exact length (BASELINE.json's tolerance)"""
+    from hpfw_amd import synth
+    n = 132301
+    pcm = synth.gen_clip(32, 3.5)[:n]
+    plan = oracle.Plan(n)
+    mag = plan.cqmag(plan.spectrum(pcm))
+    m64 = nsgt_f64.cq_magnitudes(pcm)
+    assert mag.shape == m64.shape
+    assert (np.abs(mag - m64).max(axis=1) / m64.max(axis=1)).max() < 1e-4
