@@ -464,3 +464,75 @@ def test_extreme_signals(torch_cuda, oracle, filters):
         assert np.array_equal(hp[i], plan.extract(filters, sig[i])), i
         assert bits_equal(db[i], oracle.db(plan.cqmag(plan.spectrum(sig[i])))), i
     g.close()
+
+
+@pytest.mark.parametrize("n", [1323001, 352799, 99991, 220499, 54254])
+def test_arbitrary_clip_lengths(gpu, torch_cuda, oracle, filters, n):
+    """clip lengths with a prime factor above 7 (1323001 = 11 * 120273, 13 | 352799, 99991 prime, ...): the
+    reference transforms the file's exact sample count (cqt.h:54-55) and so does the chirp-z forward transform
+    (k_bluestein.hip): forward bins and dB spectrogram bit-exact against the oracle, |CQ| within
+    1e-4 of every band's maximum against the float64 definition at that exact length, hashprints identical"""
+    torch = torch_cuda
+    from oracle import nsgt_f64
+    sec = n / 44100.0 + 0.1
+    clips = np.stack([synth.gen_clip(970 + i, sec)[:n] for i in range(2)])
+    plan = oracle.Plan(n)
+    g = gpu.geometry(n)
+    assert (g.n1, g.n2, g.kmin, g.kmax, g.m, g.c, g.n_hp) == (plan.n1, plan.n2, plan.kmin, plan.kmax, plan.m, plan.c, plan.n_hp)
+    assert g.n2 == 6300 and g.n1 * g.n2 >= n + (g.kmax - g.kmin) - 1
+    nk = plan.kmax - plan.kmin
+    d_pcm = _dev(torch, clips)
+    d_x = torch.empty((2, nk, 2), dtype=torch.float32, device="cuda")
+    gpu.stage_spectrum_dev(d_pcm.data_ptr(), n, 2, d_x.data_ptr())
+    torch.cuda.synchronize()
+    x_ref = np.stack([plan.spectrum(c) for c in clips])
+    assert np.array_equal(d_x.cpu().numpy(), x_ref), _report("spectrum", d_x.cpu().numpy(), x_ref)
+    ref64 = np.fft.fft(clips[0].astype(np.float64) / 32768.0)[plan.kmin:plan.kmax]
+    assert np.abs((x_ref[0][:, 0] + 1j * x_ref[0][:, 1]) - ref64).max() < 2e-6 * np.abs(ref64).max()
+    d_mag = torch.empty((2, 121, plan.c), dtype=torch.float32, device="cuda")
+    gpu.stage_cqmag_dev(d_x.data_ptr(), n, 2, d_mag.data_ptr())
+    d_db = torch.empty_like(d_mag)
+    gpu.stage_spectrogram_dev(d_pcm.data_ptr(), n, 2, d_db.data_ptr())
+    torch.cuda.synchronize()
+    mag = d_mag.cpu().numpy()
+    mag_ref = np.stack([plan.cqmag(x) for x in x_ref])
+    assert np.array_equal(mag, mag_ref)
+    m64 = nsgt_f64.cq_magnitudes(clips[0])
+    assert (np.abs(mag[0] - m64).max(axis=1) / m64.max(axis=1)).max() < 1e-4
+    assert bits_equal(d_db.cpu().numpy(), np.stack([oracle.db(m) for m in mag_ref]))
+    if plan.n_hp > 0:
+        assert np.array_equal(gpu.extract(clips), np.stack([plan.extract(filters, c) for c in clips]))
+
+
+def test_chirpz_path_agrees_with_mixed_radix_path(oracle, filters, monkeypatch):
+    """a 7-smooth length through both forward transforms (HPFW_FORCE_BLUESTEIN=1): each bit-exact against its
+    own oracle twin; the two spectrograms agree to float rounding and the hashprints differ in a handful of
+    bits at most (two evaluations of the same transform)"""
+    clips = np.stack([synth.gen_clip(980 + i, 5.0) for i in range(3)])
+    n = clips.shape[1]
+    a = hpfw_amd.Gpu(0)
+    a.set_filters(filters)
+    hp_a = a.extract(clips)
+    a.close()
+    monkeypatch.setenv("HPFW_FORCE_BLUESTEIN", "1")
+    b = hpfw_amd.Gpu(0)                                     # the switch is read when the plan of a length is built
+    b.set_filters(filters)
+    assert b.geometry(n).n2 == 6300 and b.geometry(n).n1 * 6300 > n
+    hp_b = b.extract(clips)
+    b.close()
+    plan_b = oracle.Plan(n, force_bluestein=True)
+    assert np.array_equal(hp_b, np.stack([plan_b.extract(filters, c) for c in clips]))
+    assert np.array_equal(hp_a, np.stack([oracle.Plan(n).extract(filters, c) for c in clips]))
+    flipped = sum(bin(int(v)).count("1") for v in (hp_a ^ hp_b).ravel())
+    assert flipped <= 1e-3 * hp_a.size * 64, flipped
+
+
+def test_many_clips_of_a_non_smooth_length(gpu, oracle, filters):
+    """more clips than one pass of the chirp-z path and an odd count: per-clip results do not depend on batching"""
+    n = 3 * 44100 + 7
+    clips = np.stack([synth.gen_clip(990 + i, 3.1)[:n] for i in range(9)])
+    want = oracle.Plan(n).extract_batch(filters, clips, n_threads=8)
+    gpu.set_batch(4)
+    got4 = gpu.extract(clips)
+    gpu.set_batch(0)
+    assert np.array_equal(got4, want) and np.array_equal(gpu.extract(clips), want)
