@@ -33,11 +33,20 @@ EXPORTS = (
     "hpfw_gpu_index_get", "hpfw_gpu_extract_db_host", "hpfw_gpu_stage_spectrogram",
     "hpfw_gpu_search_votes", "hpfw_gpu_knn_windows", "hpfw_gpu_supported_length",
     "hpfw_gpu_mel_frames", "hpfw_gpu_mel_spectrogram_pcm16", "hpfw_gpu_mel_spectrogram_pcm16_host",
+    "hpfw_gpu_cfg_set_filters", "hpfw_gpu_cfg_hashprints", "hpfw_gpu_mel_hashprints_pcm16_host",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_calc_hashprints", "par_collector_save", "par_collector_load",
     "prepare_result_free", "calc_hashprint_result_free",
 )
+
+
+class HandleConfig(ctypes.Structure):
+    """hpfw_handle_config: HashprintHandle<N, SH, FramesContext, T> (hashprint_handle.h:50-64)"""
+    _fields_ = [("rows", ctypes.c_int32), ("context", ctypes.c_int32), ("lag", ctypes.c_int32), ("bits", ctypes.c_int32)]
+
+
+COMBINER_CONFIG = (33, 32, 50, 16)      # combiner.h:12: HashPrint<uint16_t, MelSpectrogram<>, 32, 50>
 
 
 class Geometry(ctypes.Structure):
@@ -108,6 +117,9 @@ def lib():
     L.hpfw_gpu_mel_frames.restype = i64
     L.hpfw_gpu_mel_spectrogram_pcm16.argtypes = [vp, vp, i64, i64, vp, vp, vp]
     L.hpfw_gpu_mel_spectrogram_pcm16_host.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_cfg_set_filters.argtypes = [vp, ctypes.POINTER(HandleConfig), vp]
+    L.hpfw_gpu_cfg_hashprints.argtypes = [vp, ctypes.POINTER(HandleConfig), vp, vp, i64, i64, vp, i64, vp, vp]
+    L.hpfw_gpu_mel_hashprints_pcm16_host.argtypes = [vp, vp, i64, i64, vp, i64, vp]
     L.hpfw_gpu_supported_length.argtypes = [i64]
     L.hpfw_gpu_supported_length.restype = i64
     L.hpfw_gpu_search_votes.argtypes = [vp, vp, vp, i64, vp]
@@ -224,6 +236,30 @@ class Gpu:
         cols = np.zeros(pcm.shape[0], np.int32)
         check(lib().hpfw_gpu_mel_spectrogram_pcm16_host(self._h, _hp(pcm), pcm.shape[1], pcm.shape[0], _hp(out), _hp(cols)))
         return [np.ascontiguousarray(out[i, :, :cols[i]]) for i in range(pcm.shape[0])]
+
+    # ---- HashprintHandle with other template arguments ---------------------------------------
+    def cfg_set_filters(self, cfg, filters_colmajor):
+        c = HandleConfig(*cfg)
+        f = np.ascontiguousarray(filters_colmajor, np.float32).ravel()
+        if f.size != c.bits * c.rows * c.context:
+            raise ValueError("filters must hold bits x rows * context floats (column-major)")
+        check(lib().hpfw_gpu_cfg_set_filters(self._h, ctypes.byref(c), _hp(f)))
+
+    def cfg_hashprints_dev(self, cfg, d_s, d_cols, n_clips, stride, d_hp, hp_stride, d_proj=0, stream=0):
+        c = HandleConfig(*cfg)
+        check(lib().hpfw_gpu_cfg_hashprints(self._h, ctypes.byref(c), d_s, d_cols, n_clips, stride, d_hp, hp_stride,
+                                            d_proj, stream))
+
+    def mel_hashprints(self, pcm):
+        """the combiner's Algo (combiner.h:12) on host PCM [n_clips][n]: list of uint16 hashprint arrays"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        stride = max(int(lib().hpfw_gpu_mel_frames(pcm.shape[1])) - 81, 1)
+        hp = np.zeros((pcm.shape[0], stride), np.uint16)
+        n = np.zeros(pcm.shape[0], np.int32)
+        check(lib().hpfw_gpu_mel_hashprints_pcm16_host(self._h, _hp(pcm), pcm.shape[1], pcm.shape[0], _hp(hp), stride, _hp(n)))
+        return [hp[i, :n[i]].copy() for i in range(pcm.shape[0])]
 
     # ---- filter learning ------------------------------------------------------------------
     def cov_reset(self):

@@ -146,6 +146,10 @@ struct hpfw_gpu {
     size_t clipmax_cap = 0;
     int *d_cov_tiles = nullptr;
     int64_t cov_files = 0;
+    // HashprintHandle configurations other than the default (hpfw_gpu_cfg_*): filter operand images by config
+    std::map<std::vector<int>, float *> cfg_fpack;
+    float *d_cfg_proj = nullptr;
+    size_t cfg_proj_cap = 0;
     // ordering of consecutive entry points that were handed different streams (the workspaces are shared)
     hipEvent_t order_ev = nullptr;
     hipStream_t order_stream = nullptr;
@@ -550,6 +554,8 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->stage_copy) (void)hipStreamDestroy(h->stage_copy);
     if (h->stage_comp) (void)hipStreamDestroy(h->stage_comp);
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
+    for (auto &kv : h->cfg_fpack) (void)hipFree(kv.second);
+    if (h->d_cfg_proj) (void)hipFree(h->d_cfg_proj);
     if (h->d_db) (void)hipFree(h->d_db);
     if (h->d_db_off) (void)hipFree(h->d_db_off);
     if (h->d_best) (void)hipFree(h->d_best);
@@ -897,6 +903,108 @@ int hpfw_gpu_mel_spectrogram_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t
     if (d_pcm) (void)hipFree(d_pcm);
     if (d_out) (void)hipFree(d_out);
     if (d_cols) (void)hipFree(d_cols);
+    return rc;
+}
+
+// ---- HashprintHandle with other template arguments (hashprint_handle.h:50-64) -------------------------
+static int cfg_check(const hpfw_handle_config *c)
+{
+    if (!c) return fail(HPFW_E_INVALID, "null config");
+    if (c->rows < 1 || c->rows > 512 || c->context < 1 || c->context > 256 || c->lag < 1 ||
+        (c->bits != 16 && c->bits != 32 && c->bits != 64))
+        return fail(HPFW_E_INVALID, "config: rows 1..512, context 1..256, lag >= 1, bits 16, 32 or 64");
+    hpfw::CfgArgs a{c->rows, c->context, c->lag, c->bits, nullptr};
+    if (hpfw::project_cfg_lds_bytes(a) > 160 * 1024) return fail(HPFW_E_UNSUPPORTED, "config: rows x context exceeds the LDS slab");
+    return 0;
+}
+
+int hpfw_gpu_cfg_set_filters(hpfw_gpu *h, const hpfw_handle_config *c, const float *f)
+{
+    if (!h || !f) return fail(HPFW_E_INVALID, "null argument");
+    int rc = cfg_check(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<float> packed(hpfw::cfg_fpack_floats(c->rows, c->context, c->bits));
+    hpfw::pack_cfg_filters(c->rows, c->context, c->bits, f, packed.data());
+    float *&d = h->cfg_fpack[{c->rows, c->context, c->bits}];
+    if (!d) HIP_TRY(hipMalloc((void **)&d, packed.size() * 4));
+    Ordered ordered(h, nullptr);
+    HIP_TRY(hipMemcpy(d, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int hpfw_gpu_cfg_hashprints(hpfw_gpu *h, const hpfw_handle_config *c, const float *d_s, const int32_t *d_cols, int64_t n_clips,
+                            int64_t stride, void *d_hp, int64_t hp_stride, float *d_proj, void *stream)
+{
+    if (!h || !d_s || !d_hp || n_clips < 0 || stride < 1) return fail(HPFW_E_INVALID, "bad argument");
+    int rc = cfg_check(c);
+    if (rc) return rc;
+    auto it = h->cfg_fpack.find({c->rows, c->context, c->bits});
+    if (it == h->cfg_fpack.end()) return fail(HPFW_E_NOFILTERS, "no filters for this configuration: call hpfw_gpu_cfg_set_filters first");
+    const int64_t nf = stride - c->context + 1, nhp = nf - c->lag;
+    if (nhp > hp_stride) return fail(HPFW_E_INVALID, "hp_stride smaller than stride - context + 1 - lag");
+    if (n_clips == 0 || nhp <= 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
+    const hpfw::CfgArgs a{c->rows, c->context, c->lag, c->bits, it->second};
+    // clips per pass: the projection scratch stays below 1 GiB
+    const int64_t per = (int64_t)c->bits * nf * 4;
+    const int64_t chunk = d_proj ? n_clips : std::max<int64_t>(1, std::min<int64_t>(n_clips, ((int64_t)1 << 30) / per));
+    if (!d_proj && (rc = ensure((void **)&h->d_cfg_proj, &h->cfg_proj_cap, (size_t)chunk * per))) return rc;
+    const size_t word = (size_t)c->bits / 8;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += chunk) {
+        const int nb = (int)std::min<int64_t>(chunk, n_clips - c0);
+        float *pj = d_proj ? d_proj + c0 * c->bits * nf : h->d_cfg_proj;
+        const int *cols = d_cols ? d_cols + c0 : nullptr;
+        {
+            Timed t(h, K_PROJECT, s);
+            hpfw::launch_project_cfg(a, d_s + c0 * c->rows * stride, cols, nb, stride, pj, nf, s);
+        }
+        if ((rc = check_launch("project_cfg"))) return rc;
+        {
+            Timed t(h, K_PACK, s);
+            hpfw::launch_pack_cfg(a, pj, cols, nb, stride, nf, (char *)d_hp + (size_t)c0 * hp_stride * word, hp_stride, s);
+        }
+        if ((rc = check_launch("pack_cfg"))) return rc;
+    }
+    return 0;
+}
+
+int hpfw_gpu_mel_hashprints_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples, int64_t n_clips, uint16_t *hp,
+                                       int64_t hp_stride, int32_t *n_hp)
+{
+    if (!h || !pcm || !hp || !n_hp || n_clips < 0 || n_samples < 1) return fail(HPFW_E_INVALID, "bad argument");
+    const hpfw_handle_config cfg = HPFW_CONFIG_COMBINER;
+    const int64_t frames = hpfw::mel_frames(n_samples), nhp_max = frames - cfg.context + 1 - cfg.lag;
+    if (nhp_max > hp_stride) return fail(HPFW_E_INVALID, "hp_stride smaller than hpfw_gpu_mel_frames(n_samples) - 81");
+    HIP_TRY(hipSetDevice(h->device));
+    if (n_clips == 0) return 0;
+    if (h->cfg_fpack.find({cfg.rows, cfg.context, cfg.bits}) == h->cfg_fpack.end())
+        return fail(HPFW_E_NOFILTERS, "no filters for the combiner configuration: call hpfw_gpu_cfg_set_filters first");
+    int16_t *d_pcm = nullptr;
+    float *d_s = nullptr;
+    int32_t *d_cols = nullptr;
+    uint16_t *d_hp = nullptr;
+    const size_t per = (size_t)hpfw::kMelBands * frames, hp_words = (size_t)n_clips * std::max<int64_t>(hp_stride, 1);
+    int rc = 0;
+    if (hipMalloc((void **)&d_pcm, (size_t)n_clips * n_samples * 2) != hipSuccess || hipMalloc((void **)&d_s, (size_t)n_clips * per * 4) != hipSuccess ||
+        hipMalloc((void **)&d_cols, (size_t)n_clips * 4) != hipSuccess || hipMalloc((void **)&d_hp, hp_words * 2) != hipSuccess)
+        rc = fail(HPFW_E_NOMEM, "hipMalloc failed");
+    if (!rc && (hipMemcpy(d_pcm, pcm, (size_t)n_clips * n_samples * 2, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemset(d_s, 0, (size_t)n_clips * per * 4) != hipSuccess || hipMemset(d_hp, 0, hp_words * 2) != hipSuccess))
+        rc = fail(HPFW_E_HIP, "H2D copy failed");
+    if (!rc) rc = hpfw_gpu_mel_spectrogram_pcm16(h, d_pcm, n_samples, n_clips, d_s, d_cols, nullptr);
+    if (!rc) rc = hpfw_gpu_cfg_hashprints(h, &cfg, d_s, d_cols, n_clips, frames, d_hp, hp_stride, nullptr, nullptr);
+    std::vector<int32_t> cols((size_t)n_clips);
+    if (!rc && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(hp, d_hp, hp_words * 2, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(cols.data(), d_cols, (size_t)n_clips * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(HPFW_E_HIP, "kernel execution or D2H copy failed");
+    for (int64_t i = 0; !rc && i < n_clips; ++i) n_hp[i] = std::max<int32_t>(cols[(size_t)i] - cfg.context + 1 - cfg.lag, 0);
+    if (d_pcm) (void)hipFree(d_pcm);
+    if (d_s) (void)hipFree(d_s);
+    if (d_cols) (void)hipFree(d_cols);
+    if (d_hp) (void)hipFree(d_hp);
     return rc;
 }
 

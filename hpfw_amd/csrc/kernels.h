@@ -117,6 +117,21 @@ void launch_project(const float *d_fpack, const float *d_db, const float *d_tmax
 // delta over 80 frames, sign, bit pack: proj [n_clips][64][nf] -> hp [n_clips][nf-80]
 void launch_pack(const float *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s);
 
+// ---- HashprintHandle with other template arguments (k_hashprint_cfg.hip) ----------------------------
+struct CfgArgs {
+    int rows, context, lag, filters; // spectrogram rows, FramesContext, T, 8 sizeof(N)
+    const float *fpack;              // filters as the MFMA operand image (pack_cfg_filters)
+};
+size_t cfg_fpack_floats(int rows, int context, int filters);
+void pack_cfg_filters(int rows, int context, int filters, const float *f_colmajor, float *fpack);
+size_t project_cfg_lds_bytes(const CfgArgs &a);
+// d_s [n_clips][rows][stride], d_cols [n_clips] valid columns (NULL: stride) -> d_proj [n_clips][filters][proj_stride]
+void launch_project_cfg(const CfgArgs &a, const float *d_s, const int *d_cols, int n_clips, int64_t stride, float *d_proj,
+                        int64_t proj_stride, hipStream_t s);
+// -> d_hp [n_clips][hp_stride] of uint16 / uint32 / uint64 (by a.filters)
+void launch_pack_cfg(const CfgArgs &a, const float *d_proj, const int *d_cols, int n_clips, int64_t stride, int64_t proj_stride,
+                     void *d_hp, int64_t hp_stride, hipStream_t s);
+
 // ---- filter learning (index() only) -------------------------------------------------------
 // accum [2420][2420] (tiles on or above the diagonal) += sum over clips of centred^T centred / (nf - 1),
 // by lag correlations (k_cov.hip); d_ws: cov_workspace_bytes(n_clips, c) of scratch

@@ -135,6 +135,32 @@ int hpfw_gpu_mel_spectrogram_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_
 int hpfw_gpu_mel_spectrogram_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples,
                                         int64_t n_clips, float *out, int32_t *cols);
 
+/* ---- HashprintHandle<N, SpectrogramHandler, FramesContext, T> with other template arguments -------------
+ * (hashprint_handle.h:50-64).  Everything above is the live-id default <uint64_t, CQT<>, 20, 80>
+ * (live_song_id.h:16); this is the same calc_frames / filters * frames / calc_fingerprint /
+ * fingerprint_to_hashprint (hashprint_handle.h:79-142) for any spectrogram height, context, lag and word
+ * size -- the combiner's HashPrint<uint16_t, MelSpectrogram<>, 32, 50> (combiner.h:12) first of all. */
+typedef struct {
+    int32_t rows;    /* Spectrogram::RowsAtCompileTime: 33 for MelSpectrogram<> (mel.h:17-21), 121 for CQT<> */
+    int32_t context; /* FramesContext                                                                          */
+    int32_t lag;     /* T                                                                                      */
+    int32_t bits;    /* 8 * sizeof(N) = NumOfFilters (hashprint_handle.h:64): 16, 32 or 64                     */
+} hpfw_handle_config;
+#define HPFW_CONFIG_COMBINER {33, 32, 50, 16} /* combiner.h:12 */
+/* filters: Matrix<float, NumOfFilters, Dynamic> column-major, element (r, k) at r + bits * k, k = row * context + t */
+int hpfw_gpu_cfg_set_filters(hpfw_gpu *h, const hpfw_handle_config *cfg, const float *filters_colmajor);
+/* d_s [n_clips][rows][stride] (row-major: element (row, col) of clip i at (i * rows + row) * stride + col);
+ * d_cols [n_clips]: valid columns of each clip, or NULL = stride (the Mel front end drops silent frames, so its
+ * clips differ).  d_hp: uintN [n_clips][hp_stride]; clip i receives max(cols_i - context + 1 - lag, 0) words.
+ * d_proj (optional, NULL to skip): the projection filters * frames [n_clips][bits][stride - context + 1]. */
+int hpfw_gpu_cfg_hashprints(hpfw_gpu *h, const hpfw_handle_config *cfg, const float *d_s, const int32_t *d_cols,
+                            int64_t n_clips, int64_t stride, void *d_hp, int64_t hp_stride, float *d_proj, void *stream);
+/* the combiner's Algo end to end on host buffers: MelSpectrogram<44100, 33, 4410, 441>::spectrogram (mel.h:34-104)
+ * + HashprintHandle<uint16_t, Mel, 32, 50>: hp [n_clips][hp_stride] (hp_stride >= hpfw_gpu_mel_frames(n) - 81),
+ * n_hp [n_clips] the number of hashprints of each clip (0 when too few frames are left after the silent ones) */
+int hpfw_gpu_mel_hashprints_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples, int64_t n_clips,
+                                       uint16_t *hp, int64_t hp_stride, int32_t *n_hp);
+
 /* ---- filter learning: ParallelCollector::preprocess + calc_filters ------------------------
  * (parallel_collector.h:82-112, hashprint_handle.h:96-112).  The handle owns accum_cov
  * (2420 x 2420, parallel_collector.h:76): per clip, the covariance of its context frames (centred

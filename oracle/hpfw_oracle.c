@@ -1045,6 +1045,37 @@ void hpfw_oracle_pack(const float *proj, int64_t nf, uint64_t *hp)
     }
 }
 
+/* HashprintHandle<N, SH, FramesContext, T> for any template arguments (hashprint_handle.h:50-64): calc_frames
+ * (:79-93: k = row * context + t), filters * frames as an fma chain over k ascending, calc_fingerprint
+ * (:115-125) and bool_col_to_num (:137-142: bit (bits - 1 - r) <-> filter row r).  f column-major
+ * [bits][rows * context]: (r, k) at r + bits * k; s row-major [rows][stride] with `cols` valid columns;
+ * proj [bits][stride - context + 1]; hp: one 64-bit word per hashprint (the low `bits` bits used). */
+void hpfw_oracle_project_cfg(const float *f, const float *s, int rows, int context, int bits, int64_t cols, int64_t stride,
+                             float *proj)
+{
+    const int64_t nf = cols - context + 1, pst = stride - context + 1;
+    for (int64_t n = 0; n < nf; ++n)
+        for (int r = 0; r < bits; ++r) {
+            float acc = 0.0f;
+            for (int row = 0; row < rows; ++row)
+                for (int t = 0; t < context; ++t)
+                    acc = fmaf(f[(size_t)r + (size_t)bits * (size_t)(row * context + t)], s[(int64_t)row * stride + n + t], acc);
+            proj[(int64_t)r * pst + n] = acc;
+        }
+}
+
+void hpfw_oracle_pack_cfg(const float *proj, int bits, int lag, int64_t n_frames, int64_t proj_stride, uint64_t *hp)
+{
+    for (int64_t i = 0; i + lag < n_frames; ++i) {
+        uint64_t v = 0;
+        for (int r = 0; r < bits; ++r) {
+            float d = proj[(int64_t)r * proj_stride + i] - proj[(int64_t)r * proj_stride + i + lag];
+            if (d >= 0.0f) v |= 1ULL << (bits - 1 - r);
+        }
+        hp[i] = v;
+    }
+}
+
 int64_t hpfw_oracle_extract(const hpfw_oracle_plan *p, const float *f, const int16_t *pcm, uint64_t *hp)
 {
     const int64_t c = p->info.c, nk = p->info.kmax - p->info.kmin;

@@ -75,6 +75,11 @@ void hpfw_oracle_db(const float *mag, int64_t n, float *s_db);
 void hpfw_oracle_project(const float *f_colmajor, const float *s_db, int64_t c, float *proj);
 /* ---- a7 + a8: calc_fingerprint + fingerprint_to_hashprint   hashprint_handle.h:115-142 ---- */
 void hpfw_oracle_pack(const float *proj, int64_t n_frames, uint64_t *hp /* [n_frames-80] */);
+/* ---- the same for any HashprintHandle<N, SH, FramesContext, T> (hashprint_handle.h:50-64), e.g. the
+ *      combiner's <uint16_t, MelSpectrogram<>, 32, 50> (combiner.h:12): see hpfw_oracle.c ---- */
+void hpfw_oracle_project_cfg(const float *f_colmajor, const float *s, int rows, int context, int bits, int64_t cols,
+                             int64_t stride, float *proj);
+void hpfw_oracle_pack_cfg(const float *proj, int bits, int lag, int64_t n_frames, int64_t proj_stride, uint64_t *hp);
 /* ---- a1..a8 for one clip (calc_hashprint, parallel_collector.h:54-59); returns n_hp ---- */
 int64_t hpfw_oracle_extract(const hpfw_oracle_plan *p, const float *f_colmajor, const int16_t *pcm,
                             uint64_t *hp);

@@ -58,6 +58,8 @@ def lib():
         L.hpfw_oracle_db.argtypes = [vp, i64, vp]
         L.hpfw_oracle_project.argtypes = [vp, vp, i64, vp]
         L.hpfw_oracle_pack.argtypes = [vp, i64, vp]
+        L.hpfw_oracle_project_cfg.argtypes = [vp, vp, i32, i32, i32, i64, i64, vp]
+        L.hpfw_oracle_pack_cfg.argtypes = [vp, i32, i32, i64, i64, vp]
         L.hpfw_oracle_extract.restype = i64
         L.hpfw_oracle_extract.argtypes = [vp, vp, vp, vp]
         L.hpfw_oracle_extract_batch.restype = i64
@@ -171,6 +173,22 @@ def pack(proj):
     hp = np.zeros(max(nf - LAG, 0), np.uint64)
     lib().hpfw_oracle_pack(_p(pr), nf, _p(hp))
     return hp
+
+
+def hashprints_cfg(filters, s, context, lag, bits, return_projection=False):
+    """HashprintHandle<uintN, SH, context, lag> on one spectrogram s [rows][cols]; filters flat column-major
+    [bits][rows * context].  Returns uint64 words holding the `bits`-bit hashprints."""
+    f = _c(filters, np.float32)
+    s = _c(s, np.float32)
+    rows, cols = s.shape
+    nf = cols - context + 1
+    if nf <= 0:
+        return (np.zeros(0, np.uint64), np.zeros((bits, 0), np.float32)) if return_projection else np.zeros(0, np.uint64)
+    proj = np.zeros((bits, nf), np.float32)
+    lib().hpfw_oracle_project_cfg(_p(f), _p(s), rows, context, bits, cols, cols, _p(proj))
+    hp = np.zeros(max(nf - lag, 0), np.uint64)
+    lib().hpfw_oracle_pack_cfg(_p(proj), bits, lag, nf, nf, _p(hp))
+    return (hp, proj) if return_projection else hp
 
 
 def match_clip(q, r):

@@ -536,3 +536,52 @@ def test_many_clips_of_a_non_smooth_length(gpu, oracle, filters):
     got4 = gpu.extract(clips)
     gpu.set_batch(0)
     assert np.array_equal(got4, want) and np.array_equal(gpu.extract(clips), want)
+
+
+def test_combiner_configuration_16_bit_hashprints(gpu, torch_cuda, oracle):
+    """f3: HashprintHandle<uint16_t, MelSpectrogram<>, 32, 50> (combiner.h:12; hashprint_handle.h:50-64 with
+    33 rows, frames of 1056 values, 16 filters): projection bit-exact against the fmaf chain, 16-bit hashprints
+    identical, from given spectrograms of ragged widths and end to end from PCM through the Mel front end"""
+    torch = torch_cuda
+    cfg = hpfw_amd.COMBINER_CONFIG
+    rows, ctx, lag, bits = cfg
+    rng = np.random.default_rng(21)
+    filt = np.linalg.qr(rng.standard_normal((rows * ctx, bits)))[0].astype(np.float32)   # [k][r] = column-major [bits][k]
+    gpu.cfg_set_filters(cfg, filt)
+    stride = 700
+    cols = np.array([700, 82, 81, 400, 33, 0], np.int32)          # 82: one hashprint; 81: none; fewer than a frame: none
+    s = rng.uniform(-80, 0, (len(cols), rows, stride)).astype(np.float32)
+    s[3, :, :200] = -80.0                                         # constant stretch: exact zeros in the deltas
+    nf = stride - ctx + 1
+    d_s, d_cols = _dev(torch, s), _dev(torch, cols)
+    d_hp = torch.zeros((len(cols), nf - lag), dtype=torch.int16, device="cuda")
+    d_proj = torch.zeros((len(cols), bits, nf), dtype=torch.float32, device="cuda")
+    gpu.cfg_hashprints_dev(cfg, d_s.data_ptr(), d_cols.data_ptr(), len(cols), stride, d_hp.data_ptr(), nf - lag, d_proj.data_ptr())
+    torch.cuda.synchronize()
+    hp, proj = d_hp.cpu().numpy().view(np.uint16), d_proj.cpu().numpy()
+    for i, c in enumerate(cols):
+        want_hp, want_proj = oracle.hashprints_cfg(filt, s[i][:, :c], ctx, lag, bits, return_projection=True)
+        n = max(c - ctx + 1, 0)
+        assert bits_equal(proj[i][:, :n], want_proj), i
+        assert np.array_equal(hp[i][:max(n - lag, 0)], want_hp.astype(np.uint16)), i
+    assert (hp[3][:100] == 0xFFFF).all()                          # delta == 0 -> bit set (hashprint_handle.h:121)
+    # end to end: PCM -> dB-mel spectrogram (silent frames dropped) -> 16-bit hashprints
+    clips = np.stack([synth.gen_clip(960 + i, 6.0) for i in range(3)])
+    clips[1, 50000:120000] = 0
+    clips[2, :] = 0                                               # silent: no column, no hashprint
+    got = gpu.mel_hashprints(clips)
+    mel = oracle.Mel()
+    for c, g in zip(clips, got):
+        sp = mel.spectrogram(c)
+        want = oracle.hashprints_cfg(filt, sp, ctx, lag, bits).astype(np.uint16) if sp.shape[1] else np.zeros(0, np.uint16)
+        assert np.array_equal(g, want)
+    assert got[0].size == oracle.Mel.frames(clips.shape[1]) - 81 and got[2].size == 0 and 0 < got[1].size < got[0].size
+    # the same kernels with the live-id arguments <uint64_t, CQT<>, 20, 80> agree with the specialised path
+    filt64 = synth.make_filters()
+    gpu.cfg_set_filters((121, 20, 80, 64), filt64)
+    s64 = rng.uniform(-80, 0, (2, 121, 300)).astype(np.float32)
+    d_hp64 = torch.zeros((2, 300 - 99), dtype=torch.int64, device="cuda")
+    gpu.cfg_hashprints_dev((121, 20, 80, 64), _dev(torch, s64).data_ptr(), 0, 2, 300, d_hp64.data_ptr(), 300 - 99)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert np.array_equal(d_hp64.cpu().numpy().view(np.uint64)[i], oracle.pack(oracle.project(filt64, s64[i])))
