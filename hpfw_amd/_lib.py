@@ -35,6 +35,7 @@ EXPORTS = (
     "hpfw_gpu_mel_frames", "hpfw_gpu_mel_spectrogram_pcm16", "hpfw_gpu_mel_spectrogram_pcm16_host",
     "hpfw_gpu_cfg_set_filters", "hpfw_gpu_cfg_hashprints", "hpfw_gpu_mel_hashprints_pcm16_host",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
+    "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_calc_hashprints", "par_collector_save", "par_collector_load",
     "prepare_result_free", "calc_hashprint_result_free",
@@ -129,6 +130,8 @@ def lib():
     L.hpfw_gpu_set_kernel_timing.argtypes = [vp, i32]
     L.hpfw_gpu_get_kernel_timing.argtypes = [vp, vp, vp, vp, ctypes.POINTER(i32)]
     L.hpfw_gpu_plan_checksum.argtypes = [i64, vp]
+    L.hpfw_gpu_plan_checksum_ex.argtypes = [i64, i32, u32, vp]
+    L.hpfw_gpu_set_conventions.argtypes = [vp, u32]
     L.par_collector_new.restype = vp
     L.par_collector_del.argtypes = [vp]
     L.par_collector_del.restype = None
@@ -189,6 +192,10 @@ class Gpu:
         g = Geometry()
         check(lib().hpfw_gpu_geometry(self._h, int(n_samples), ctypes.byref(g)))
         return g
+
+    def set_conventions(self, flags):
+        """HPFW_CONV_* bits: essentia conventions that cannot be checked offline (include/hpfw_gpu.h)"""
+        check(lib().hpfw_gpu_set_conventions(self._h, int(flags)))
 
     def set_batch(self, clips_per_pass):
         check(lib().hpfw_gpu_set_batch(self._h, int(clips_per_pass)))
@@ -397,9 +404,12 @@ def supported_length(n_samples):
     return int(lib().hpfw_gpu_supported_length(int(n_samples)))
 
 
-def plan_checksum(n_samples):
+CONV_HANN_PERIODIC, CONV_LG_HALF_EVEN, CONV_FLOAT_GEOMETRY, CONV_NO_IFFT_SCALE = 1, 2, 4, 8
+
+
+def plan_checksum(n_samples, conventions=0):
     out = np.zeros(8, np.uint64)
-    rc = lib().hpfw_gpu_plan_checksum(int(n_samples), _hp(out))
+    rc = lib().hpfw_gpu_plan_checksum_ex(abs(int(n_samples)), int(n_samples < 0), int(conventions), _hp(out))
     if rc != 0:
         raise HpfwError(f"unsupported clip length {n_samples}")
     return out

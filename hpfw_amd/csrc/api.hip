@@ -96,6 +96,7 @@ struct hpfw_gpu {
     std::map<int64_t, std::unique_ptr<DevPlan>> plans; // one per clip length, least recently used evicted
     size_t plan_bytes = 0;
     uint64_t plan_clock = 0;
+    unsigned conventions = 0; // hpfw_gpu_set_conventions: essentia conventions that cannot be checked offline
     int batch = 1024; // clips per pass: ~10 GB of workspace at 30 s; every launch fills the 256 CUs many times over
     // extraction workspace
     size_t ws_bytes[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -243,7 +244,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     auto dp = std::make_unique<DevPlan>();
     std::string why;
     // HPFW_FORCE_BLUESTEIN=1 (tests): the chirp-z forward transform for 7-smooth lengths too
-    if (!hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr))
+    if (!hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions))
         return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n) + ": " + why);
     const hpfw::HostPlan &p = dp->hp;
     using hpfw::cf;
@@ -595,6 +596,19 @@ int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out)
     if (rc) return rc;
     const hpfw::HostPlan &p = dp->hp;
     *out = {p.n, p.n1, p.n2, p.kmin, p.kmax, p.m, p.c, p.n_frames, p.n_hp};
+    return 0;
+}
+
+int hpfw_gpu_set_conventions(hpfw_gpu *h, unsigned flags)
+{
+    if (!h || flags > hpfw::kConvAll) return fail(HPFW_E_INVALID, "unknown convention flag");
+    HIP_TRY(hipSetDevice(h->device));
+    if (flags != h->conventions) { // the tables of every cached length were built under the old conventions
+        HIP_TRY(hipDeviceSynchronize());
+        h->plans.clear();
+        h->plan_bytes = 0;
+    }
+    h->conventions = flags;
     return 0;
 }
 

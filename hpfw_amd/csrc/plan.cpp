@@ -371,7 +371,7 @@ static void build_bluestein_tables(HostPlan &p)
     });
 }
 
-bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bool force_bluestein)
+bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bool force_bluestein, unsigned conv)
 {
     if (n < 2) {
         why = "clip too short";
@@ -390,8 +390,19 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
     int64_t kmin = n, kmax = 0, big_m = 0;
     for (int j = 0; j < kBins; ++j) {
         const double f = kMinFreq * std::pow(2.0, (double)j / kBpo);
-        const int64_t posit = (int64_t)std::floor(f / fftres);
-        int64_t lg = (int64_t)std::round(q * f / fftres);
+        int64_t posit;
+        double bw; // window length before rounding
+        if (conv & kConvFloatGeometry) { // essentia's Real is float
+            const float fres = (float)kSampleRate / (float)n;
+            const float qf = std::pow(2.0f, 1.0f / (float)kBpo) - std::pow(2.0f, -1.0f / (float)kBpo);
+            const float ff = (float)kMinFreq * std::pow(2.0f, (float)j / (float)kBpo);
+            posit = (int64_t)std::floor(ff / fres);
+            bw = (double)(qf * ff / fres);
+        } else {
+            posit = (int64_t)std::floor(f / fftres);
+            bw = q * f / fftres;
+        }
+        int64_t lg = (conv & kConvLgHalfEven) ? (int64_t)std::nearbyint(bw) : (int64_t)std::round(bw);
         if (lg < kMinWindow) lg = kMinWindow;
         const int64_t st = posit - lg / 2;
         p.start[j] = (int)st;
@@ -616,10 +627,11 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
     p.g.resize((size_t)goff);
     parallel_rows(kBins, [&](int64_t j) {
         const int64_t lg = p.lg[j];
-        const double scale = 1.0 / ((double)big_m * (double)p.psize[j]);
+        const double scale = 1.0 / (((conv & kConvNoIfftScale) ? 1.0 : (double)big_m) * (double)p.psize[j]);
+        const double hann_den = (conv & kConvHannPeriodic) ? (double)lg : (double)(lg - 1);
         HostCf *gj = p.g.data() + p.g_off[(size_t)j];
         for (int64_t i = 0; i < lg; ++i) {
-            const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / (double)(lg - 1));
+            const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / hann_den);
             double cc, ss;
             chirp_d(i, big_m, cc, ss);
             gj[i] = {(float)(w * cc * scale), (float)(w * ss * scale)};
@@ -753,13 +765,19 @@ extern "C" int64_t hpfw_gpu_supported_length(int64_t n_samples)
     return -1;
 }
 
+extern "C" int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein, unsigned conventions, uint64_t *out8);
+
 extern "C" int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8)
+{
+    // negative length: the chirp-z tables of |n_samples| even when it is 7-smooth
+    return hpfw_gpu_plan_checksum_ex(n_samples < 0 ? -n_samples : n_samples, n_samples < 0, 0, out8);
+}
+
+extern "C" int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein, unsigned conventions, uint64_t *out8)
 {
     hpfw::HostPlan p;
     std::string why;
-    const bool force = n_samples < 0; // negative length: the chirp-z tables of |n_samples| even when it is 7-smooth
-    if (force) n_samples = -n_samples;
-    if (!out8 || !hpfw::build_plan(n_samples, p, why, false, force)) return -2;
+    if (!out8 || conventions > hpfw::kConvAll || !hpfw::build_plan(n_samples, p, why, false, force_bluestein != 0, conventions)) return -2;
     out8[0] = fnv1a(p.tw_n2.data(), p.tw_n2.size() * 8);
     out8[1] = fnv1a(p.tw_n1.data(), p.tw_n1.size() * 8);
     out8[2] = fnv1a(p.tw_big.data(), p.tw_big.size() * 8);

@@ -55,9 +55,19 @@ struct HostPlan {
 
 // Returns false (and a reason) when the clip length is unsupported.
 // geometry_only: stop after the sizes (n1, n2, M, C, bins consumed) are known, build no table
+// Conventions of essentia's NSGConstantQ that cannot be checked offline (essentia is not vendored; DESIGN.md
+// appendix A): a maintainer holding one real essentia output flips these until the geometry and the spectrogram
+// match, without touching a kernel.  0 = the restatement's defaults.
+enum : unsigned {
+    kConvHannPeriodic = 1u,   // window 0.5 - 0.5 cos(2 pi i / L) instead of the symmetric 2 pi i / (L - 1)
+    kConvLgHalfEven = 2u,     // Lg = round-half-to-even(bw / fftres) instead of round-half-away-from-zero
+    kConvFloatGeometry = 4u,  // fftres, band frequencies, posit and Lg evaluated in float (essentia's Real) instead of double
+    kConvNoIfftScale = 8u,    // band transforms without the 1/M of the inverse FFT (only the 1e-10 power floor sees it)
+    kConvAll = 15u
+};
 // force_bluestein: take the chirp-z forward transform even when the length is 7-smooth (tests)
 bool build_plan(int64_t n_samples, HostPlan &out, std::string &why, bool geometry_only = false,
-                bool force_bluestein = false);
+                bool force_bluestein = false, unsigned conventions = 0);
 // S16: DFT of length n in double, in place (n's prime factors at most 31): recursive decimation in time by
 // the smallest prime factor, X[k] = F_0[k mod m] + sum_q W_n^{qk} F_q[k mod m] in ascending q, plain products
 void dft_generic_d(double *re, double *im, int64_t n);

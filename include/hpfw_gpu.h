@@ -84,6 +84,16 @@ void hpfw_gpu_destroy(hpfw_gpu *h);
 int hpfw_gpu_set_filters(hpfw_gpu *h, const float *filters_colmajor);
 int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out);
 
+/* essentia's NSGConstantQ is not vendored with hpfw and its version is not pinned (CMakeLists.txt:36), so four of
+ * its conventions are restated from the published algorithm and cannot be checked offline (DESIGN.md appendix
+ * A).  They are switchable per handle: a maintainer holding one real essentia output can pin them without
+ * touching a kernel (the tables of every clip length are rebuilt).  0 = the defaults. */
+#define HPFW_CONV_HANN_PERIODIC 1u  /* window 0.5 - 0.5 cos(2 pi i / L) instead of 2 pi i / (L - 1)                 */
+#define HPFW_CONV_LG_HALF_EVEN 2u   /* Lg = round-half-to-even(bw / fftres) instead of round-half-away-from-zero   */
+#define HPFW_CONV_FLOAT_GEOMETRY 4u /* fftres, f_j, posit_j, Lg_j evaluated in float (essentia's Real), not double */
+#define HPFW_CONV_NO_IFFT_SCALE 8u  /* band transforms without the inverse FFT's 1/M (seen only by the 1e-10 floor) */
+int hpfw_gpu_set_conventions(hpfw_gpu *h, unsigned flags);
+
 /* ---- extraction: calc_hashprint for n_clips clips of n_samples samples each ------------- */
 /* d_hp receives [n_clips][n_hp] */
 int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples, int64_t n_clips,
@@ -256,6 +266,8 @@ int hpfw_gpu_get_kernel_timing(hpfw_gpu *h, const char **names, float *ms, int *
  * clips of n_samples samples (twiddles, digit reversal, bands, window*chirp, chirp spectra).
  * No device is touched. */
 int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8);
+/* the same with the chirp-z forward transform forced and under given conventions (HPFW_CONV_*) */
+int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein, unsigned conventions, uint64_t *out8);
 
 /* ---- legacy FFI: modules/python/parallel_collector_wrapper.hpp:12-38, same shapes --------- */
 typedef struct {

@@ -323,6 +323,7 @@ struct hpfw_oracle_plan {
     int n_cls;
     bluestein_class bc[8];
     /* S15: forward DFT of a clip whose length has a prime factor above 7, as a chirp-z convolution */
+    unsigned conv;   /* HPFW_O_CONV_*: essentia conventions that cannot be checked offline (hpfw_oracle.h) */
     int bluestein;
     int64_t bz_l;    /* L = n1 * n2 >= N + (kmax - kmin) - 1, n2 = 6300 */
     cf *bz_w;        /* [n1][n2]: w[r + n1 t] = e^{-i pi n^2 / N}, 0 from n = N on */
@@ -345,8 +346,19 @@ static int make_bands(hpfw_oracle_plan *p)
     int64_t kmin = n, kmax = 0, m = 0;
     for (int j = 0; j < HPFW_O_BINS; ++j) {
         double f = MIN_FREQ * pow(2.0, (double)j / BINS_PER_OCTAVE);
-        int64_t posit = (int64_t)floor(f / fftres);
-        int64_t lg = (int64_t)round(q * f / fftres);
+        int64_t posit;
+        double bw;
+        if (p->conv & HPFW_O_CONV_FLOAT_GEOMETRY) { /* essentia's Real is float */
+            float fres = (float)SAMPLE_RATE / (float)n;
+            float qf = powf(2.0f, 1.0f / (float)BINS_PER_OCTAVE) - powf(2.0f, -1.0f / (float)BINS_PER_OCTAVE);
+            float ff = (float)MIN_FREQ * powf(2.0f, (float)j / (float)BINS_PER_OCTAVE);
+            posit = (int64_t)floorf(ff / fres);
+            bw = (double)(qf * ff / fres);
+        } else {
+            posit = (int64_t)floor(f / fftres);
+            bw = q * f / fftres;
+        }
+        int64_t lg = (p->conv & HPFW_O_CONV_LG_HALF_EVEN) ? (int64_t)nearbyint(bw) : (int64_t)round(bw);
         if (lg < MIN_WINDOW) lg = MIN_WINDOW;
         int64_t st = posit - lg / 2;
         p->start[j] = (int32_t)st;
@@ -489,9 +501,10 @@ static int make_bluestein(hpfw_oracle_plan *p)
          * 0.5 - 0.5 cos(2 pi i / (size - 1)), un-normalised, no zero-phase */
         int64_t lg = p->lg[j];
         p->g[j] = (cf *)malloc(sizeof(cf) * (size_t)lg);
-        double scale = 1.0 / ((double)big_m * (double)ps);
+        double scale = 1.0 / (((p->conv & HPFW_O_CONV_NO_IFFT_SCALE) ? 1.0 : (double)big_m) * (double)ps);
+        double hann_den = (p->conv & HPFW_O_CONV_HANN_PERIODIC) ? (double)lg : (double)(lg - 1);
         for (int64_t i = 0; i < lg; ++i) {
-            double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)(lg - 1));
+            double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / hann_den);
             double cc, ss;
             chirp_d(i, big_m, &cc, &ss);
             p->g[j][i].r = (float)(w * cc * scale);
@@ -671,11 +684,14 @@ static void make_forward_bluestein(hpfw_oracle_plan *p)
     free(yi);
 }
 
-hpfw_oracle_plan *hpfw_oracle_plan_create2(int64_t n, int force_bluestein)
+hpfw_oracle_plan *hpfw_oracle_plan_create2(int64_t n, int force_bluestein) { return hpfw_oracle_plan_create3(n, force_bluestein, 0); }
+
+hpfw_oracle_plan *hpfw_oracle_plan_create3(int64_t n, int force_bluestein, unsigned conventions)
 {
-    if (n < 2) return NULL;
+    if (n < 2 || conventions > 15u) return NULL;
     hpfw_oracle_plan *p = (hpfw_oracle_plan *)calloc(1, sizeof(*p));
     p->info.n_samples = n;
+    p->conv = conventions;
     {
         int64_t rest = n;
         while (rest % 2 == 0) rest /= 2;

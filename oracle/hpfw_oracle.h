@@ -55,6 +55,13 @@ hpfw_oracle_plan *hpfw_oracle_plan_create(int64_t n_samples); /* NULL when the c
 /* force_bluestein: take the chirp-z forward transform (the path of lengths with a prime factor
  * above 7) even when N is 7-smooth */
 hpfw_oracle_plan *hpfw_oracle_plan_create2(int64_t n_samples, int force_bluestein);
+/* essentia conventions that cannot be checked offline (essentia is not vendored), switchable so that one real
+ * essentia output can pin them: DESIGN.md appendix A.  0 = the restatement's defaults. */
+#define HPFW_O_CONV_HANN_PERIODIC 1u  /* window 0.5 - 0.5 cos(2 pi i / L) instead of 2 pi i / (L - 1)     */
+#define HPFW_O_CONV_LG_HALF_EVEN 2u   /* Lg rounded half-to-even instead of half-away-from-zero            */
+#define HPFW_O_CONV_FLOAT_GEOMETRY 4u /* fftres, f_j, posit_j, Lg_j in float (essentia's Real), not double */
+#define HPFW_O_CONV_NO_IFFT_SCALE 8u  /* band transforms without the inverse FFT's 1/M                     */
+hpfw_oracle_plan *hpfw_oracle_plan_create3(int64_t n_samples, int force_bluestein, unsigned conventions);
 /* S16: the double-precision DFT the chirp-z tables are built with, in place */
 void hpfw_oracle_dft_double(double *re, double *im, int64_t n);
 void hpfw_oracle_plan_destroy(hpfw_oracle_plan *p);

@@ -21,29 +21,43 @@ MIN_WINDOW = 96
 BINS = 121
 
 
-def bands(n):
-    fftres = SR / n
-    q = 2.0 ** (1.0 / BPO) - 2.0 ** (-1.0 / BPO)
+# essentia conventions that cannot be checked offline (same bits as HPFW_CONV_* of include/hpfw_gpu.h)
+CONV_HANN_PERIODIC, CONV_LG_HALF_EVEN, CONV_FLOAT_GEOMETRY, CONV_NO_IFFT_SCALE = 1, 2, 4, 8
+
+
+def bands(n, conventions=0):
     nb = int(np.floor(BPO * np.log2(FMAX / FMIN))) + 1
     assert nb == BINS
-    f = FMIN * 2.0 ** (np.arange(nb) / BPO)
-    posit = np.floor(f / fftres).astype(np.int64)
-    lg = np.maximum(np.floor(q * f / fftres + 0.5).astype(np.int64), MIN_WINDOW)
+    if conventions & CONV_FLOAT_GEOMETRY:                     # essentia's Real is float
+        f32 = np.float32
+        fftres = f32(SR) / f32(n)
+        q = f32(2.0) ** (f32(1.0) / f32(BPO)) - f32(2.0) ** (f32(-1.0) / f32(BPO))
+        f = f32(FMIN) * f32(2.0) ** (np.arange(nb, dtype=np.float32) / f32(BPO))
+        posit = np.floor(f / fftres).astype(np.int64)
+        bw = (q * f / fftres).astype(np.float64)
+    else:
+        fftres = SR / n
+        q = 2.0 ** (1.0 / BPO) - 2.0 ** (-1.0 / BPO)
+        f = FMIN * 2.0 ** (np.arange(nb) / BPO)
+        posit = np.floor(f / fftres).astype(np.int64)
+        bw = q * f / fftres
+    rounded = np.rint(bw) if conventions & CONV_LG_HALF_EVEN else np.floor(bw + 0.5)
+    lg = np.maximum(rounded.astype(np.int64), MIN_WINDOW)
     return posit, lg
 
 
-def cq_magnitudes(pcm):
+def cq_magnitudes(pcm, conventions=0):
     """|c_j[3c]| in float64, bin-major [121][ceil(M/3)], for int16 PCM."""
     x = np.asarray(pcm, np.float64) / 32768.0
     n = x.size
     spec = np.fft.fft(x)
-    posit, lg = bands(n)
+    posit, lg = bands(n, conventions)
     m = int(lg.max())
     cols = (m + 2) // 3
     out = np.zeros((BINS, cols))
     for j in range(BINS):
         L = int(lg[j])
-        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(L) / (L - 1))
+        win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(L) / (L if conventions & CONV_HANN_PERIODIC else L - 1))
         idx = (posit[j] - L // 2 + np.arange(L)) % n
         prod = spec[idx] * win
         buf = np.zeros(m, np.complex128)
@@ -53,6 +67,8 @@ def cq_magnitudes(pcm):
         buf[: L - half] = prod[half:]
         buf[m - half:] = prod[:half]
         cj = np.fft.ifft(buf)  # 1/M normalised
+        if conventions & CONV_NO_IFFT_SCALE:
+            cj = cj * m
         out[j] = np.abs(cj[::3])[:cols]
     return out
 

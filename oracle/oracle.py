@@ -49,6 +49,8 @@ def lib():
         L.hpfw_oracle_plan_create.argtypes = [i64]
         L.hpfw_oracle_plan_create2.restype = vp
         L.hpfw_oracle_plan_create2.argtypes = [i64, i32]
+        L.hpfw_oracle_plan_create3.restype = vp
+        L.hpfw_oracle_plan_create3.argtypes = [i64, i32, ctypes.c_uint32]
         L.hpfw_oracle_dft_double.argtypes = [vp, vp, i64]
         L.hpfw_oracle_plan_destroy.argtypes = [vp]
         L.hpfw_oracle_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
@@ -99,8 +101,8 @@ def _c(a, dtype):
 class Plan:
     """Geometry + tables for clips of n_samples samples (essentia NSGConstantQ, cqt.h:54-61)."""
 
-    def __init__(self, n_samples, force_bluestein=False):
-        self._h = lib().hpfw_oracle_plan_create2(int(n_samples), int(bool(force_bluestein)))
+    def __init__(self, n_samples, force_bluestein=False, conventions=0):
+        self._h = lib().hpfw_oracle_plan_create3(int(n_samples), int(bool(force_bluestein)), int(conventions))
         if not self._h:
             raise ValueError(f"unsupported clip length {n_samples} (too short or too long)")
         info = PlanInfo()

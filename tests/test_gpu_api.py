@@ -226,9 +226,13 @@ def test_c_abi_error_codes(torch_cuda):
     with pytest.raises(hpfw_amd.HpfwError) as e:
         g.extract(pcm)
     assert "-3" in str(e.value) and "filters" in str(e.value)        # HPFW_E_NOFILTERS
+    assert g.geometry(132301).n2 == 6300                              # 11 | 132301: the chirp-z forward transform
     with pytest.raises(hpfw_amd.HpfwError) as e:
-        g.geometry(132301)
+        g.geometry(4410)                                              # 0.1 s: the bands leave the half spectrum
     assert "-2" in str(e.value)                                       # HPFW_E_UNSUPPORTED
+    with pytest.raises(hpfw_amd.HpfwError) as e:
+        g.set_conventions(64)
+    assert "-1" in str(e.value)                                       # HPFW_E_INVALID
     import ctypes
     h = ctypes.c_void_p()
     assert L.hpfw_gpu_create(99, ctypes.byref(h)) == -1               # HPFW_E_INVALID: no such device

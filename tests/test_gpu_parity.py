@@ -585,3 +585,36 @@ def test_combiner_configuration_16_bit_hashprints(gpu, torch_cuda, oracle):
     torch.cuda.synchronize()
     for i in range(2):
         assert np.array_equal(d_hp64.cpu().numpy().view(np.uint64)[i], oracle.pack(oracle.project(filt64, s64[i])))
+
+
+@pytest.mark.parametrize("conv", [1, 2, 4, 8, 15])
+def test_switchable_essentia_conventions(torch_cuda, oracle, filters, conv):
+    """the four conventions of essentia's NSGConstantQ that cannot be checked offline (Hann end point, Lg rounding,
+    float geometry, inverse-FFT scale; include/hpfw_gpu.h HPFW_CONV_*) are plan-level switches: under every
+    setting the GPU path stays bit-identical to the oracle and within 1e-4 of the float64 definition evaluated
+    under the same setting -- no kernel knows about them"""
+    from oracle import nsgt_f64
+    torch = torch_cuda
+    clips = np.stack([synth.gen_clip(930 + i, 3.0) for i in range(2)])
+    n = clips.shape[1]
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filters)
+    base = g.extract(clips)
+    g.set_conventions(conv)                                   # rebuilds the tables of every length
+    plan = oracle.Plan(n, conventions=conv)
+    geo = g.geometry(n)
+    assert (geo.m, geo.c, geo.kmin, geo.kmax) == (plan.m, plan.c, plan.kmin, plan.kmax)
+    assert np.array_equal(g.extract(clips), np.stack([plan.extract(filters, c) for c in clips]))
+    nk = plan.kmax - plan.kmin
+    d_pcm = _dev(torch, clips)
+    d_x = torch.empty((2, nk, 2), dtype=torch.float32, device="cuda")
+    g.stage_spectrum_dev(d_pcm.data_ptr(), n, 2, d_x.data_ptr())
+    d_mag = torch.empty((2, 121, plan.c), dtype=torch.float32, device="cuda")
+    g.stage_cqmag_dev(d_x.data_ptr(), n, 2, d_mag.data_ptr())
+    torch.cuda.synchronize()
+    mag = d_mag.cpu().numpy()
+    m64 = nsgt_f64.cq_magnitudes(clips[0], conv)
+    assert mag[0].shape == m64.shape and (np.abs(mag[0] - m64).max(axis=1) / m64.max(axis=1)).max() < 1e-4
+    g.set_conventions(0)
+    assert np.array_equal(g.extract(clips), base)
+    g.close()
