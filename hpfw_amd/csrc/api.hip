@@ -151,10 +151,6 @@ struct hpfw_gpu {
     std::map<std::vector<int>, float *> cfg_fpack;
     float *d_cfg_proj = nullptr;
     size_t cfg_proj_cap = 0;
-    // the chirp-z size classes of one pass are independent launches: they run side by side on these streams
-    // (forked from and joined back into the caller's stream), so that their launch tails overlap
-    hipStream_t cq_side[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t cq_fork = nullptr, cq_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // ordering of consecutive entry points that were handed different streams (the workspaces are shared)
     hipEvent_t order_ev = nullptr;
     hipStream_t order_stream = nullptr;
@@ -453,39 +449,6 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
     return check_launch("fwd_cols");
 }
 
-// the band transforms of nb clips: x -> mag (and the wave maxima mm).  Classes held in LDS go out side by side
-// (HPFW_CQ_ONE_STREAM=1: one after the other); classes that pass through the shared global workspace stay in turn.
-int run_cq(hpfw_gpu *h, DevPlan *dp, const hpfw::cf *x, int nb, float *mag, float *mm, bool db_term, hipStream_t s)
-{
-    using hpfw::cf;
-    static const bool one_stream = std::getenv("HPFW_CQ_ONE_STREAM") != nullptr;
-    std::vector<const hpfw::CqClassDev *> lds_cls, big_cls;
-    for (const hpfw::CqClassDev &cd : dp->cls) (cd.outer ? big_cls : lds_cls).push_back(&cd);
-    const int n_side = one_stream ? 0 : std::min<int>(7, (int)lds_cls.size() - 1);
-    if (n_side > 0) {
-        if (!h->cq_fork) {
-            HIP_TRY(hipEventCreateWithFlags(&h->cq_fork, hipEventDisableTiming));
-            for (int i = 0; i < 7; ++i) {
-                HIP_TRY(hipStreamCreateWithFlags(&h->cq_side[i], hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&h->cq_join[i], hipEventDisableTiming));
-            }
-        }
-        HIP_TRY(hipEventRecord(h->cq_fork, s));
-        for (int i = 0; i < n_side; ++i) HIP_TRY(hipStreamWaitEvent(h->cq_side[i], h->cq_fork, 0));
-    }
-    for (size_t i = 0; i < lds_cls.size(); ++i) {
-        // class i on side stream i - 1 while there are side streams; the rest share the caller's stream
-        hipStream_t cs = (i >= 1 && (int)i <= n_side) ? h->cq_side[i - 1] : s;
-        hpfw::launch_cq_class(dp->cq, *lds_cls[i], x, nb, mag, mm, db_term, cs);
-    }
-    for (const hpfw::CqClassDev *cd : big_cls) hpfw::launch_cq_big_class(dp->cq, *cd, x, nb, (cf *)h->d_cqwork, mag, mm, db_term, s);
-    for (int i = 0; i < n_side; ++i) {
-        HIP_TRY(hipEventRecord(h->cq_join[i], h->cq_side[i]));
-        HIP_TRY(hipStreamWaitEvent(s, h->cq_join[i], 0));
-    }
-    return check_launch("cq_chirpz");
-}
-
 // front end for nb clips: PCM -> dB terms t (and their per-clip maximum in d_clipmax) at clip slot
 // `slot` of the S workspace; finish_db: also turn them into the dB spectrogram S = max(t - t_max, -80)
 // in place (the projection does that itself while staging, the covariance wants S)
@@ -498,10 +461,14 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
     float *mm = (float *)h->ws[4] + (size_t)slot * 121 * hpfw::kCqMaxWaves; // this pass's wave maxima
     int rc;
     if ((rc = run_forward(h, dp, d_pcm, nb, x, s))) return rc;
-    {
+    for (const hpfw::CqClassDev &cd : dp->cls) {
         Timed t(h, K_CQ, s);
-        if ((rc = run_cq(h, dp, x, nb, mag, mm, true, s))) return rc;
+        if (cd.outer)
+            hpfw::launch_cq_big_class(dp->cq, cd, x, nb, (cf *)h->d_cqwork, mag, mm, true, s);
+        else
+            hpfw::launch_cq_class(dp->cq, cd, x, nb, mag, mm, true, s);
     }
+    if ((rc = check_launch("cq_chirpz"))) return rc;
     {
         Timed t(h, K_DB, s);
         hpfw::launch_clipmax(mm, h->d_clipmax + slot, nb, s);
@@ -588,11 +555,6 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->stage_copy) (void)hipStreamDestroy(h->stage_copy);
     if (h->stage_comp) (void)hipStreamDestroy(h->stage_comp);
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
-    for (int i = 0; i < 7; ++i) {
-        if (h->cq_side[i]) (void)hipStreamDestroy(h->cq_side[i]);
-        if (h->cq_join[i]) (void)hipEventDestroy(h->cq_join[i]);
-    }
-    if (h->cq_fork) (void)hipEventDestroy(h->cq_fork);
     for (auto &kv : h->cfg_fpack) (void)hipFree(kv.second);
     if (h->d_cfg_proj) (void)hipFree(h->d_cfg_proj);
     if (h->d_db) (void)hipFree(h->d_db);
@@ -771,8 +733,15 @@ int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        if ((rc = run_cq(h, dp, (const hpfw::cf *)d_x + c0 * nk, nb, d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s)))
-            return rc;
+        for (const hpfw::CqClassDev &cd : dp->cls) {
+            if (cd.outer)
+                hpfw::launch_cq_big_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb, (hpfw::cf *)h->d_cqwork,
+                                          d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s);
+            else
+                hpfw::launch_cq_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb,
+                                      d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s);
+        }
+        if ((rc = check_launch("cq_chirpz"))) return rc;
     }
     return 0;
 }
