@@ -76,6 +76,64 @@ def main():
                        "clips_per_launch_profiled": clips, "source": f"{tag}_pmc.json",
                        "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / clips, launches of the largest grid"},
                       open(os.path.join(here, "traffic.json"), "w"), indent=1)
+    # ---- calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (tools/fetch_calib.bin streams 1 GiB per kernel)
+    calib = {}
+    for which, counter, kern in (("calib_fetch", "FETCH_SIZE", "calib_read"), ("calib_write", "WRITE_SIZE", "calib_write")):
+        files = glob.glob(os.path.join(src, which, "**", "*_counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        acc = defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(files[0])):
+            if kern in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                width = {"b2": 2, "b4": 4, "b8": 8, "b16": 16}[r["Kernel_Name"].split("<")[1].split(">")[0].strip()]
+                a = acc[width]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+        for width, (tot, n) in sorted(acc.items()):
+            calib.setdefault(counter, {})[f"{width}_bytes_per_lane"] = {
+                "counter_KiB_per_launch": tot / n, "bytes_streamed": 1 << 30,
+                "counter_bytes_over_true_bytes": tot / n * 1024.0 / (1 << 30)}
+    if calib:
+        calib["note"] = ("coalesced streaming of 1 GiB (past the 256 MiB Infinity Cache), 2 launches each; a ratio of 0.5 for "
+                         "FETCH_SIZE is the gfx950 half-counting of MI355X_MICROARCH.md; bytes = counter / ratio")
+        json.dump(calib, open(os.path.join(here, f"{tag}_counter_calibration.json"), "w"), indent=1, sort_keys=True)
+    # ---- SQ counters (separate passes sq1..sq5), launches of the largest grid of every kernel
+    sq = {}
+    for d in sorted(glob.glob(os.path.join(src, "sq*"))):
+        files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        acc = defaultdict(lambda: defaultdict(lambda: defaultdict(lambda: [0.0, 0])))
+        for r in csv.DictReader(open(files[0])):
+            if "hpfw::" in r["Kernel_Name"]:
+                a = acc[short(r["Kernel_Name"])][int(r["Grid_Size"])][r["Counter_Name"]]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+        for k, by_grid in acc.items():
+            grid = max(by_grid)
+            for cname, (tot, n) in by_grid[grid].items():
+                sq.setdefault(k, {"grid_work_items": grid})[cname] = tot / n
+    for k, d in sq.items():
+        busy, wc = d.get("SQ_BUSY_CYCLES"), d.get("SQ_WAVE_CYCLES")
+        der = {}
+        # SQ_BUSY_CYCLES sums the 32 shader engines' busy cycles, the per-SIMD counters the 1024 SIMDs':
+        # x / (32 * SQ_BUSY_CYCLES) is the fraction of the kernel's cycles a SIMD spent on x
+        if busy and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            der["mfma_busy_fraction"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * busy)
+        if busy and "SQ_INSTS_VALU" in d:
+            der["valu_issue_fraction"] = d["SQ_INSTS_VALU"] * 2.0 / (32.0 * busy)   # 2 cycles per wave64 VALU instruction
+        if wc:
+            for name, key in (("active", "SQ_ACTIVE_INST_ANY"), ("parked_waitcnt_or_barrier", "SQ_WAIT_ANY"),
+                              ("issue_stalled", "SQ_WAIT_INST_ANY"), ("lds_issue_stalled", "SQ_WAIT_INST_LDS")):
+                if key in d:
+                    der["wave_cycles_" + name] = d[key] / wc
+            if busy:
+                der["resident_waves_per_simd"] = wc * 4.0 / (32.0 * busy)   # SQ_WAVE_CYCLES counts in units of 4 cycles
+        if d.get("SQ_LDS_IDX_ACTIVE"):
+            der["lds_bank_conflict_fraction"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
+        d["derived"] = der
+    if sq:
+        json.dump(sq, open(os.path.join(here, f"{tag}_sq.json"), "w"), indent=1, sort_keys=True)
     print(open(os.path.join(here, f"{tag}_kernel_stats.csv")).read() if rows else "no trace")
     print(json.dumps(pmc, indent=1, sort_keys=True))
 

@@ -1,18 +1,36 @@
 #!/bin/bash
-# Round profile: kernel trace + stats of the default bench command, then FETCH_SIZE and WRITE_SIZE in
-# separate --pmc passes (kernel trace only), all under gpurun_out/prof; summarise with
+# Round profile (run on the GPU box): everything lands under gpurun_out/prof; condense afterwards with
 #   python profiles/summarize.py <tag> gpurun_out/prof 1000
+#  1. trace/   rocprofv3 --kernel-trace --stats of the default bench command (python3 bench.py)
+#  2. fetch/, write/   FETCH_SIZE and WRITE_SIZE in separate --pmc passes (kernel trace only)
+#  3. sq1..sq5/   SQ counters (occupancy, VALU / MFMA / LDS activity, waits, bank conflicts) in separate passes
+#  4. calib_fetch/, calib_write/   the counters on known byte counts at 2/4/8/16 B per lane (tools/fetch_calib.bin)
+# The program after "--" is python3 / the binary itself: no env, no shell, nothing that re-execs after the
+# profiler's library has initialised the GPU; the --pmc passes run with --no-parity so that the profiled process
+# holds nothing but the product.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof
 mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace -o p --output-format csv -- python3 bench.py > gpurun_out/prof/bench_trace.log 2> gpurun_out/prof/bench_trace.err || { echo "trace run failed"; tail -5 gpurun_out/prof/bench_trace.err; exit 1; }
 echo "trace done"
-for c in fetch:FETCH_SIZE write:WRITE_SIZE; do
-  d=${c%%:*}; n=${c##*:}
-  rocprofv3 --kernel-trace --pmc $n -d gpurun_out/prof/$d -o p --output-format csv -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/prof/bench_$d.log 2> gpurun_out/prof/bench_$d.err || { echo "$d run failed"; tail -5 gpurun_out/prof/bench_$d.err; exit 1; }
+LIGHT="--no-parity --no-cpu-baseline --no-pcie --no-learn --steps 2 --warmup 1"
+for c in fetch:FETCH_SIZE write:WRITE_SIZE \
+         "sq1:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
+         "sq2:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+         "sq3:SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY" \
+         "sq4:SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY" \
+         "sq5:SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA"; do
+  d=${c%%:*}; n=${c#*:}
+  rocprofv3 --kernel-trace --pmc $n -d gpurun_out/prof/$d -o p --output-format csv -- python3 bench.py $LIGHT > gpurun_out/prof/bench_$d.log 2> gpurun_out/prof/bench_$d.err || { echo "$d run failed"; tail -5 gpurun_out/prof/bench_$d.err; }
+  echo "$d done"
+done
+for c in calib_fetch:FETCH_SIZE calib_write:WRITE_SIZE; do
+  d=${c%%:*}; n=${c#*:}
+  rocprofv3 --kernel-trace --pmc $n -d gpurun_out/prof/$d -o p --output-format csv -- tools/fetch_calib.bin > gpurun_out/prof/$d.log 2>&1 || echo "$d failed"
   echo "$d done"
 done
 # keep only what the summariser reads (the raw traces are large)
-find gpurun_out/prof/fetch gpurun_out/prof/write -name "*_kernel_trace.csv" -delete
-ls -R gpurun_out/prof | head -40
+find gpurun_out/prof -path "*trace*" -prune -o -name "*_kernel_trace.csv" -print | xargs -r rm -f
+find gpurun_out/prof -name "*agent_info*" -delete
+du -sh gpurun_out/prof
