@@ -8,7 +8,7 @@ into the tracked summaries:
   profiles/traffic.json             HBM bytes per clip of the dominant kernel, read by bench.py
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters are in KiB, and on gfx950 FETCH_SIZE
 reports half of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section).
-usage: python profiles/summarize.py r01 [gpurun_out/prof] [clips_per_launch=1000]"""
+usage: python profiles/summarize.py r02 [gpurun_out/prof] [clips_per_launch=1000] [output dir]"""
 import csv
 import glob
 import json
@@ -29,7 +29,10 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
     clips = float(sys.argv[3]) if len(sys.argv) > 3 else 1000.0   # clips per back-end launch in the profiled run
-    here = os.path.dirname(os.path.abspath(__file__))
+    # summaries go next to this script, or to the directory given as the 4th argument (the GPU box writes
+    # them under gpurun_out/, the only directory that travels back)
+    here = sys.argv[4] if len(sys.argv) > 4 else os.path.dirname(os.path.abspath(__file__))
+    os.makedirs(here, exist_ok=True)
     traces = glob.glob(os.path.join(src, "trace", "**", "*_kernel_trace.csv"), recursive=True)
     rows = []
     if traces:

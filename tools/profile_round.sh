@@ -30,7 +30,11 @@ for c in calib_fetch:FETCH_SIZE calib_write:WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $n -d gpurun_out/prof/$d -o p --output-format csv -- tools/fetch_calib.bin > gpurun_out/prof/$d.log 2>&1 || echo "$d failed"
   echo "$d done"
 done
-# keep only what the summariser reads (the raw traces are large)
-find gpurun_out/prof -path "*trace*" -prune -o -name "*_kernel_trace.csv" -print | xargs -r rm -f
-find gpurun_out/prof -name "*agent_info*" -delete
-du -sh gpurun_out/prof
+# condense on the box (the raw traces are far above what travels back), keep the summaries and the logs
+TAG=${1:-r02}
+python3 profiles/summarize.py $TAG gpurun_out/prof 1000 gpurun_out/profiles_$TAG > gpurun_out/profiles_$TAG.log 2>&1 || tail -5 gpurun_out/profiles_$TAG.log
+cp gpurun_out/prof/trace/p_kernel_stats.csv gpurun_out/profiles_$TAG/${TAG}_rocprof_stats_raw.csv 2>/dev/null || find gpurun_out/prof/trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/profiles_$TAG/${TAG}_rocprof_stats_raw.csv \;
+grep -h "^{" gpurun_out/prof/bench_trace.log | tail -1 > gpurun_out/profiles_$TAG/${TAG}_bench_under_trace.json
+mkdir -p gpurun_out/prof_logs && cp gpurun_out/prof/*.log gpurun_out/prof/*.err gpurun_out/prof_logs/ 2>/dev/null
+rm -rf gpurun_out/prof
+ls -la gpurun_out/profiles_$TAG
