@@ -19,7 +19,7 @@ KERNEL_KINDS = ("fwd_rows", "fwd_cols", "cq_chirpz", "db", "project_mfma", "delt
 
 # every symbol include/hpfw_gpu.h declares (tests check that the library exports all of them)
 EXPORTS = (
-    "hpfw_gpu_last_error", "hpfw_gpu_version", "hpfw_gpu_create", "hpfw_gpu_destroy",
+    "hpfw_gpu_last_error", "hpfw_gpu_version", "hpfw_gpu_create", "hpfw_gpu_destroy", "hpfw_gpu_device",
     "hpfw_gpu_set_filters", "hpfw_gpu_geometry", "hpfw_gpu_extract_pcm16",
     "hpfw_gpu_extract_pcm16_host", "hpfw_gpu_set_batch", "hpfw_gpu_stage_spectrum",
     "hpfw_gpu_stage_cqmag", "hpfw_gpu_stage_db", "hpfw_gpu_stage_project", "hpfw_gpu_stage_pack",

@@ -526,6 +526,8 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     return 0;
 }
 
+int hpfw_gpu_device(const hpfw_gpu *h) { return h ? h->device : -1; }
+
 void hpfw_gpu_destroy(hpfw_gpu *h)
 {
     if (!h) return;

@@ -407,87 +407,131 @@ struct KeptGroup {
 // skipped as the reference does (:101-103), so *got may be < n; results keep the input order; the name
 // is the stem of the path (:123,129).  HPFW_PREPARE_KEEP_FILTERS=1 skips the learning step and keeps
 // the filters that load() / a previous prepare() installed.
-static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int n, bool learn, bool cache_spectros,
-                          std::vector<uint64_t *> &hp, std::vector<int> &hp_size)
-{
-    const std::string spectro_dir = c->cache_dir + "spectros/";
-    if (cache_spectros) {
-        std::error_code ec;
-        std::filesystem::create_directories(spectro_dir, ec);
-    }
-    size_t keep_budget = (size_t)32 << 30;
-    if (const char *e = std::getenv("HPFW_PREPARE_KEEP_GB")) keep_budget = (size_t)std::max(0.0, std::atof(e) * 1073741824.0);
-    hp.assign((size_t)n, nullptr);
-    hp_size.assign((size_t)n, 0);
+// The two halves of prepare() around the point where the filters are learned: accumulate() is preprocess()'s
+// parallel_for (parallel_collector.h:85-105: spectrogram, covariance into accum_cov, spectrogram cached),
+// finish() is collect_fingerprints (:115-137) for the files of this call.  Between the two the caller learns the
+// filters -- from this collector's accum_cov alone (collect_files) or from the sum over the collectors of a
+// multi-GPU group (hpfw_gpu_group_prepare, multi.cpp).
+struct hpfw_prepare_job {
+    std::vector<uint64_t *> hp;
+    std::vector<int> hp_size;
     std::vector<KeptGroup> kept;
     std::vector<int> again; // files whose spectrogram could not be kept
     size_t kept_bytes = 0;
     int64_t used = 0;
+    bool learn = true, cache_spectros = true;
+};
 
-    // one pass over `files`: first = covariance (+ keep the spectrograms); otherwise hashprints at once
-    auto pass = [&](const std::vector<int> &files, bool first) {
-        size_t at = 0;
-        while (at < files.size()) {
-            size_t end = at;
-            uintmax_t bytes = 0; // a window: at most 256 files and about 1 GiB of audio
-            while (end < files.size() && end - at < 256 && (end == at || bytes < ((uintmax_t)1 << 30))) {
-                std::error_code ec;
-                const uintmax_t sz = std::filesystem::file_size(filenames[files[end]], ec);
-                if (!ec) bytes += sz;
-                ++end;
-            }
-            std::vector<Loaded> clips;
-            read_window(filenames, files, at, end, clips);
-            std::map<int64_t, std::vector<int>> by_len; // length -> positions in the window, in input order
-            for (size_t i = 0; i < clips.size(); ++i)
-                if (clips[i].ok) by_len[(int64_t)clips[i].pcm.size()].push_back((int)i);
-            for (auto &[len, pos] : by_len) {
-                hpfw_geometry g;
-                if (hpfw_gpu_geometry(c->gpu, len, &g) != 0 || g.n_frames < 2) continue; // skipped
-                float *d_db = group_spectrograms(c->gpu, clips, pos, len, g);
-                if (!d_db) continue;
-                std::vector<int> ids;
-                for (int q : pos) ids.push_back(files[at + (size_t)q]);
-                const size_t sz = pos.size() * (size_t)121 * g.c * 4;
-                if (first && cache_spectros) {
-                    // cache.set_spectro(filename, spectro) (parallel_collector.h:98-100): "it will also be needed
-                    // when adding new tracks" -- a later prepare() recomputes every cached track's hashprints
-                    std::vector<float> host(sz / 4);
-                    if (hipMemcpy(host.data(), d_db, sz, hipMemcpyDeviceToHost) == hipSuccess)
-                        host_team((int)ids.size(), [&](int k) {
-                            const std::string stem = std::filesystem::path(filenames[ids[(size_t)k]]).stem().string();
-                            (void)save_spectro_cereal(spectro_dir + stem, host.data() + (size_t)k * 121 * g.c, (int32_t)g.c);
-                        });
-                }
-                if (first && learn) {
-                    if (hpfw_gpu_cov_accumulate_db(c->gpu, d_db, (int64_t)pos.size(), g.c, nullptr) == 0) used += (int64_t)pos.size();
-                    if (g.n_hp > 0 && kept_bytes + sz <= keep_budget) {
-                        kept.push_back(KeptGroup{ids, g, d_db});
-                        kept_bytes += sz;
-                        continue;
-                    }
-                    if (g.n_hp > 0) again.insert(again.end(), ids.begin(), ids.end());
-                } else if (g.n_hp > 0) {
-                    std::vector<uint64_t *> out(pos.size(), nullptr);
-                    if (group_hashprints(c->gpu, d_db, pos.size(), g, out.data()))
-                        for (size_t k = 0; k < ids.size(); ++k) {
-                            hp[(size_t)ids[k]] = out[k];
-                            hp_size[(size_t)ids[k]] = (int)g.n_hp;
-                        }
-                }
-                (void)hipDeviceSynchronize();
-                (void)hipFree(d_db);
-            }
-            at = end;
+// one pass over `files`: first = covariance (+ keep the spectrograms); otherwise hashprints at once
+static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_prepare_job &job, const std::vector<int> &files,
+                         bool first)
+{
+    const std::string spectro_dir = c->cache_dir + "spectros/";
+    size_t keep_budget = (size_t)32 << 30;
+    if (const char *e = std::getenv("HPFW_PREPARE_KEEP_GB")) keep_budget = (size_t)std::max(0.0, std::atof(e) * 1073741824.0);
+    (void)hipSetDevice(hpfw_gpu_device(c->gpu));
+    size_t at = 0;
+    while (at < files.size()) {
+        size_t end = at;
+        uintmax_t bytes = 0; // a window: at most 256 files and about 1 GiB of audio
+        while (end < files.size() && end - at < 256 && (end == at || bytes < ((uintmax_t)1 << 30))) {
+            std::error_code ec;
+            const uintmax_t sz = std::filesystem::file_size(filenames[files[end]], ec);
+            if (!ec) bytes += sz;
+            ++end;
         }
-    };
+        std::vector<Loaded> clips;
+        read_window(filenames, files, at, end, clips);
+        std::map<int64_t, std::vector<int>> by_len; // length -> positions in the window, in input order
+        for (size_t i = 0; i < clips.size(); ++i)
+            if (clips[i].ok) by_len[(int64_t)clips[i].pcm.size()].push_back((int)i);
+        for (auto &kv : by_len) {
+            const int64_t len = kv.first;
+            const std::vector<int> &pos = kv.second;
+            hpfw_geometry g;
+            if (hpfw_gpu_geometry(c->gpu, len, &g) != 0 || g.n_frames < 2) continue; // skipped
+            float *d_db = group_spectrograms(c->gpu, clips, pos, len, g);
+            if (!d_db) continue;
+            std::vector<int> ids;
+            for (int q : pos) ids.push_back(files[at + (size_t)q]);
+            const size_t sz = pos.size() * (size_t)121 * g.c * 4;
+            if (first && job.cache_spectros) {
+                // cache.set_spectro(filename, spectro) (parallel_collector.h:98-100): "it will also be needed
+                // when adding new tracks" -- a later prepare() recomputes every cached track's hashprints
+                std::vector<float> host(sz / 4);
+                if (hipMemcpy(host.data(), d_db, sz, hipMemcpyDeviceToHost) == hipSuccess)
+                    host_team((int)ids.size(), [&](int k) {
+                        const std::string stem = std::filesystem::path(filenames[ids[(size_t)k]]).stem().string();
+                        (void)save_spectro_cereal(spectro_dir + stem, host.data() + (size_t)k * 121 * g.c, (int32_t)g.c);
+                    });
+            }
+            if (first && job.learn) {
+                if (hpfw_gpu_cov_accumulate_db(c->gpu, d_db, (int64_t)pos.size(), g.c, nullptr) == 0) job.used += (int64_t)pos.size();
+                if (g.n_hp > 0 && job.kept_bytes + sz <= keep_budget) {
+                    job.kept.push_back(KeptGroup{ids, g, d_db});
+                    job.kept_bytes += sz;
+                    continue;
+                }
+                if (g.n_hp > 0) job.again.insert(job.again.end(), ids.begin(), ids.end());
+            } else if (g.n_hp > 0) {
+                std::vector<uint64_t *> out(pos.size(), nullptr);
+                if (group_hashprints(c->gpu, d_db, pos.size(), g, out.data()))
+                    for (size_t k = 0; k < ids.size(); ++k) {
+                        job.hp[(size_t)ids[k]] = out[k];
+                        job.hp_size[(size_t)ids[k]] = (int)g.n_hp;
+                    }
+            }
+            (void)hipDeviceSynchronize();
+            (void)hipFree(d_db);
+        }
+        at = end;
+    }
+}
 
+static void prepare_accumulate(hpfw_legacy_collector *c, const char **filenames, int n, hpfw_prepare_job &job)
+{
+    if (job.cache_spectros) {
+        std::error_code ec;
+        std::filesystem::create_directories(c->cache_dir + "spectros/", ec);
+    }
+    job.hp.assign((size_t)n, nullptr);
+    job.hp_size.assign((size_t)n, 0);
     std::vector<int> all((size_t)n);
     for (int i = 0; i < n; ++i) all[(size_t)i] = i;
-    pass(all, true);
+    prepare_pass(c, filenames, job, all, true);
+}
+
+// hashprints of the spectrograms kept on the device, then of the files that have to be read again; ok = false:
+// the filters could not be learned -- release what was kept and produce nothing
+static void prepare_finish(hpfw_legacy_collector *c, const char **filenames, hpfw_prepare_job &job, bool ok)
+{
+    (void)hipSetDevice(hpfw_gpu_device(c->gpu));
+    for (KeptGroup &k : job.kept) {
+        std::vector<uint64_t *> out(k.files.size(), nullptr);
+        if (ok && group_hashprints(c->gpu, k.d_db, k.files.size(), k.g, out.data()))
+            for (size_t q = 0; q < k.files.size(); ++q) {
+                job.hp[(size_t)k.files[q]] = out[q];
+                job.hp_size[(size_t)k.files[q]] = (int)k.g.n_hp;
+            }
+        (void)hipFree(k.d_db);
+    }
+    job.kept.clear();
+    if (ok && !job.again.empty()) {
+        std::sort(job.again.begin(), job.again.end());
+        prepare_pass(c, filenames, job, job.again, false);
+    }
+}
+
+static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int n, bool learn, bool cache_spectros,
+                          std::vector<uint64_t *> &hp, std::vector<int> &hp_size)
+{
+    hpfw_prepare_job job;
+    job.learn = learn;
+    job.cache_spectros = cache_spectros;
+    prepare_accumulate(c, filenames, n, job);
     bool failed = false;
     if (learn) {
-        if (used > 0) {
+        if (job.used > 0) {
             c->filters.assign((size_t)HPFW_FILTERS * HPFW_FRAME_SIZE, 0.0f);
             if (hpfw_gpu_learn_filters(c->gpu, c->filters.data()) != 0) {
                 c->filters.clear();
@@ -496,20 +540,10 @@ static bool collect_files(hpfw_legacy_collector *c, const char **filenames, int 
                 par_collector_save(c, nullptr);
             }
         }
-        for (KeptGroup &k : kept) {
-            std::vector<uint64_t *> out(k.files.size(), nullptr);
-            if (!failed && group_hashprints(c->gpu, k.d_db, k.files.size(), k.g, out.data()))
-                for (size_t q = 0; q < k.files.size(); ++q) {
-                    hp[(size_t)k.files[q]] = out[q];
-                    hp_size[(size_t)k.files[q]] = (int)k.g.n_hp;
-                }
-            (void)hipFree(k.d_db);
-        }
-        if (!failed && !again.empty()) {
-            std::sort(again.begin(), again.end());
-            pass(again, false);
-        }
+        prepare_finish(c, filenames, job, !failed);
     }
+    hp.swap(job.hp);
+    hp_size.swap(job.hp_size);
     return !failed;
 }
 
@@ -649,6 +683,107 @@ FilenameHashprintPair *par_collector_prepare(hpfw_legacy_collector *c, const cha
 FilenameHashprintPair *par_collector_calc_hashprints(hpfw_legacy_collector *c, const char **filenames, int n)
 {
     return guarded([&] { return calc_hashprints_impl(c, filenames, n); });
+}
+
+// ---- the halves of prepare() for a multi-GPU host (libhpfw_gpu_multi.so; declared in legacy_internal.h) ----
+hpfw_legacy_collector *hpfw_internal_collector_on_device(int device, const char *cache)
+{
+    auto *c = new hpfw_legacy_collector();
+    if (hpfw_gpu_create(device, &c->gpu) != 0) {
+        delete c;
+        return nullptr;
+    }
+    par_collector_load(c, cache);
+    return c;
+}
+
+hpfw_gpu *hpfw_internal_collector_gpu(hpfw_legacy_collector *c) { return c ? c->gpu : nullptr; }
+
+int hpfw_internal_collector_set_filters(hpfw_legacy_collector *c, const float *f)
+{
+    if (!c || !f) return HPFW_E_INVALID;
+    c->filters.assign(f, f + (size_t)HPFW_FILTERS * HPFW_FRAME_SIZE);
+    return hpfw_gpu_set_filters(c->gpu, f);
+}
+
+hpfw_prepare_job *hpfw_internal_prepare_accumulate(hpfw_legacy_collector *c, const char **filenames, int n, int learn)
+{
+    return guarded([&]() -> hpfw_prepare_job * {
+        if (!c || !filenames || n < 0) return nullptr;
+        auto *job = new hpfw_prepare_job();
+        job->learn = learn != 0;
+        job->cache_spectros = !std::getenv("HPFW_NO_SPECTRO_CACHE");
+        prepare_accumulate(c, filenames, n, *job);
+        return job;
+    });
+}
+
+int64_t hpfw_internal_prepare_used(const hpfw_prepare_job *job) { return job ? job->used : 0; }
+
+// hashprints of the job's files (input order, failed files dropped) [+ with_cached: every other spectrogram of
+// the cache, sorted by name]; consumes the job.  ok = 0: learning failed, release and return NULL.
+FilenameHashprintPair *hpfw_internal_prepare_finish(hpfw_legacy_collector *c, hpfw_prepare_job *job, const char **filenames, int n,
+                                                    int ok, int with_cached, int *got)
+{
+    if (got) *got = 0;
+    FilenameHashprintPair *res = guarded([&]() -> FilenameHashprintPair * {
+        if (!c || !job || !got) return nullptr;
+        if (job->learn || !ok) prepare_finish(c, filenames, *job, ok != 0);
+        if (!ok) return nullptr;
+        std::vector<std::string> stems;
+        std::vector<uint64_t *> r_hp;
+        std::vector<int> r_size;
+        for (int i = 0; i < n; ++i) {
+            if (!job->hp[(size_t)i]) continue;
+            stems.push_back(std::filesystem::path(filenames[i]).stem().string());
+            r_hp.push_back(job->hp[(size_t)i]);
+            r_size.push_back(job->hp_size[(size_t)i]);
+        }
+        if (with_cached && job->cache_spectros) {
+            std::vector<std::string> done;
+            for (int i = 0; i < n; ++i) done.push_back(std::filesystem::path(filenames[i]).stem().string()); // other shards' files too
+            collect_cached(c, done, stems, r_hp, r_size);
+        }
+        auto *out = new FilenameHashprintPair[std::max<size_t>(stems.size(), 1)];
+        for (size_t w = 0; w < stems.size(); ++w) {
+            out[w].filename = new char[stems[w].size() + 1];
+            std::memcpy(out[w].filename, stems[w].c_str(), stems[w].size() + 1);
+            out[w].hashprint = r_hp[w];
+            out[w].hp_size = r_size[w];
+        }
+        *got = (int)stems.size();
+        return out;
+    });
+    delete job;
+    return res;
+}
+
+// the tracks of the cache other than the n named files (whose hashprints the shards have just produced), sorted;
+// consumes the (empty) job
+FilenameHashprintPair *hpfw_internal_prepare_finish_cached(hpfw_legacy_collector *c, hpfw_prepare_job *job, const char **filenames, int n,
+                                                           int *got)
+{
+    if (got) *got = 0;
+    FilenameHashprintPair *res = guarded([&]() -> FilenameHashprintPair * {
+        if (!c || !got) return nullptr;
+        (void)hipSetDevice(hpfw_gpu_device(c->gpu));
+        std::vector<std::string> done, stems;
+        std::vector<uint64_t *> r_hp;
+        std::vector<int> r_size;
+        for (int i = 0; i < n; ++i) done.push_back(std::filesystem::path(filenames[i]).stem().string());
+        collect_cached(c, done, stems, r_hp, r_size);
+        auto *out = new FilenameHashprintPair[std::max<size_t>(stems.size(), 1)];
+        for (size_t w = 0; w < stems.size(); ++w) {
+            out[w].filename = new char[stems[w].size() + 1];
+            std::memcpy(out[w].filename, stems[w].c_str(), stems[w].size() + 1);
+            out[w].hashprint = r_hp[w];
+            out[w].hp_size = r_size[w];
+        }
+        *got = (int)stems.size();
+        return out;
+    });
+    delete job;
+    return res;
 }
 
 void prepare_result_free(FilenameHashprintPair *res, int got)

@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/hpfw_gpu_multi.h"
+#include "legacy_internal.h"
 
 extern "C" void hpfw_internal_set_error(const char *msg); // libhpfw_gpu.so: feeds hpfw_gpu_last_error()
 
@@ -52,6 +53,8 @@ struct Dev {
 } // namespace
 
 struct hpfw_gpu_group {
+    std::vector<hpfw_legacy_collector *> collectors; // one per shard, created by the first load / prepare
+    std::string cache;
     std::vector<Shard> shards;
     std::vector<Dev> devs;
     int per_dev = 1; // shards on every device (uniform)
@@ -216,6 +219,7 @@ void hpfw_gpu_group_destroy(hpfw_gpu_group *g)
         if (d.d_recv) (void)hipFree(d.d_recv);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
+    for (hpfw_legacy_collector *c : g->collectors) par_collector_del(c);
     for (Shard &s : g->shards) {
         if (s.dev_slot < (int)g->devs.size()) (void)hipSetDevice(g->devs[(size_t)s.dev_slot].device);
         if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -360,22 +364,24 @@ int hpfw_gpu_group_cov_accumulate_pcm16(hpfw_gpu_group *g, const int16_t *pcm, i
     });
 }
 
-int hpfw_gpu_group_learn_filters(hpfw_gpu_group *g, float *filters_out)
+// accum_cov summed over the given handles (one per shard, shard order): afterwards every handle holds the total
+// and the total file count.  One in-place ncclAllReduce of 23.4 MB when every shard has its own device.
+static int sum_covariances(hpfw_gpu_group *g, const std::vector<hpfw_gpu *> &hs, int64_t *files_out)
 {
-    if (!g) return fail(HPFW_E_INVALID, "null group");
     const size_t nn = (size_t)HPFW_FRAME_SIZE * HPFW_FRAME_SIZE;
     int64_t files = 0;
-    for (Shard &s : g->shards) files += hpfw_gpu_cov_files(s.h);
+    for (hpfw_gpu *h : hs) files += hpfw_gpu_cov_files(h);
+    *files_out = files;
     if (files == 0) return fail(HPFW_E_INVALID, "no covariance accumulated");
     int rc;
     if (g->per_dev == 1) {
-        // accum_cov is a plain sum over files (parallel_collector.h:93-97): one in-place all-reduce of 23.4 MB
-        std::vector<float *> d_cov(g->shards.size(), nullptr);
-        for (size_t i = 0; i < g->shards.size(); ++i)
-            if ((rc = hpfw_gpu_cov_device(g->shards[i].h, &d_cov[i]))) return rc;
+        // accum_cov is a plain sum over files (parallel_collector.h:93-97)
+        std::vector<float *> d_cov(hs.size(), nullptr);
+        for (size_t i = 0; i < hs.size(); ++i)
+            if ((rc = hpfw_gpu_cov_device(hs[i], &d_cov[i]))) return rc;
         for (Dev &d : g->devs) {
             HIP_OK(hipSetDevice(d.device), "hipSetDevice");
-            HIP_OK(hipDeviceSynchronize(), "covariance kernels"); // the accumulation ran on the handle's own streams
+            HIP_OK(hipDeviceSynchronize(), "covariance kernels"); // the accumulation ran on the handles' own streams
         }
         NCCL_OK(ncclGroupStart(), "ncclGroupStart");
         for (Dev &d : g->devs) {
@@ -392,17 +398,28 @@ int hpfw_gpu_group_learn_filters(hpfw_gpu_group *g, float *filters_out)
             HIP_OK(hipStreamSynchronize(d.stream), "all-reduce");
         }
     } else {
-        // shards that share a device: their matrices are summed on the host (RCCL cannot span them)
+        // shards that share a device: their matrices are summed on the host (RCCL has one rank per device)
         std::vector<float> sum(nn, 0.0f), one(nn);
-        for (Shard &s : g->shards) {
-            if ((rc = hpfw_gpu_cov_get(s.h, one.data(), nullptr))) return rc;
+        for (hpfw_gpu *h : hs) {
+            if ((rc = hpfw_gpu_cov_get(h, one.data(), nullptr))) return rc;
             for (size_t i = 0; i < nn; ++i) sum[i] += one[i];
         }
-        for (Shard &s : g->shards)
-            if ((rc = hpfw_gpu_cov_set(s.h, sum.data(), files))) return rc;
+        for (hpfw_gpu *h : hs)
+            if ((rc = hpfw_gpu_cov_set(h, sum.data(), files))) return rc;
     }
-    for (Shard &s : g->shards)
-        if ((rc = hpfw_gpu_cov_set_files(s.h, files))) return rc;
+    for (hpfw_gpu *h : hs)
+        if ((rc = hpfw_gpu_cov_set_files(h, files))) return rc;
+    return 0;
+}
+
+int hpfw_gpu_group_learn_filters(hpfw_gpu_group *g, float *filters_out)
+{
+    if (!g) return fail(HPFW_E_INVALID, "null group");
+    std::vector<hpfw_gpu *> hs;
+    for (Shard &s : g->shards) hs.push_back(s.h);
+    int64_t files = 0;
+    int rc = sum_covariances(g, hs, &files);
+    if (rc) return rc;
     std::vector<float> f((size_t)HPFW_FILTERS * HPFW_FRAME_SIZE);
     HIP_OK(hipSetDevice(g->devs[(size_t)g->shards[0].dev_slot].device), "hipSetDevice");
     if ((rc = hpfw_gpu_learn_filters(g->shards[0].h, f.data()))) return rc;
@@ -410,6 +427,130 @@ int hpfw_gpu_group_learn_filters(hpfw_gpu_group *g, float *filters_out)
         if ((rc = hpfw_gpu_set_filters(g->shards[i].h, f.data()))) return rc;
     if (filters_out) std::memcpy(filters_out, f.data(), f.size() * 4);
     return 0;
+}
+
+// ---- ParallelCollector over the shards ----------------------------------------------------------------------
+static int ensure_collectors(hpfw_gpu_group *g, const char *cache)
+{
+    if (cache && *cache) g->cache = cache;
+    if (!g->collectors.empty()) return 0;
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        const int dev = g->devs[(size_t)g->shards[i].dev_slot].device;
+        hpfw_legacy_collector *c = hpfw_internal_collector_on_device(dev, g->cache.c_str());
+        if (!c) {
+            for (hpfw_legacy_collector *d : g->collectors) par_collector_del(d);
+            g->collectors.clear();
+            return HPFW_E_HIP; // message set by hpfw_gpu_create
+        }
+        // accum_cov.cereal carries the covariance of earlier runs (the reference keeps accumulating, cache.h:34-36,
+        // live_song_id.h:23-29): it enters the sum once, through shard 0
+        if (i > 0) (void)hpfw_gpu_cov_reset(hpfw_internal_collector_gpu(c));
+        g->collectors.push_back(c);
+    }
+    return 0;
+}
+
+int hpfw_gpu_group_load(hpfw_gpu_group *g, const char *cache)
+{
+    if (!g) return fail(HPFW_E_INVALID, "null group");
+    if (!g->collectors.empty()) { // load again: every shard re-reads the cache
+        if (cache && *cache) g->cache = cache;
+        for (size_t i = 0; i < g->collectors.size(); ++i) {
+            par_collector_load(g->collectors[i], g->cache.c_str());
+            if (i > 0) (void)hpfw_gpu_cov_reset(hpfw_internal_collector_gpu(g->collectors[i]));
+        }
+        return 0;
+    }
+    return ensure_collectors(g, cache);
+}
+
+int hpfw_gpu_group_save(hpfw_gpu_group *g, const char *cache)
+{
+    if (!g) return fail(HPFW_E_INVALID, "null group");
+    if (cache && *cache) g->cache = cache;
+    if (g->collectors.empty()) return 0; // nothing loaded, nothing learned
+    par_collector_save(g->collectors[0], g->cache.c_str());
+    return 0;
+}
+
+FilenameHashprintPair *hpfw_gpu_group_prepare(hpfw_gpu_group *g, const char **filenames, int n, int *got)
+{
+    if (got) *got = 0;
+    if (!g || !filenames || n < 0 || !got) {
+        (void)fail(HPFW_E_INVALID, "bad argument");
+        return nullptr;
+    }
+    if (ensure_collectors(g, nullptr)) return nullptr;
+    const int ns = (int)g->shards.size();
+    const bool learn = !std::getenv("HPFW_PREPARE_KEEP_FILTERS");
+    std::vector<hpfw_prepare_job *> jobs((size_t)ns, nullptr);
+    std::vector<int64_t> lo((size_t)ns), hi((size_t)ns);
+    for (int i = 0; i < ns; ++i) hpfw_gpu_shard_range(n, i, ns, &lo[(size_t)i], &hi[(size_t)i]);
+    // 1. preprocess (parallel_collector.h:82-105) on every shard's block of files
+    int rc = per_shard(g, [&](int i) {
+        jobs[(size_t)i] = hpfw_internal_prepare_accumulate(g->collectors[(size_t)i], filenames + lo[(size_t)i],
+                                                           (int)(hi[(size_t)i] - lo[(size_t)i]), learn ? 1 : 0);
+        return jobs[(size_t)i] ? 0 : (int)HPFW_E_NOMEM;
+    });
+    // 2. one all-reduce of accum_cov, the eigen-solve on shard 0 (:111), the filters to every shard, the cache saved (:61-66)
+    bool ok = rc == 0;
+    if (ok && learn) {
+        std::vector<hpfw_gpu *> hs;
+        for (hpfw_legacy_collector *c : g->collectors) hs.push_back(hpfw_internal_collector_gpu(c));
+        int64_t files = 0, used = 0;
+        for (hpfw_prepare_job *j : jobs) used += hpfw_internal_prepare_used(j);
+        std::vector<float> f((size_t)HPFW_FILTERS * HPFW_FRAME_SIZE);
+        ok = used > 0 && sum_covariances(g, hs, &files) == 0 && hipSetDevice(hpfw_gpu_device(hs[0])) == hipSuccess &&
+             hpfw_gpu_learn_filters(hs[0], f.data()) == 0;
+        for (size_t i = 0; ok && i < g->collectors.size(); ++i) ok = hpfw_internal_collector_set_filters(g->collectors[i], f.data()) == 0;
+        // the total stays on shard 0 only, so that the next prepare() adds every file once
+        for (size_t i = 1; i < hs.size(); ++i) (void)hpfw_gpu_cov_reset(hs[i]);
+        if (ok) par_collector_save(g->collectors[0], g->cache.c_str());
+        if (used == 0) ok = true; // nothing readable: an empty result, as the single collector returns
+    }
+    // 3. collect_fingerprints (:115-137): every shard hashes its own files; shard 0 adds the older tracks of the cache
+    std::vector<FilenameHashprintPair *> part((size_t)ns, nullptr);
+    std::vector<int> part_n((size_t)ns, 0);
+    (void)per_shard(g, [&](int i) {
+        if (jobs[(size_t)i])
+            part[(size_t)i] = hpfw_internal_prepare_finish(g->collectors[(size_t)i], jobs[(size_t)i], filenames + lo[(size_t)i],
+                                                           (int)(hi[(size_t)i] - lo[(size_t)i]), ok ? 1 : 0, 0, &part_n[(size_t)i]);
+        return 0;
+    });
+    FilenameHashprintPair *cached = nullptr;
+    int cached_n = 0;
+    if (ok && !std::getenv("HPFW_NO_SPECTRO_CACHE")) {
+        // older tracks: an accumulate over zero files followed by a finish that walks the cache, told about all n names
+        hpfw_prepare_job *walk = hpfw_internal_prepare_accumulate(g->collectors[0], filenames, 0, 0);
+        if (walk) cached = hpfw_internal_prepare_finish_cached(g->collectors[0], walk, filenames, n, &cached_n);
+    }
+    if (!ok) {
+        for (int i = 0; i < ns; ++i)
+            if (part[(size_t)i]) prepare_result_free(part[(size_t)i], part_n[(size_t)i]);
+        (void)fail(HPFW_E_INVALID, "prepare: the filters could not be learned");
+        return nullptr;
+    }
+    int total = cached_n;
+    for (int i = 0; i < ns; ++i) total += part_n[(size_t)i];
+    auto *res = new FilenameHashprintPair[(size_t)std::max(total, 1)];
+    int w = 0;
+    auto take = [&](FilenameHashprintPair *p, int cnt) {
+        for (int k = 0; k < cnt; ++k) res[w++] = p[k]; // ownership of the strings and hashprints moves
+        delete[] p;
+    };
+    for (int i = 0; i < ns; ++i)
+        if (part[(size_t)i]) take(part[(size_t)i], part_n[(size_t)i]);
+    if (cached) take(cached, cached_n);
+    *got = w;
+    return res;
+}
+
+uint64_t *hpfw_gpu_group_calc_hashprint(hpfw_gpu_group *g, const char *filename, int *size)
+{
+    if (size) *size = 0;
+    if (!g || !filename || !size || ensure_collectors(g, nullptr)) return nullptr;
+    (void)hipSetDevice(g->devs[(size_t)g->shards[0].dev_slot].device);
+    return par_collector_calc_hashprint(g->collectors[0], filename, size);
 }
 
 } // extern "C"

@@ -17,6 +17,7 @@ EXPORTS = (
     "hpfw_gpu_group_extract_pcm16", "hpfw_gpu_group_index_build", "hpfw_gpu_group_index_size",
     "hpfw_gpu_shard_range", "hpfw_gpu_group_search_topk", "hpfw_gpu_group_cov_reset",
     "hpfw_gpu_group_cov_accumulate_pcm16", "hpfw_gpu_group_learn_filters",
+    "hpfw_gpu_group_load", "hpfw_gpu_group_save", "hpfw_gpu_group_prepare", "hpfw_gpu_group_calc_hashprint",
 )
 
 _multi = None
@@ -51,6 +52,12 @@ def lib():
     L.hpfw_gpu_group_cov_reset.argtypes = [vp]
     L.hpfw_gpu_group_cov_accumulate_pcm16.argtypes = [vp, vp, i64, i64]
     L.hpfw_gpu_group_learn_filters.argtypes = [vp, vp]
+    L.hpfw_gpu_group_load.argtypes = [vp, ctypes.c_char_p]
+    L.hpfw_gpu_group_save.argtypes = [vp, ctypes.c_char_p]
+    L.hpfw_gpu_group_prepare.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), i32, ctypes.POINTER(i32)]
+    L.hpfw_gpu_group_prepare.restype = ctypes.POINTER(_lib.FilenameHashprintPair)
+    L.hpfw_gpu_group_calc_hashprint.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(i32)]
+    L.hpfw_gpu_group_calc_hashprint.restype = ctypes.POINTER(ctypes.c_uint64)
     _multi = L
     return L
 
@@ -125,3 +132,34 @@ class GpuGroup:
         f = np.zeros(64 * 2420, np.float32)
         _lib.check(lib().hpfw_gpu_group_learn_filters(self._g, _lib._hp(f)))
         return f
+
+    # ---- ParallelCollector over the shards ------------------------------------------------------------
+    def load(self, cache=""):
+        _lib.check(lib().hpfw_gpu_group_load(self._g, cache.encode("utf-8")))
+
+    def save(self, cache=""):
+        _lib.check(lib().hpfw_gpu_group_save(self._g, cache.encode("utf-8")))
+
+    def prepare(self, filenames):
+        """list of (uint64 array, stem): this call's files in input order, then the older tracks of the cache"""
+        raw = [str(f).encode("utf-8") for f in filenames]
+        names = (ctypes.c_char_p * len(raw))(*raw)
+        got = ctypes.c_int(0)
+        res = lib().hpfw_gpu_group_prepare(self._g, names, len(raw), ctypes.byref(got))
+        if not res:
+            raise _lib.HpfwError("group prepare failed: " + _lib.lib().hpfw_gpu_last_error().decode())
+        out = []
+        for i in range(got.value):
+            a = np.ctypeslib.as_array(res[i].hashprint, shape=(res[i].hp_size,)).astype(np.uint64).copy()
+            out.append((a, res[i].filename.decode("utf-8")))
+        _lib.lib().prepare_result_free(res, got)
+        return out
+
+    def calc_hashprint(self, filename):
+        size = ctypes.c_int(0)
+        hp = lib().hpfw_gpu_group_calc_hashprint(self._g, str(filename).encode("utf-8"), ctypes.byref(size))
+        if not hp:
+            raise _lib.HpfwError("group calc_hashprint failed: " + _lib.lib().hpfw_gpu_last_error().decode())
+        a = np.ctypeslib.as_array(hp, shape=(size.value,)).astype(np.uint64).copy()
+        _lib.lib().calc_hashprint_result_free(hp)
+        return a

@@ -79,6 +79,7 @@ const char *hpfw_gpu_version(void);
 
 int hpfw_gpu_create(int device, hpfw_gpu **out);
 void hpfw_gpu_destroy(hpfw_gpu *h);
+int hpfw_gpu_device(const hpfw_gpu *h); /* the device ordinal the handle was created on */
 
 /* filters = ParallelCollector::filters (parallel_collector.h:77), host pointer, 64 x 2420 floats */
 int hpfw_gpu_set_filters(hpfw_gpu *h, const float *filters_colmajor);

@@ -79,6 +79,20 @@ int hpfw_gpu_group_cov_reset(hpfw_gpu_group *g);
 int hpfw_gpu_group_cov_accumulate_pcm16(hpfw_gpu_group *g, const int16_t *pcm, int64_t n_samples, int64_t n_clips);
 int hpfw_gpu_group_learn_filters(hpfw_gpu_group *g, float *filters_colmajor_out);
 
+/* ---- ParallelCollector over the shards (parallel_collector.h:48-73): index() end to end on the node's GPUs ----
+ * prepare: the files are sharded contiguously; every shard (its own host thread, collector and device) reads its
+ * files, computes their spectrograms (cached under <cache>/spectros/ as cache.h:30-33 does) and adds their frame
+ * covariances to its accum_cov; ONE ncclAllReduce sums accum_cov over the devices; shard 0 solves for the filters
+ * and writes filters.cereal / accum_cov.cereal; every shard then hashes the spectrograms it kept on its device.
+ * Results: this call's files in input order (failed files dropped, :101-103), then every other track of the
+ * cache, sorted (collect_fingerprints walks the whole cache, :115-137); release with prepare_result_free.
+ * HPFW_PREPARE_KEEP_FILTERS=1 keeps loaded filters instead of learning.  cache: NULL / "" = "cache/". */
+int hpfw_gpu_group_load(hpfw_gpu_group *g, const char *cache);  /* ParallelCollector::load on every shard */
+int hpfw_gpu_group_save(hpfw_gpu_group *g, const char *cache);  /* ParallelCollector::save (shard 0 holds accum_cov) */
+FilenameHashprintPair *hpfw_gpu_group_prepare(hpfw_gpu_group *g, const char **filenames, int n, int *got);
+/* calc_hashprint (parallel_collector.h:54-59) on shard 0; release with calc_hashprint_result_free */
+uint64_t *hpfw_gpu_group_calc_hashprint(hpfw_gpu_group *g, const char *filename, int *size);
+
 #ifdef __cplusplus
 }
 #endif

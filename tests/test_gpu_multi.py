@@ -109,15 +109,70 @@ def test_cpp_sharded_live_song_identification(torch_cuda, filters, tmp_path):
         synth.write_wav(p, pcm)
         queries.append(p)
     outs = {}
-    for name, env in (("live_id", {}), ("live_id_multi", {"HPFW_GPU_DEVICES": "0,0,0"})):
-        work = tmp_path / ("run_" + name)
+    for name, env, extra in (("live_id", {}, []), ("live_id_multi", {"HPFW_GPU_DEVICES": "0,0,0"}, []),
+                             ("live_id_multi", {"HPFW_GPU_DEVICES": "0,0"}, ["--one-collector"])):
+        work = tmp_path / ("run_" + name + "_".join(extra))
         os.makedirs(str(work / "cache"))
         with open(str(work / "cache" / "filters.cereal"), "wb") as f:
             f.write(np.array([64, 2420], np.int32).tobytes() + np.ascontiguousarray(filters, np.float32).tobytes())
-        r = subprocess.run([exes[name], "--index"] + tracks + ["--search"] + queries, cwd=str(work), capture_output=True,
+        r = subprocess.run([exes[name]] + extra + ["--index"] + tracks + ["--search"] + queries, cwd=str(work), capture_output=True,
                            text=True, timeout=300, env=dict(os.environ, HPFW_PREPARE_KEEP_FILTERS="1", **env))
         assert r.returncode == 0, r.stdout + r.stderr
-        outs[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("=> ")]
+        outs[name + "".join(extra)] = [ln for ln in r.stdout.splitlines() if ln.startswith("=> ")]
         if name == "live_id_multi":
-            assert "shards: 3" in r.stderr
-    assert outs["live_id"] == outs["live_id_multi"] and outs["live_id"][-1] == "=> 0 1"
+            assert ("shards: 2" if extra else "shards: 3") in r.stderr
+    assert outs["live_id"] == outs["live_id_multi"] == outs["live_id_multi--one-collector"] and outs["live_id"][-1] == "=> 0 1"
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_group_prepare_learns_over_shards(torch_cuda, oracle, tmp_path, devices):
+    """ParallelCollector::prepare over the shards (hpfw_gpu_group_prepare): files sharded per device, covariance summed
+    (ncclAllReduce, or on the host when shards share a device), filters solved once, every shard hashes its own files;
+    a second call adds tracks and returns every track of the cache"""
+    secs = [3.0, 4.0, 3.0, 3.5, 3.0, 5.0, 3.0]
+    clips = [synth.gen_clip(850 + i, s) for i, s in enumerate(secs)]
+    paths = []
+    for i, c in enumerate(clips):
+        p = str(tmp_path / f"song{i}.wav")
+        synth.write_wav(p, c)
+        paths.append(p)
+    bad = str(tmp_path / "missing.wav")
+    cache = str(tmp_path / "cache") + "/"
+    g = multi.GpuGroup(devices)
+    g.load(cache)                                             # nothing there yet
+    res = g.prepare(paths[:3] + [bad] + paths[3:5])
+    assert [n for _, n in res] == [f"song{i}" for i in range(5)]
+    filt = np.frombuffer(open(os.path.join(cache, "filters.cereal"), "rb").read()[8:], np.float32)
+    for (hp, _), c in zip(res, clips[:5]):
+        assert np.array_equal(hp, oracle.Plan(c.size).extract(filt, c))
+    assert sorted(os.listdir(os.path.join(cache, "spectros"))) == [f"song{i}" for i in range(5)]
+    # the covariance in the cache is the sum over the five readable files, whatever the sharding
+    one = hpfw_amd.Gpu(0)
+    for c in clips[:5]:
+        one.cov_accumulate(c[None, :])
+    cov, _ = one.cov_get()
+    rawc = np.frombuffer(open(os.path.join(cache, "accum_cov.cereal"), "rb").read()[8:], np.float32).reshape(2420, 2420)
+    assert np.abs(cov - rawc).max() <= 2e-5 * np.abs(cov).max()
+    if len(devices) == 1:                                     # one shard: the single collector's bits
+        pc = hpfw_amd.ParallelCollector()
+        cache1 = str(tmp_path / "cache1") + "/"
+        pc.load(cache1)
+        ref = pc.prepare(paths[:5])
+        assert all(np.array_equal(a[0], b[0]) for a, b in zip(res, ref))
+    assert np.array_equal(g.calc_hashprint(paths[1]), res[1][0])
+    g.close()
+    g2 = multi.GpuGroup(devices)                              # "a new process" adds two tracks
+    g2.load(cache)
+    res2 = g2.prepare(paths[5:])
+    assert [n for _, n in res2] == ["song5", "song6"] + [f"song{i}" for i in range(5)]
+    filt2 = np.frombuffer(open(os.path.join(cache, "filters.cereal"), "rb").read()[8:], np.float32)
+    by_name = {n: hp for hp, n in res2}
+    for i, c in enumerate(clips):
+        assert np.array_equal(by_name[f"song{i}"], oracle.Plan(c.size).extract(filt2, c)), i
+    for c in clips[5:]:
+        one.cov_accumulate(c[None, :])
+    cov2, _ = one.cov_get()
+    rawc2 = np.frombuffer(open(os.path.join(cache, "accum_cov.cereal"), "rb").read()[8:], np.float32).reshape(2420, 2420)
+    assert np.abs(cov2 - rawc2).max() <= 2e-5 * np.abs(cov2).max()
+    one.close()
+    g2.close()
