@@ -41,17 +41,27 @@ struct RowsArgs {
 constexpr int group_twiddle_count(int r1, int r2) { return (r1 - 1) * r2 + (r2 - 1); }
 
 // one fused group of the forward DIF at sub-length len: radix R1, then radix R2 (or 1), in place
-template <int R1, int R2, class Lds>
-HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int len, int tid, int nthreads)
+// N2C, LENC: the transform length and the sub-length when the group sequence is fixed at compile time (0 = taken
+// from the arguments at run time): every LDS address is then the thread's base plus an immediate offset, no
+// address or 1 / m2 is computed or kept in registers, and the loop over butterflies disappears when the workgroup
+// holds at least one thread per butterfly.
+template <int R1, int R2, int N2C = 0, int LENC = 0, class Lds>
+HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int len_rt, int tid, int nthreads)
 {
-    const int n = a.n2;
+    const int n = N2C ? N2C : a.n2;
+    const int len = LENC ? LENC : len_rt;
     const int m1 = len / R1, m2 = m1 / R2;
     const int nb = n / (R1 * R2);
     const float inv_m2 = 1.0f / (float)m2;
     for (int b = tid; b < nb; b += nthreads) {
-        int blk = (int)((float)b * inv_m2);
-        if (blk * m2 > b) --blk;
-        if ((blk + 1) * m2 <= b) ++blk;
+        int blk;
+        if constexpr (N2C != 0) {
+            blk = b / m2; // a constant divisor: multiply and shift
+        } else {
+            blk = (int)((float)b * inv_m2);
+            if (blk * m2 > b) --blk;
+            if ((blk + 1) * m2 <= b) ++blk;
+        }
         const int j0 = b - blk * m2;
         const int base = blk * len + j0;
         const cf *__restrict__ tb = gt + b;
@@ -89,10 +99,11 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
 // j0 of the next group's block b' = blk R1 R2 + s R2 + s2 (in place: position b' m2 + j0) goes to
 // j0 (n / m2) + b'.  The last group, whose thread b owns block b, then reads with its lanes on
 // consecutive addresses instead of m2 complex apart (8-way bank conflicts for m2 = 20).
-template <int R1, int R2, class Lds>
-HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int len, int tid, cf *out)
+template <int R1, int R2, int N2C = 0, int LENC = 0, class Lds>
+HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int len_rt, int tid, cf *out)
 {
-    const int n = a.n2;
+    const int n = N2C ? N2C : a.n2;
+    const int len = LENC ? LENC : len_rt;
     const int m1 = len / R1, m2 = m1 / R2;
     const int nb = n / (R1 * R2);
     if (tid >= nb) return;
@@ -126,10 +137,11 @@ HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restr
     }
 }
 
-template <int R1, int R2, class Lds>
-HPFW_DEVICE void rows_pre_store(Lds &lds, const RowsArgs &a, int len, int tid, const cf *out)
+template <int R1, int R2, int N2C = 0, int LENC = 0, class Lds>
+HPFW_DEVICE void rows_pre_store(Lds &lds, const RowsArgs &a, int len_rt, int tid, const cf *out)
 {
-    const int n = a.n2;
+    const int n = N2C ? N2C : a.n2;
+    const int len = LENC ? LENC : len_rt;
     const int m2 = len / (R1 * R2);
     const int nb = n / (R1 * R2);
     if (tid >= nb) return;
@@ -143,10 +155,10 @@ HPFW_DEVICE void rows_pre_store(Lds &lds, const RowsArgs &a, int len, int tid, c
 // around a barrier: compute from element e of block b at e nb + b into registers; then store output
 // f = s + R1 s2 of the block -- frequency k2 = kb_last[b] + nb f -- at lds[k2]: natural order, so the
 // Hermitian split reads lds[k2] and lds[n2 - k2] on consecutive lanes and needs no position table.
-template <int R1, int R2, class Lds>
+template <int R1, int R2, int N2C = 0, class Lds>
 HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int tid, cf *out)
 {
-    const int nb = a.n2 / (R1 * R2);
+    const int nb = (N2C ? N2C : a.n2) / (R1 * R2);
     if (tid >= nb) return;
     const cf *__restrict__ tb = gt + tid;
     cf e[R1][R2];
@@ -176,10 +188,10 @@ HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__rest
     }
 }
 
-template <int R1, int R2, class Lds>
+template <int R1, int R2, int N2C = 0, class Lds>
 HPFW_DEVICE void rows_last_store(Lds &lds, const RowsArgs &a, int tid, const cf *out)
 {
-    const int nb = a.n2 / (R1 * R2);
+    const int nb = (N2C ? N2C : a.n2) / (R1 * R2);
     if (tid >= nb) return;
     const int k0 = a.kb_last[tid];
 #pragma unroll
@@ -207,6 +219,7 @@ HPFW_DEVICE void rows_group_r2(Lds &lds, const RowsArgs &a, const cf *gt, int le
 // The group sequence either comes from the plan at run time (any 7-smooth n2) ...
 struct RuntimeGroups {
     static constexpr bool kNatural = false; // outputs stay at their digit-reversed positions
+    static constexpr int kProduct = 0;      // the transform length is a run-time value
     template <class Lds>
     HPFW_DEVICE_STATIC void run(Lds &lds, const RowsArgs &a, int nthreads)
     {
@@ -263,39 +276,42 @@ struct StaticGroups<R1, R2, Rest...> {
             return StaticGroups<Rest...>::min_threads(n2);
         }
     }
-    template <class Lds>
-    HPFW_DEVICE_STATIC void run_from(Lds &lds, const RowsArgs &a, int nthreads, int len, int g)
+    // N2 = the product of the whole list, LEN = the sub-length this group starts from: both known at compile time
+    template <int N2, int LEN, class Lds>
+    HPFW_DEVICE_STATIC void run_from(Lds &lds, const RowsArgs &a, int nthreads, int g)
     {
         const cf *gt = a.gtw + a.groups.tw_off[g];
         if constexpr (sizeof...(Rest) == 0) {
             HPFW_CARRY(cf, outv, R1 * R2, nthreads);
-            HPFW_FOR_THREADS(tid, nthreads) { rows_last_compute<R1, R2>(lds, a, gt, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
+            HPFW_FOR_THREADS(tid, nthreads) { rows_last_compute<R1, R2, N2>(lds, a, gt, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
-            HPFW_FOR_THREADS(tid, nthreads) { rows_last_store<R1, R2>(lds, a, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
+            HPFW_FOR_THREADS(tid, nthreads) { rows_last_store<R1, R2, N2>(lds, a, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
         } else if constexpr (sizeof...(Rest) == 2) {
             HPFW_CARRY(cf, outv, R1 * R2, nthreads);
-            HPFW_FOR_THREADS(tid, nthreads) { rows_pre_compute<R1, R2>(lds, a, gt, len, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
+            HPFW_FOR_THREADS(tid, nthreads) { rows_pre_compute<R1, R2, N2, LEN>(lds, a, gt, LEN, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
-            HPFW_FOR_THREADS(tid, nthreads) { rows_pre_store<R1, R2>(lds, a, len, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
+            HPFW_FOR_THREADS(tid, nthreads) { rows_pre_store<R1, R2, N2, LEN>(lds, a, LEN, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
-            StaticGroups<Rest...>::run_from(lds, a, nthreads, len / (R1 * R2), g + 1);
+            StaticGroups<Rest...>::template run_from<N2, LEN / (R1 * R2)>(lds, a, nthreads, g + 1);
         } else {
-            HPFW_FOR_THREADS(tid, nthreads) { rows_group<R1, R2>(lds, a, gt, len, tid, nthreads); }
+            HPFW_FOR_THREADS(tid, nthreads) { rows_group<R1, R2, N2, LEN>(lds, a, gt, LEN, tid, nthreads); }
             HPFW_BARRIER();
-            StaticGroups<Rest...>::run_from(lds, a, nthreads, len / (R1 * R2), g + 1);
+            StaticGroups<Rest...>::template run_from<N2, LEN / (R1 * R2)>(lds, a, nthreads, g + 1);
         }
     }
     template <class Lds>
     HPFW_DEVICE_STATIC void run(Lds &lds, const RowsArgs &a, int nthreads)
     {
         static_assert(sizeof...(Rest) >= 2, "the transposed layout needs a group before the last");
-        run_from(lds, a, nthreads, a.n2, 0);
+        run_from<kProduct, kProduct>(lds, a, nthreads, 0); // the launcher checked a.n2 == kProduct (matches())
     }
     static bool matches(const RowGroups &g, int i, int n)
     {
         return i < n && g.r1[i] == R1 && g.r2[i] == R2 && StaticGroups<Rest...>::matches(g, i + 1, n);
     }
+    // the whole list against a plan: same groups, hence the same product
+    static bool matches_plan(const RowsArgs &a) { return matches(a.groups, 0, a.groups.n) && a.n2 == kProduct; }
 };
 
 // n2 = 6300 = 7 3 5 3 5 4: every clip length that is a multiple of 1/7 s at 44.1 kHz up to 50 s
@@ -319,7 +335,10 @@ template <class Groups, class Lds, class Load>
 HPFW_DEVICE void rows_body_from(Lds &lds, const RowsArgs &a, int nthreads, const Load &load, int a0,
                                 float *__restrict__ ya, float *__restrict__ yb)
 {
-    const int n2 = a.n2;
+    // a compile-time group sequence knows its length: loop bounds and the half-spectrum size become constants
+    const int n2 = Groups::kProduct ? Groups::kProduct : a.n2;
+    const int h = Groups::kProduct ? Groups::kProduct / 2 + 1 : a.h;
+    const int hpad = Groups::kProduct ? (Groups::kProduct / 2 + 1 + 31) / 32 * 32 : a.hpad;
     HPFW_FOR_THREADS(tid, nthreads)
     {
         // loads in batches of kLd so that their latencies overlap
@@ -342,20 +361,20 @@ HPFW_DEVICE void rows_body_from(Lds &lds, const RowsArgs &a, int nthreads, const
     Groups::run(lds, a, nthreads);
     // Hermitian split + twiddle.  The table reads (digit-reversal positions, T_N rows) of kEpi outputs
     // are issued together before any store, so their latencies overlap instead of adding up.
-    const cf *__restrict__ twa = a.tw_big + (int64_t)a0 * a.h;
-    const cf *__restrict__ twb = yb ? twa + a.h : twa;
+    const cf *__restrict__ twa = a.tw_big + (int64_t)a0 * h;
+    const cf *__restrict__ twb = yb ? twa + h : twa;
     const int *__restrict__ pos = a.pos_n2;
     constexpr bool kNat = Groups::kNatural;
     constexpr int kEpi = 9;
     HPFW_FOR_THREADS(tid, nthreads)
     {
-        for (int k0 = tid; k0 < a.h; k0 += kEpi * nthreads) {
+        for (int k0 = tid; k0 < h; k0 += kEpi * nthreads) {
             int pk[kEpi], pm[kEpi];
             cf wa[kEpi], wb[kEpi];
 #pragma unroll
             for (int e = 0; e < kEpi; ++e) {
                 const int k2 = k0 + e * nthreads;
-                const int kk = k2 < a.h ? k2 : 0;
+                const int kk = k2 < h ? k2 : 0;
                 pk[e] = kNat ? kk : pos[kk];
                 pm[e] = kNat ? (kk == 0 ? 0 : n2 - kk) : pos[kk == 0 ? 0 : n2 - kk];
                 wa[e] = twa[kk];
@@ -364,18 +383,18 @@ HPFW_DEVICE void rows_body_from(Lds &lds, const RowsArgs &a, int nthreads, const
 #pragma unroll
             for (int e = 0; e < kEpi; ++e) {
                 const int k2 = k0 + e * nthreads;
-                if (k2 < a.h) {
+                if (k2 < h) {
                     const cf zk = lds[pk[e]];
                     const cf zm = lds[pm[e]];
                     const cf va = {0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
                     const cf vb = {0.5f * (zk.i + zm.i), 0.5f * (zm.r - zk.r)};
                     const cf oa = c_mul(va, wa[e]);
                     ya[k2] = oa.r;
-                    ya[a.hpad + k2] = oa.i;
+                    ya[hpad + k2] = oa.i;
                     if (yb) {
                         const cf ob = c_mul(vb, wb[e]);
                         yb[k2] = ob.r;
-                        yb[a.hpad + k2] = ob.i;
+                        yb[hpad + k2] = ob.i;
                     }
                 }
             }

@@ -13,6 +13,8 @@
 //              the N/2 bins feed the 121 bands): a dense [4 K1 x 2 n1] . [2 n1 x h] real contraction on
 //              v_mfma_f32_32x32x2_f32.  The MFMA chains its k index in ascending order, which is the
 //              specification's fma chain over residues (Re then Im part of each), bit for bit.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace hpfw {
@@ -68,8 +70,9 @@ __global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int64_t n_val
 // 512 threads x 128 VGPRs and 50 KB of LDS: two workgroups per CU, every pass one butterfly per thread.
 constexpr int kFwdThreads = 512;
 
-template <class Groups>
-__global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, const i16x2 *__restrict__ pairs,
+// WAVES: waves per SIMD the register allocation is held to (4: two workgroups per CU; 6: three)
+template <class Groups, int WAVES>
+__global__ __launch_bounds__(kFwdThreads, WAVES) void fwd_rows_kernel(RowsArgs a, const i16x2 *__restrict__ pairs,
                                                                   int64_t clip_pitch, int pair_pitch,
                                                                   float *__restrict__ yp)
 {
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void fwd_rows_kernel(RowsArgs a, co
     const int a0 = 2 * p;
     float *ya = yp + ((int64_t)clip * 2 * a.n1 + 2 * a0) * a.hpad;
     float *yb = (a0 + 1 < a.n1) ? ya + 2 * (int64_t)a.hpad : nullptr;
-    rows_body<Groups>(lds, a, (int)blockDim.x, pairs + clip * clip_pitch + (int64_t)p * pair_pitch, a0, ya, yb);
+    rows_body<Groups>(lds, a, kFwdThreads, pairs + clip * clip_pitch + (int64_t)p * pair_pitch, a0, ya, yb);
 }
 
 // ---- column DFT on the matrix cores --------------------------------------------------------
@@ -203,12 +206,12 @@ void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_cli
 
 size_t fwd_rows_lds_bytes(const RowsArgs &a) { return (size_t)a.n2 * sizeof(cf); }
 
-template <class Groups>
+template <class Groups, int WAVES>
 static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, float *d_yp, hipStream_t s)
 {
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_rows_kernel<Groups>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_rows_kernel<Groups, WAVES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set.mark();
     }
@@ -216,7 +219,7 @@ static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, 
     // pre-passed stream: [clip][pair][n2]; in place: pair p of time step t at pcm word t n1/2 + p
     const int64_t clip_pitch = a.pair_stride == 1 ? (int64_t)((a.n1 + 1) / 2) * a.n2 : (int64_t)a.n1 * a.n2 / 2;
     const int pair_pitch = a.pair_stride == 1 ? a.n2 : 1;
-    hipLaunchKernelGGL(fwd_rows_kernel<Groups>, grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, d_pairs,
+    hipLaunchKernelGGL((fwd_rows_kernel<Groups, WAVES>), grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, d_pairs,
                        clip_pitch, pair_pitch, d_yp);
 }
 
@@ -225,10 +228,15 @@ static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, 
 void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_src, int n_clips, float *d_yp, hipStream_t s)
 {
     // the compile-time sequence runs its last two groups one butterfly per thread
-    if (Groups6300::matches(a.groups, 0, a.groups.n) && Groups6300::min_threads(a.n2) <= kFwdThreads)
-        launch_rows_t<Groups6300>(a, d_src, n_clips, d_yp, s);
-    else
-        launch_rows_t<RuntimeGroups>(a, d_src, n_clips, d_yp, s);
+    static const int waves = std::getenv("HPFW_ROWS_WAVES") ? std::atoi(std::getenv("HPFW_ROWS_WAVES")) : 4;
+    if (Groups6300::matches_plan(a) && Groups6300::min_threads(a.n2) <= kFwdThreads) {
+        if (waves == 6)
+            launch_rows_t<Groups6300, 6>(a, d_src, n_clips, d_yp, s);
+        else
+            launch_rows_t<Groups6300, 4>(a, d_src, n_clips, d_yp, s);
+    } else {
+        launch_rows_t<RuntimeGroups, 4>(a, d_src, n_clips, d_yp, s);
+    }
 }
 
 template <int STEP>
