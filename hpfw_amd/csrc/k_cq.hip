@@ -43,7 +43,7 @@ __global__ __launch_bounds__(cq_threads(NP)) void cq_kernel(CqPlanDev cp, CqClas
     const int clip = blockIdx.y;
     const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[j] - cp.kmin);
     float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
-    cq_band_body<NP>(lds, red, (int)blockDim.x, xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
+    cq_band_body<NP>(lds, red, cq_threads(NP), xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
                        [](float m) { return DBT ? db_term(m * m) : m; });
     // wave maximum -> wavemax[clip][band][wave]: plain stores (clipmax_kernel reduces them); one
     // atomicMax per wave on a per-clip word cost 0.4 ms per 1000 clips in contention

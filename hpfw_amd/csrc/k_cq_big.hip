@@ -114,7 +114,8 @@ __global__ __launch_bounds__(cq_big_threads(LEN0)) void cq_big_local_kernel(int 
 {
     using S = Size<LEN0>;
     cf *lds = reinterpret_cast<cf *>(smem_raw);
-    const int tid = threadIdx.x, nthreads = (int)blockDim.x;
+    const int tid = threadIdx.x;
+    constexpr int nthreads = cq_big_threads(LEN0);
     const int blk = blockIdx.x, bi = blockIdx.y, clip = blockIdx.z;
     cf *w = work + (int64_t)clip * work_clip_pitch + (int64_t)bi * p + (int64_t)blk * LEN0;
     for (int i = tid; i < LEN0; i += nthreads) lds[pad16(i)] = w[i];

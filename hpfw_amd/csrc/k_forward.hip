@@ -13,8 +13,6 @@
 //              the N/2 bins feed the 121 bands): a dense [4 K1 x 2 n1] . [2 n1 x h] real contraction on
 //              v_mfma_f32_32x32x2_f32.  The MFMA chains its k index in ascending order, which is the
 //              specification's fma chain over residues (Re then Im part of each), bit for bit.
-#include <cstdlib>
-
 #include "kernels.h"
 
 namespace hpfw {
@@ -51,17 +49,33 @@ __global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int64_t n_val
     __syncthreads();
     i16x2 *dst = pairs + (int64_t)clip * np * n2 + t0;
     const bool even = (n1 & 1) == 0; // then a pair is one aligned 32-bit word of the tile
-    for (int i = tid; i < np * kPairsTile; i += 256) {
-        const int p = i / kPairsTile, tt = i - p * kPairsTile;
+    // the tile length is a power of two: a thread keeps its time step and walks the pairs (no division per word)
+    const int lg = 31 - __builtin_clz((unsigned)kPairsTile);
+    const int tt = tid & (kPairsTile - 1), pstep = 256 >> lg;
+    if (pstep >= 1) {
         if (tt < nt) {
-            i16x2 v;
-            if (even) {
-                v = *reinterpret_cast<const i16x2 *>(tile + tt * n1 + 2 * p);
-            } else {
-                v.x = tile[tt * n1 + 2 * p];
-                v.y = (2 * p + 1 < n1) ? tile[tt * n1 + 2 * p + 1] : (short)0;
+            const int16_t *row = tile + tt * n1;
+            i16x2 *out = dst + tt;
+            for (int p = tid >> lg; p < np; p += pstep) {
+                i16x2 v;
+                if (even) {
+                    v = *reinterpret_cast<const i16x2 *>(row + 2 * p);
+                } else {
+                    v.x = row[2 * p];
+                    v.y = (2 * p + 1 < n1) ? row[2 * p + 1] : (short)0;
+                }
+                out[(int64_t)p * n2] = v;
             }
-            dst[(int64_t)p * n2 + tt] = v;
+        }
+    } else { // a tile longer than the workgroup (not produced by the launcher): the general walk
+        for (int i = tid; i < np * kPairsTile; i += 256) {
+            const int p = i >> lg, t2 = i & (kPairsTile - 1);
+            if (t2 < nt) {
+                i16x2 v;
+                v.x = tile[t2 * n1 + 2 * p];
+                v.y = (2 * p + 1 < n1) ? tile[t2 * n1 + 2 * p + 1] : (short)0;
+                dst[(int64_t)p * n2 + t2] = v;
+            }
         }
     }
 }
@@ -228,15 +242,12 @@ static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, 
 void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_src, int n_clips, float *d_yp, hipStream_t s)
 {
     // the compile-time sequence runs its last two groups one butterfly per thread
-    static const int waves = std::getenv("HPFW_ROWS_WAVES") ? std::atoi(std::getenv("HPFW_ROWS_WAVES")) : 4;
-    if (Groups6300::matches_plan(a) && Groups6300::min_threads(a.n2) <= kFwdThreads) {
-        if (waves == 6)
-            launch_rows_t<Groups6300, 6>(a, d_src, n_clips, d_yp, s);
-        else
-            launch_rows_t<Groups6300, 4>(a, d_src, n_clips, d_yp, s);
-    } else {
+    // 4 waves per SIMD (two workgroups per CU): held to 6 (80 VGPRs, three workgroups) the static kernel measured
+    // slower, 4.42 against 4.17 ms for pairs + rows per 1000 clips
+    if (Groups6300::matches_plan(a) && Groups6300::min_threads(a.n2) <= kFwdThreads)
+        launch_rows_t<Groups6300, 4>(a, d_src, n_clips, d_yp, s);
+    else
         launch_rows_t<RuntimeGroups, 4>(a, d_src, n_clips, d_yp, s);
-    }
 }
 
 template <int STEP>
