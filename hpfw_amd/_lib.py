@@ -34,6 +34,7 @@ EXPORTS = (
     "hpfw_gpu_search_votes", "hpfw_gpu_knn_windows", "hpfw_gpu_supported_length",
     "hpfw_gpu_mel_frames", "hpfw_gpu_mel_spectrogram_pcm16", "hpfw_gpu_mel_spectrogram_pcm16_host",
     "hpfw_gpu_cfg_set_filters", "hpfw_gpu_cfg_hashprints", "hpfw_gpu_mel_hashprints_pcm16_host",
+    "hpfw_gpu_cfg_cov_reset", "hpfw_gpu_cfg_cov_accumulate", "hpfw_gpu_cfg_cov_get", "hpfw_gpu_cfg_learn_filters",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
@@ -121,6 +122,10 @@ def lib():
     L.hpfw_gpu_cfg_set_filters.argtypes = [vp, ctypes.POINTER(HandleConfig), vp]
     L.hpfw_gpu_cfg_hashprints.argtypes = [vp, ctypes.POINTER(HandleConfig), vp, vp, i64, i64, vp, i64, vp, vp]
     L.hpfw_gpu_mel_hashprints_pcm16_host.argtypes = [vp, vp, i64, i64, vp, i64, vp]
+    L.hpfw_gpu_cfg_cov_reset.argtypes = [vp, ctypes.POINTER(HandleConfig)]
+    L.hpfw_gpu_cfg_cov_accumulate.argtypes = [vp, ctypes.POINTER(HandleConfig), vp, vp, i64, i64, vp]
+    L.hpfw_gpu_cfg_cov_get.argtypes = [vp, ctypes.POINTER(HandleConfig), vp, ctypes.POINTER(i64)]
+    L.hpfw_gpu_cfg_learn_filters.argtypes = [vp, ctypes.POINTER(HandleConfig), vp]
     L.hpfw_gpu_supported_length.argtypes = [i64]
     L.hpfw_gpu_supported_length.restype = i64
     L.hpfw_gpu_search_votes.argtypes = [vp, vp, vp, i64, vp]
@@ -256,6 +261,24 @@ class Gpu:
         c = HandleConfig(*cfg)
         check(lib().hpfw_gpu_cfg_hashprints(self._h, ctypes.byref(c), d_s, d_cols, n_clips, stride, d_hp, hp_stride,
                                             d_proj, stream))
+
+    def cfg_cov_reset(self, cfg):
+        check(lib().hpfw_gpu_cfg_cov_reset(self._h, ctypes.byref(HandleConfig(*cfg))))
+
+    def cfg_cov_accumulate_dev(self, cfg, d_s, d_cols, n_clips, stride, stream=0):
+        check(lib().hpfw_gpu_cfg_cov_accumulate(self._h, ctypes.byref(HandleConfig(*cfg)), d_s, d_cols, n_clips, stride, stream))
+
+    def cfg_cov_get(self, cfg):
+        kt = cfg[0] * cfg[1]
+        cov = np.zeros((kt, kt), np.float32)
+        n = ctypes.c_int64(0)
+        check(lib().hpfw_gpu_cfg_cov_get(self._h, ctypes.byref(HandleConfig(*cfg)), _hp(cov), ctypes.byref(n)))
+        return cov, int(n.value)
+
+    def cfg_learn_filters(self, cfg):
+        f = np.zeros(cfg[3] * cfg[0] * cfg[1], np.float32)
+        check(lib().hpfw_gpu_cfg_learn_filters(self._h, ctypes.byref(HandleConfig(*cfg)), _hp(f)))
+        return f
 
     def mel_hashprints(self, pcm):
         """the combiner's Algo (combiner.h:12) on host PCM [n_clips][n]: list of uint16 hashprint arrays"""

@@ -151,6 +151,14 @@ struct hpfw_gpu {
     std::map<std::vector<int>, float *> cfg_fpack;
     float *d_cfg_proj = nullptr;
     size_t cfg_proj_cap = 0;
+    struct CfgCov {
+        float *d_accum = nullptr;
+        int *d_tiles = nullptr;
+        int64_t clips = 0;
+    };
+    std::map<std::vector<int>, CfgCov> cfg_cov; // accum_cov of other configurations, by (rows, context)
+    float *d_cfg_cov_ws = nullptr;
+    size_t cfg_cov_ws_cap = 0;
     // ordering of consecutive entry points that were handed different streams (the workspaces are shared)
     hipEvent_t order_ev = nullptr;
     hipStream_t order_stream = nullptr;
@@ -559,6 +567,11 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
     for (auto &kv : h->cfg_fpack) (void)hipFree(kv.second);
     if (h->d_cfg_proj) (void)hipFree(h->d_cfg_proj);
+    for (auto &kv : h->cfg_cov) {
+        if (kv.second.d_accum) (void)hipFree(kv.second.d_accum);
+        if (kv.second.d_tiles) (void)hipFree(kv.second.d_tiles);
+    }
+    if (h->d_cfg_cov_ws) (void)hipFree(h->d_cfg_cov_ws);
     if (h->d_db) (void)hipFree(h->d_db);
     if (h->d_db_off) (void)hipFree(h->d_db_off);
     if (h->d_best) (void)hipFree(h->d_best);
@@ -984,6 +997,104 @@ int hpfw_gpu_cfg_hashprints(hpfw_gpu *h, const hpfw_handle_config *c, const floa
         }
         if ((rc = check_launch("pack_cfg"))) return rc;
     }
+    return 0;
+}
+
+static int cfg_cov_slot(hpfw_gpu *h, const hpfw_handle_config *c, hpfw_gpu::CfgCov **out)
+{
+    const int kt = c->rows * c->context;
+    hpfw_gpu::CfgCov &cc = h->cfg_cov[{c->rows, c->context}];
+    if (!cc.d_accum) {
+        HIP_TRY(hipMalloc((void **)&cc.d_accum, (size_t)kt * kt * 4));
+        HIP_TRY(hipMemset(cc.d_accum, 0, (size_t)kt * kt * 4));
+        std::vector<int> xy((size_t)2 * hpfw::cov_cfg_tile_count(kt));
+        hpfw::cov_cfg_tile_list(kt, xy.data());
+        HIP_TRY(hipMalloc((void **)&cc.d_tiles, xy.size() * 4));
+        HIP_TRY(hipMemcpy(cc.d_tiles, xy.data(), xy.size() * 4, hipMemcpyHostToDevice));
+        cc.clips = 0;
+    }
+    *out = &cc;
+    return 0;
+}
+
+int hpfw_gpu_cfg_cov_reset(hpfw_gpu *h, const hpfw_handle_config *c)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    int rc = cfg_check(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    auto it = h->cfg_cov.find({c->rows, c->context});
+    if (it == h->cfg_cov.end()) return 0;
+    Ordered ordered(h, nullptr);
+    const int kt = c->rows * c->context;
+    HIP_TRY(hipMemset(it->second.d_accum, 0, (size_t)kt * kt * 4));
+    it->second.clips = 0;
+    return 0;
+}
+
+int hpfw_gpu_cfg_cov_accumulate(hpfw_gpu *h, const hpfw_handle_config *c, const float *d_s, const int32_t *d_cols, int64_t n_clips,
+                                int64_t stride, void *stream)
+{
+    if (!h || !d_s || n_clips < 0 || stride < 1) return fail(HPFW_E_INVALID, "bad argument");
+    int rc = cfg_check(c);
+    if (rc) return rc;
+    const hpfw::CfgArgs a{c->rows, c->context, c->lag, c->bits, nullptr};
+    if (!hpfw::cov_cfg_supported(a)) return fail(HPFW_E_UNSUPPORTED, "covariance: context below 9 is not supported");
+    HIP_TRY(hipSetDevice(h->device));
+    hpfw_gpu::CfgCov *cc;
+    if ((rc = cfg_cov_slot(h, c, &cc))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
+    const int64_t chunk = 512; // clips per pass: bounds the partial tiles and the per-clip sums
+    if ((rc = ensure((void **)&h->d_cfg_cov_ws, &h->cfg_cov_ws_cap,
+                     hpfw::cov_cfg_workspace_bytes(a, (int)std::min(chunk, std::max<int64_t>(n_clips, 1))))))
+        return rc;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += chunk) {
+        const int nb = (int)std::min(chunk, n_clips - c0);
+        hpfw::launch_cov_cfg(a, d_s + c0 * c->rows * stride, d_cols ? d_cols + c0 : nullptr, nb, stride, cc->d_tiles,
+                             h->d_cfg_cov_ws, cc->d_accum, s);
+        if ((rc = check_launch("cov_cfg"))) return rc;
+    }
+    cc->clips += n_clips;
+    return 0;
+}
+
+int hpfw_gpu_cfg_cov_get(hpfw_gpu *h, const hpfw_handle_config *c, float *cov, int64_t *n_clips)
+{
+    if (!h || !cov) return fail(HPFW_E_INVALID, "null argument");
+    int rc = cfg_check(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nn = (size_t)c->rows * c->context * c->rows * c->context;
+    auto it = h->cfg_cov.find({c->rows, c->context});
+    if (it == h->cfg_cov.end()) {
+        std::memset(cov, 0, nn * 4);
+        if (n_clips) *n_clips = 0;
+        return 0;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cov, it->second.d_accum, nn * 4, hipMemcpyDeviceToHost));
+    if (n_clips) *n_clips = it->second.clips;
+    return 0;
+}
+
+int hpfw_gpu_cfg_learn_filters(hpfw_gpu *h, const hpfw_handle_config *c, float *filters_out)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    int rc = cfg_check(c);
+    if (rc) return rc;
+    const int kt = c->rows * c->context;
+    std::vector<float> cov((size_t)kt * kt);
+    int64_t clips = 0;
+    if ((rc = hpfw_gpu_cfg_cov_get(h, c, cov.data(), &clips))) return rc;
+    if (clips == 0) return fail(HPFW_E_INVALID, "no covariance accumulated for this configuration");
+    std::vector<float> rows((size_t)c->bits * kt);
+    if (hpfw::top_eigenvectors(cov.data(), kt, c->bits, rows.data(), nullptr) != 0) return fail(HPFW_E_INVALID, "eigen-solve failed");
+    std::vector<float> colmajor((size_t)c->bits * kt);
+    for (int r = 0; r < c->bits; ++r)
+        for (int k = 0; k < kt; ++k) colmajor[(size_t)r + (size_t)c->bits * k] = rows[(size_t)r * kt + k];
+    if ((rc = hpfw_gpu_cfg_set_filters(h, c, colmajor.data()))) return rc;
+    if (filters_out) std::memcpy(filters_out, colmajor.data(), colmajor.size() * 4);
     return 0;
 }
 

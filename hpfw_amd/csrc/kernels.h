@@ -132,6 +132,14 @@ void launch_project_cfg(const CfgArgs &a, const float *d_s, const int *d_cols, i
 void launch_pack_cfg(const CfgArgs &a, const float *d_proj, const int *d_cols, int n_clips, int64_t stride, int64_t proj_stride,
                      void *d_hp, int64_t hp_stride, hipStream_t s);
 
+// calc_cov + accumulate for such a configuration (k_cov_cfg.hip): accum [kt][kt], kt = rows * context, both triangles
+bool cov_cfg_supported(const CfgArgs &a);
+int cov_cfg_tile_count(int kt);
+void cov_cfg_tile_list(int kt, int *xy /* 2 * cov_cfg_tile_count(kt) */);
+size_t cov_cfg_workspace_bytes(const CfgArgs &a, int n_clips);
+void launch_cov_cfg(const CfgArgs &a, const float *d_s, const int *d_cols, int n_clips, int64_t stride, const int *d_tiles,
+                    float *d_ws, float *d_accum, hipStream_t s);
+
 // ---- filter learning (index() only) -------------------------------------------------------
 // accum [2420][2420] (tiles on or above the diagonal) += sum over clips of centred^T centred / (nf - 1),
 // by lag correlations (k_cov.hip); d_ws: cov_workspace_bytes(n_clips, c) of scratch

@@ -166,6 +166,16 @@ int hpfw_gpu_cfg_set_filters(hpfw_gpu *h, const hpfw_handle_config *cfg, const f
  * d_proj (optional, NULL to skip): the projection filters * frames [n_clips][bits][stride - context + 1]. */
 int hpfw_gpu_cfg_hashprints(hpfw_gpu *h, const hpfw_handle_config *cfg, const float *d_s, const int32_t *d_cols,
                             int64_t n_clips, int64_t stride, void *d_hp, int64_t hp_stride, float *d_proj, void *stream);
+/* filter learning for such a configuration: calc_cov of every clip's frames (hashprint_handle.h:96-102: centred on the
+ * clip's own frame means, / (n_frames - 1); clips with fewer than two frames add nothing) accumulated on the GPU as
+ * ParallelCollector::preprocess does (parallel_collector.h:93-97), then calc_filters (hashprint_handle.h:105-112) on the
+ * host: the `bits` leading eigenvectors become the configuration's filters.  d_s / d_cols / stride as above.
+ * cov: host, [rows * context][rows * context].  context >= 9. */
+int hpfw_gpu_cfg_cov_reset(hpfw_gpu *h, const hpfw_handle_config *cfg);
+int hpfw_gpu_cfg_cov_accumulate(hpfw_gpu *h, const hpfw_handle_config *cfg, const float *d_s, const int32_t *d_cols,
+                                int64_t n_clips, int64_t stride, void *stream);
+int hpfw_gpu_cfg_cov_get(hpfw_gpu *h, const hpfw_handle_config *cfg, float *cov, int64_t *n_clips);
+int hpfw_gpu_cfg_learn_filters(hpfw_gpu *h, const hpfw_handle_config *cfg, float *filters_colmajor_out);
 /* the combiner's Algo end to end on host buffers: MelSpectrogram<44100, 33, 4410, 441>::spectrogram (mel.h:34-104)
  * + HashprintHandle<uint16_t, Mel, 32, 50>: hp [n_clips][hp_stride] (hp_stride >= hpfw_gpu_mel_frames(n) - 81),
  * n_hp [n_clips] the number of hashprints of each clip (0 when too few frames are left after the silent ones) */

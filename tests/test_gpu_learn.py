@@ -192,3 +192,61 @@ def test_spectrogram_cache_and_incremental_indexing(torch_cuda, oracle, tmp_path
     finally:
         del os.environ["HPFW_NO_SPECTRO_CACHE"]
     assert [n for _, n in third] == ["trk0"]
+
+
+def test_covariance_and_filters_of_the_combiner_configuration(torch_cuda, oracle):
+    """f3: calc_cov + accumulate + calc_filters (hashprint_handle.h:96-112, parallel_collector.h:93-97) for
+    HashprintHandle<uint16_t, MelSpectrogram<>, 32, 50> (frames of 33 x 32 = 1056 values): the covariance summed over
+    clips of ragged widths against float64 numpy; the 16 learned filters against the leading eigenvectors; hashprints
+    under the learned filters identical to the oracle's"""
+    torch = torch_cuda
+    cfg = hpfw_amd.COMBINER_CONFIG
+    rows, ctx, lag, bits = cfg
+    rng = np.random.default_rng(33)
+    stride = 420
+    cols = np.array([420, 300, 33, 32, 10, 157], np.int32)          # 33: two frames; 32: one frame (adds nothing); 10: none
+    base = rng.uniform(-70, -5, (len(cols), rows, 1)).astype(np.float32)
+    s = (base + np.cumsum(rng.standard_normal((len(cols), rows, stride)).astype(np.float32), axis=2) * 1.5).astype(np.float32)
+    g = hpfw_amd.Gpu(0)
+    d_s = torch.from_numpy(s).cuda()
+    d_cols = torch.from_numpy(cols).cuda()
+    g.cfg_cov_accumulate_dev(cfg, d_s.data_ptr(), d_cols.data_ptr(), 3, stride)
+    g.cfg_cov_accumulate_dev(cfg, d_s[3:].data_ptr(), d_cols[3:].data_ptr(), 3, stride)    # accumulates across calls
+    cov, n = g.cfg_cov_get(cfg)
+    assert n == 6
+    want = np.zeros((rows * ctx, rows * ctx))
+    for i, c in enumerate(cols):
+        nf = c - ctx + 1
+        if nf < 2:
+            continue
+        x = np.stack([s[i, k // ctx, (k % ctx):(k % ctx) + nf] for k in range(rows * ctx)]).astype(np.float64)
+        xc = x - x.mean(axis=1, keepdims=True)
+        want += xc @ xc.T / (nf - 1)
+    assert np.abs(cov - want).max() <= 5e-5 * np.abs(want).max()
+    assert np.array_equal(cov, cov.T)
+    filt = g.cfg_learn_filters(cfg)                               # column-major [16][1056]
+    f_rows = filt.reshape(rows * ctx, bits).T.astype(np.float64)
+    w, v = np.linalg.eigh(want)
+    w, v = w[::-1], v[:, ::-1]
+    ray = np.einsum("rk,kl,rl->r", f_rows, want, f_rows)
+    assert np.abs(ray - w[:bits]).max() / w[0] < 1e-4
+    assert np.abs(f_rows @ f_rows.T - np.eye(bits)).max() < 1e-4
+    nf = stride - ctx + 1
+    d_hp = torch.zeros((len(cols), nf - lag), dtype=torch.int16, device="cuda")
+    g.cfg_hashprints_dev(cfg, d_s.data_ptr(), d_cols.data_ptr(), len(cols), stride, d_hp.data_ptr(), nf - lag)
+    torch.cuda.synchronize()
+    hp = d_hp.cpu().numpy().view(np.uint16)
+    for i, c in enumerate(cols):
+        want_hp = oracle.hashprints_cfg(filt, s[i][:, :c], ctx, lag, bits).astype(np.uint16)
+        assert np.array_equal(hp[i][:want_hp.size], want_hp), i
+    g.cfg_cov_reset(cfg)
+    assert g.cfg_cov_get(cfg)[1] == 0 and not g.cfg_cov_get(cfg)[0].any()
+    # the same kernels on the live-id configuration (121 x 20) agree with the lag-correlation kernels of k_cov.hip
+    s2 = rng.uniform(-80, 0, (2, 121, 260)).astype(np.float32)
+    d_s2 = torch.from_numpy(s2).cuda()
+    g.cfg_cov_accumulate_dev((121, 20, 80, 64), d_s2.data_ptr(), 0, 2, 260)
+    g.cov_accumulate_db_dev(d_s2.data_ptr(), 2, 260)
+    a, _ = g.cfg_cov_get((121, 20, 80, 64))
+    b, _ = g.cov_get()
+    assert np.abs(a - b).max() <= 5e-5 * np.abs(b).max()
+    g.close()

@@ -11,6 +11,16 @@ import hpfw_amd  # noqa: E402
 from hpfw_amd import synth  # noqa: E402
 from oracle import oracle  # noqa: E402
 
+def _factors(m):
+    out, f = [], 2
+    while m > 1:
+        while m % f == 0:
+            out.append(f)
+            m //= f
+        f += 1
+    return out
+
+
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 filt = synth.make_filters()
@@ -19,7 +29,11 @@ g.set_filters(filt)
 bad = 0
 t0 = time.time()
 for r in range(rounds):
-    n = hpfw_amd.supported_length(int(rng.integers(60000, 44100 * 75)))
+    if r % 2 == 0:   # a 7-smooth length (mixed-radix forward transform), 1.4 s to 75 s
+        smooth = [m for m in range(10, 526) if all(p in (2, 3, 5, 7) for p in _factors(m))]
+        n = 6300 * int(rng.choice(smooth))
+    else:            # any length (almost surely with a prime factor above 7: the chirp-z forward transform); the
+        n = int(rng.integers(60000, 44100 * 20))   # oracle's dense column DFT costs n1^2, so these stay below 20 s
     nb = int(rng.integers(1, 5))
     g.set_batch(int(rng.integers(1, 4)))
     clips = np.stack([synth.gen_clip(int(rng.integers(1, 1 << 30)), n / 44100.0)[:n] for _ in range(nb)])
