@@ -120,7 +120,10 @@ public:
 
     /// storage.h:67-75: the cereal BinaryOutputArchive image of std::vector<FilenameFingerprintPair>
     /// (parallel_collector.h:26-35): u64 count, then per entry u64 length + bytes of the filename and
-    /// u64 length + that many u64 hashprints.  A dump written by the reference loads here and vice versa.
+    /// u64 length + that many u64 hashprints.  The FORMAT is the reference's: a dump written by either side loads on
+    /// the other.  Whether queries hashed on one side match a database hashed on the other is a separate question:
+    /// it needs the same filters.cereal and as far as essentia's unverifiable conventions agree (INTEGRATION.md,
+    /// "What a switch changes"; hpfw_gpu_set_conventions).
     auto save(const std::optional<std::string> &filename) const -> std::string
     {
         const auto dump_name = filename.value_or("db/dump.cereal");
