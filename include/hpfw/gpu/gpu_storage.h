@@ -7,6 +7,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <fstream>
 #include <limits>
 #include <optional>
@@ -27,9 +28,12 @@ public:
         int64_t offset;
     };
 
-    GpuStorage()
+    /// the device: HPFW_GPU_DEVICE (the collector reads the same variable), default 0; ShardedGpuStorage
+    /// (sharded_storage.h) is the storage over several devices
+    GpuStorage() : GpuStorage(env_device()) {}
+    explicit GpuStorage(int device)
     {
-        if (hpfw_gpu_create(0, &h_) != 0) throw std::runtime_error(std::string("hpfw::db::GpuStorage: ") + hpfw_gpu_last_error());
+        if (hpfw_gpu_create(device, &h_) != 0) throw std::runtime_error(std::string("hpfw::db::GpuStorage: ") + hpfw_gpu_last_error());
     }
     ~GpuStorage() { hpfw_gpu_destroy(h_); }
     GpuStorage(const GpuStorage &) = delete;
@@ -167,6 +171,11 @@ public:
     }
 
 private:
+    static int env_device()
+    {
+        const char *e = std::getenv("HPFW_GPU_DEVICE");
+        return e ? std::atoi(e) : 0;
+    }
     static void put(std::ostream &os, uint64_t v) { os.write(reinterpret_cast<const char *>(&v), 8); }
     static uint64_t get(std::istream &is, const std::string &name)
     {
