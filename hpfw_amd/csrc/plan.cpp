@@ -275,17 +275,22 @@ struct DftPlanD {
         for (int q = 0; q < p; ++q)
             rec(level + 1, ir + q * st, ii + q * st, st * p, tr + q * m, ti + q * m, outr + q * m, outi + q * m);
         const double *wr = twr[level].data(), *wi = twi[level].data();
-        for (int64_t k = 0; k < n; ++k) {
-            const int64_t km = k % m;
+        // X[k] = F_0[k mod m] + sum_q W_n^{qk} F_q[k mod m]; the indices k mod m and q k mod n are carried along
+        // instead of divided out (the values, and so every rounding, are those of the plain formula)
+        int64_t jq[32]; // q k mod n for q = 1 .. p - 1 (p <= 31)
+        for (int q = 1; q < p; ++q) jq[q] = 0;
+        for (int64_t k = 0, km = 0; k < n; ++k) {
             double ar = tr[km], ai = ti[km];
             for (int q = 1; q < p; ++q) {
-                const int64_t j = (q * k) % n;
+                const int64_t j = jq[q];
                 const double fr = tr[q * m + km], fi = ti[q * m + km];
                 ar = ar + (wr[j] * fr - wi[j] * fi);
                 ai = ai + (wr[j] * fi + wi[j] * fr);
+                jq[q] = j + q >= n ? j + q - n : j + q;
             }
             outr[k] = ar;
             outi[k] = ai;
+            if (++km == m) km = 0;
         }
     }
     // in place on re / im [n]; scratch: 2 n doubles each
@@ -314,38 +319,43 @@ static void build_bluestein_tables(HostPlan &p)
     const int64_t n = p.n, n1 = p.n1, n2 = p.n2, big_l = p.bz_l, nk = p.kmax - p.kmin;
     auto chirp = [&](int64_t m, double &re, double &im) { // w[m] = e^{-i pi m^2 / N} = T_{2N}[m^2 mod 2N]
         const int64_t mm = m < 0 ? -m : m;
-        twiddle_d((int64_t)(((__int128)mm * mm) % (2 * n)), 2 * n, re, im);
+        // m^2 mod 2N exactly: in 64 bits while m^2 fits (|m| < 3.03e9), in 128 bits beyond
+        const int64_t r = mm < 3037000499ll ? (mm * mm) % (2 * n) : (int64_t)(((__int128)mm * mm) % (2 * n));
+        twiddle_d(r, 2 * n, re, im);
     };
+    // w in double for n in [0, N): the chirp table, w[k] / L and the lags b[m] = conj(w[|m|]) all take their values here
+    // (every lag has |m| < N), so each phase is evaluated once
+    std::vector<double> wd_r((size_t)n), wd_i((size_t)n);
+    parallel_rows((n + 65535) / 65536, [&](int64_t blk) {
+        for (int64_t i = blk * 65536, e = std::min<int64_t>(n, (blk + 1) * 65536); i < e; ++i) chirp(i, wd_r[(size_t)i], wd_i[(size_t)i]);
+    });
     p.bz_w.assign((size_t)big_l, HostCf{0.0f, 0.0f});
     p.bz_tl.resize((size_t)big_l);
     parallel_rows(n1, [&](int64_t r) {
         for (int64_t t = 0; t < n2; ++t) {
             const int64_t idx = r + n1 * t;
-            if (idx < n) {
-                double c, s;
-                chirp(idx, c, s);
-                p.bz_w[(size_t)(r * n2 + t)] = {(float)c, (float)s};
-            }
-            p.bz_tl[(size_t)(r * n2 + t)] = twiddle_f(r * t, big_l);
+            if (idx < n) p.bz_w[(size_t)(r * n2 + t)] = {(float)wd_r[(size_t)idx], (float)wd_i[(size_t)idx]};
         }
     });
     p.bz_wk.resize((size_t)nk);
-    for (int64_t k = p.kmin; k < p.kmax; ++k) {
-        double c, s;
-        chirp(k, c, s);
-        p.bz_wk[(size_t)(k - p.kmin)] = {(float)(c / (double)big_l), (float)(s / (double)big_l)};
-    }
+    for (int64_t k = p.kmin; k < p.kmax; ++k)
+        p.bz_wk[(size_t)(k - p.kmin)] = {(float)(wd_r[(size_t)k] / (double)big_l), (float)(wd_i[(size_t)k] / (double)big_l)};
     // Bhat = DFT_L(b), b[m mod L] = conj(w[m]) for the lags m in [kmin - (N - 1), kmax - 1], in double:
     // rows (length n2 over t for every residue r), times W_L^{r k2}, columns (length n1 over r for every k2)
     std::vector<double> yr((size_t)big_l, 0.0), yi((size_t)big_l, 0.0); // [r][t], then [r][k2]
     const int64_t mlo = p.kmin - (n - 1), mhi = p.kmax - 1;
-    for (int64_t m = mlo; m <= mhi; ++m) {
-        const int64_t idx = ((m % big_l) + big_l) % big_l;
-        double c, s;
-        chirp(m, c, s);
-        yr[(size_t)((idx % n1) * n2 + idx / n1)] = c;
-        yi[(size_t)((idx % n1) * n2 + idx / n1)] = -s;
+    {
+        const int64_t count = mhi - mlo + 1, blk = 1 << 16; // every lag has its own slot: blocks of lags side by side
+        parallel_rows((count + blk - 1) / blk, [&](int64_t b) {
+            for (int64_t m = mlo + b * blk, e = std::min(mhi + 1, mlo + (b + 1) * blk); m < e; ++m) {
+                const int64_t idx = ((m % big_l) + big_l) % big_l, mm = m < 0 ? -m : m;
+                yr[(size_t)((idx % n1) * n2 + idx / n1)] = wd_r[(size_t)mm];
+                yi[(size_t)((idx % n1) * n2 + idx / n1)] = -wd_i[(size_t)mm];
+            }
+        });
     }
+    std::vector<double>().swap(wd_r);
+    std::vector<double>().swap(wd_i);
     const DftPlanD rows_plan(n2), cols_plan(n1);
     parallel_rows(n1, [&](int64_t r) {
         std::vector<double> scratch;
@@ -353,21 +363,28 @@ static void build_bluestein_tables(HostPlan &p)
         rows_plan.run(re, im, scratch);
         for (int64_t k2 = 0; k2 < n2; ++k2) {
             double wr, wi;
-            twiddle_d((r * k2) % big_l, big_l, wr, wi);
+            twiddle_d((r * k2) % big_l, big_l, wr, wi); // W_L^{r k2}: in double for Bhat, rounded for the device's T_L table
+            p.bz_tl[(size_t)(r * n2 + k2)] = {(float)wr, (float)wi};
             const double gr = re[k2], gi = im[k2];
             re[k2] = gr * wr - gi * wi;
             im[k2] = gr * wi + gi * wr;
         }
     });
     p.bz_bhat.resize((size_t)big_l);
-    parallel_rows(n2, [&](int64_t k2) {
-        std::vector<double> scratch, cr((size_t)n1), ci((size_t)n1);
-        for (int64_t r = 0; r < n1; ++r) {
-            cr[(size_t)r] = yr[(size_t)(r * n2 + k2)];
-            ci[(size_t)r] = yi[(size_t)(r * n2 + k2)];
-        }
-        cols_plan.run(cr.data(), ci.data(), scratch);
-        for (int64_t k1 = 0; k1 < n1; ++k1) p.bz_bhat[(size_t)(k1 * n2 + k2)] = {(float)cr[(size_t)k1], (float)ci[(size_t)k1]};
+    // columns in blocks of 8: a cache line of eight doubles of every row feeds eight column transforms
+    constexpr int64_t kCb = 8;
+    parallel_rows((n2 + kCb - 1) / kCb, [&](int64_t cb) {
+        const int64_t k0 = cb * kCb, nc = std::min(kCb, n2 - k0);
+        std::vector<double> scratch, cr((size_t)(kCb * n1)), ci((size_t)(kCb * n1));
+        for (int64_t r = 0; r < n1; ++r)
+            for (int64_t c = 0; c < nc; ++c) {
+                cr[(size_t)(c * n1 + r)] = yr[(size_t)(r * n2 + k0 + c)];
+                ci[(size_t)(c * n1 + r)] = yi[(size_t)(r * n2 + k0 + c)];
+            }
+        for (int64_t c = 0; c < nc; ++c) cols_plan.run(cr.data() + c * n1, ci.data() + c * n1, scratch);
+        for (int64_t k1 = 0; k1 < n1; ++k1)
+            for (int64_t c = 0; c < nc; ++c)
+                p.bz_bhat[(size_t)(k1 * n2 + k0 + c)] = {(float)cr[(size_t)(c * n1 + k1)], (float)ci[(size_t)(c * n1 + k1)]};
     });
 }
 
