@@ -292,8 +292,14 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         if ((rc = upload(p.bz_bhat, reinterpret_cast<const hpfw::HostCf **>(&bz.bhat), dp->owned))) return rc;
         if ((rc = upload(p.bz_wk, reinterpret_cast<const hpfw::HostCf **>(&bz.wk), dp->owned))) return rc;
         std::vector<float> apack((size_t)p.n1 * bz.n_tiles * 64);
-        hpfw::pack_bz_coefficients(p.n1, reinterpret_cast<const float *>(p.tw_n1.data()), bz.n_tiles, apack.data());
+        hpfw::pack_bz_coefficients(p.n1, 0, p.n1, reinterpret_cast<const float *>(p.tw_n1.data()), bz.n_tiles, apack.data());
         if ((rc = upload(apack, &bz.apack, dp->owned))) return rc;
+        bz.k1lo = p.kmin / p.n2;
+        bz.k1n = (p.kmax - 1) / p.n2 - bz.k1lo + 1;
+        bz.n_tiles2 = ((2 * bz.k1n + 31) / 32 + 2) / 3 * 3;
+        std::vector<float> apack2((size_t)p.n1 * bz.n_tiles2 * 64);
+        hpfw::pack_bz_coefficients(p.n1, bz.k1lo, bz.k1n, reinterpret_cast<const float *>(p.tw_n1.data()), bz.n_tiles2, apack2.data());
+        if ((rc = upload(apack2, &bz.apack2, dp->owned))) return rc;
     }
     // column DFT: coefficient image for the MFMA A operand
     hpfw::ColsArgs &ca = dp->cols;
@@ -428,17 +434,23 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
             hpfw::launch_bz_rows_first(dp->rows, dp->bz, (const hpfw::i16x2 *)h->ws[5], nb, yp, s);
         }
         if ((rc = check_launch("bz_rows"))) return rc;
+        float *other = (float *)h->ws[6];
         {
             Timed t(h, K_COLS, s);
-            hpfw::launch_bz_cols(dp->bz, 0, yp, (float *)h->ws[6], nb, s);
-            hpfw::launch_bz_cols(dp->bz, 1, (const float *)h->ws[6], yp, nb, s);
+            hpfw::launch_bz_cols_full(dp->bz, yp, other, nb, s); // Y' -> C [k1][k2]
         }
         if ((rc = check_launch("bz_cols"))) return rc;
         {
             Timed t(h, K_ROWS, s);
-            hpfw::launch_bz_rows_last(dp->rows, dp->bz, yp, nb, x, s);
+            hpfw::launch_bz_transpose(dp->bz, other, yp, nb, s);            // C -> C' [r][t]
+            hpfw::launch_bz_rows_second(dp->rows, dp->bz, yp, nb, other, s); // C' -> Y''
         }
-        return check_launch("bz_rows");
+        if ((rc = check_launch("bz_rows"))) return rc;
+        {
+            Timed t(h, K_COLS, s);
+            hpfw::launch_bz_cols_last(dp->bz, other, nb, x, s);
+        }
+        return check_launch("bz_cols");
     }
     {
         Timed t(h, K_ROWS, s);

@@ -9,12 +9,13 @@
 // dense DFT on the matrix cores and does not care about n1's factors):
 //   pcm_pairs    (k_forward.hip) PCM -> residue streams, zeros beyond N
 //   bz_rows<0>   per residue r: a[r + n1 t] = x w, FFT_n2 in LDS, times T_L[r k2]           -> Y'  planar
-//   bz_cols<0>   A[n2 k1 + k2] = sum_r T_n1[r k1] Y'[r][k2] (f32 MFMA), C = conj(A Bhat)     -> C   planar
-//   bz_cols<1>   D[k1][j2] = sum_j1 T_n1[j1 k1] C[j1][j2] (f32 MFMA), times T_L[j2 k1]       -> E   planar
-//   bz_rows<1>   per k1: FFT_n2 over j2 in LDS: F[k1 + n1 k2]; X[k] = conj(F[k]) w[k] / L for the consumed bins
-// The second transform runs columns first so that the first one's output tile (k1 rows, k2 columns) is its
-// input tile as it stands: no transposition between the two.  Arithmetic order = the oracle's, bit for bit:
-// MFMA chains its k index (Re then Im part of each residue) in ascending order (S6).
+//   bz_cols<0>   A[n2 k1 + k2] = sum_r T_n1[r k1] Y'[r][k2] (f32 MFMA, all n1 rows), C = conj(A Bhat) -> C planar [k1][k2]
+//   bz_transpose the flat index j = n2 k1 + k2 = r + n1 t regrouped by residue                  -> C' planar [r][t]
+//   bz_rows<1>   per residue r: FFT_n2 over t in LDS, times T_L[r k2]                          -> Y'' planar
+//   bz_cols<1>   F[n2 k1 + k2] = sum_r T_n1[r k1] Y''[r][k2] for the rows k1 that hold consumed bins only (about a
+//                tenth of them, as in fwd_cols); X[k] = conj(F[k]) w[k] / L
+// Only the first transform's column stage is a full n1 x n1 contraction.  Arithmetic order = the oracle's, bit for
+// bit: MFMA chains its k index (Re then Im part of each residue) in ascending order (S6).
 #include "kernels.h"
 
 namespace hpfw {
@@ -25,14 +26,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBzThreads = 512;
 
-// MODE 0: first transform's rows; MODE 1: second transform's rows
+// MODE 0: first transform's rows (input x w from the pair streams); MODE 1: second transform's rows (input C', planar)
 template <int MODE>
 __global__ __launch_bounds__(kBzThreads, 4) void bz_rows_kernel(RowsArgs a, BzArgs bz, const i16x2 *__restrict__ pairs,
-                                                                const float *__restrict__ in, float *__restrict__ out,
-                                                                cf *__restrict__ x)
+                                                                const float *__restrict__ in, float *__restrict__ out)
 {
     cf *lds = reinterpret_cast<cf *>(smem_raw);
-    const int row = blockIdx.y; // residue r (MODE 0) or output residue k1 (MODE 1)
+    const int row = blockIdx.y; // the residue r of the flat index r + n1 t (of the samples, or of C)
     const int clip = blockIdx.x;
     const int n2 = a.n2, nthreads = kBzThreads, tid = threadIdx.x;
     const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad; // floats per clip of a planar buffer
@@ -66,25 +66,43 @@ __global__ __launch_bounds__(kBzThreads, 4) void bz_rows_kernel(RowsArgs a, BzAr
     }
     __syncthreads();
     Groups6300::run(lds, a, nthreads); // outputs in natural order
-    if (MODE == 0) {
-        const cf *__restrict__ tl = bz.tl + (int64_t)row * n2;
-        float *__restrict__ ore = out + clip * plane + (int64_t)2 * row * bz.n2pad;
-        float *__restrict__ oim = ore + bz.n2pad;
-        for (int k2 = tid; k2 < n2; k2 += nthreads) {
-            const cf o = c_mul(lds[k2], tl[k2]);
-            ore[k2] = o.r;
-            oim[k2] = o.i;
+    // both transforms: times T_L[row k2], planar rows (2 row, 2 row + 1) of the output
+    const cf *__restrict__ tl = bz.tl + (int64_t)row * n2;
+    float *__restrict__ ore = out + clip * plane + (int64_t)2 * row * bz.n2pad;
+    float *__restrict__ oim = ore + bz.n2pad;
+    for (int k2 = tid; k2 < n2; k2 += nthreads) {
+        const cf o = c_mul(lds[k2], tl[k2]);
+        ore[k2] = o.r;
+        oim[k2] = o.i;
+    }
+}
+
+// C [k1][k2] (planar, n2pad columns) -> C' [r][t] (the same planar shape) with n2 k1 + k2 = r + n1 t: a workgroup takes
+// the flat range of T time steps t (T n1 consecutive flat elements: coalesced reads), one plane at a time through
+// LDS, and writes for every residue its T values side by side.
+__global__ __launch_bounds__(256) void bz_transpose_kernel(BzArgs bz, int tsteps, const float *__restrict__ in, float *__restrict__ out)
+{
+    float *tile = reinterpret_cast<float *>(smem_raw); // [tsteps][n1]
+    const int clip = blockIdx.y, t0 = blockIdx.x * tsteps;
+    const int nt = min(tsteps, bz.n2 - t0);
+    const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad;
+    const int64_t j0 = (int64_t)bz.n1 * t0;
+    const int count = bz.n1 * nt;
+    for (int part = 0; part < 2; ++part) { // Re plane, then Im plane
+        const float *src = in + clip * plane + (int64_t)part * bz.n2pad;
+        for (int i = threadIdx.x; i < count; i += 256) {
+            const int64_t j = j0 + i;
+            const int k1 = (int)(j / bz.n2), k2 = (int)(j - (int64_t)k1 * bz.n2);
+            tile[i] = src[(int64_t)2 * k1 * bz.n2pad + k2];
         }
-    } else {
-        // bins k = row + n1 k2 inside [kmin, kmax)
-        const int lo = bz.kmin > row ? (bz.kmin - row + bz.n1 - 1) / bz.n1 : 0;
-        const int hi = bz.kmax > row ? (bz.kmax - 1 - row) / bz.n1 : -1; // inclusive
-        cf *__restrict__ xo = x + (int64_t)clip * (bz.kmax - bz.kmin);
-        for (int k2 = lo + tid; k2 <= hi && k2 < n2; k2 += nthreads) {
-            const int k = row + bz.n1 * k2;
-            const cf f = lds[k2];
-            xo[k - bz.kmin] = c_mul(cf{f.r, -f.i}, bz.wk[k - bz.kmin]);
+        __syncthreads();
+        float *dst = out + clip * plane + (int64_t)part * bz.n2pad + t0;
+        // thread -> (residue, time step) with the time step fastest: runs of nt floats per residue
+        for (int i = threadIdx.x; i < count; i += 256) {
+            const int r = i / nt, tt = i - r * nt;
+            dst[(int64_t)2 * r * bz.n2pad + tt] = tile[tt * bz.n1 + r];
         }
+        __syncthreads();
     }
 }
 
@@ -97,9 +115,11 @@ __device__ __forceinline__ float bz_ld(__amdgpu_buffer_rsrc_t r, int voff, int s
 // residue r, n2pad columns), A = the DFT coefficients of ALL n1 output rows (Re / Im row pairs), packed by
 // pack_bz_coefficients.  One wave = 32 columns x 3 row tiles of 32 (16 complex rows each); blockIdx.z = the
 // group of 3 row tiles.  Same register-blocked operand stream as fwd_cols_kernel (k_forward.hip).
-// MODE 0: out = conj(D Bhat[k1][k2]); MODE 1: out = D T_L[k1][k2].
+// MODE 0: all n1 rows, out = conj(D Bhat[k1][k2]) planar; MODE 1: the rows k1lo .. k1lo + k1n - 1 that hold consumed
+// bins, x[k - kmin] = conj(D) w[k] / L for k = n2 k1 + k2 in [kmin, kmax).
 template <int MODE, int kStep>
-__global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float *__restrict__ in, float *__restrict__ out)
+__global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float *__restrict__ in, float *__restrict__ out,
+                                                         cf *__restrict__ x)
 {
     constexpr int NT = 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,12 +131,13 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
     const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad;
     const __amdgpu_buffer_rsrc_t rb =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in + clip * plane), (short)0, (int)(plane * 4), 0x00020000);
+    const int n_tiles = MODE == 0 ? bz.n_tiles : bz.n_tiles2;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(bz.apack), (short)0, bz.n1 * bz.n_tiles * 256, 0x00020000); // [r][tile][lane]
+        const_cast<float *>(MODE == 0 ? bz.apack : bz.apack2), (short)0, bz.n1 * n_tiles * 256, 0x00020000); // [r][tile][lane]
     const int vb = (hb * bz.n2pad + ctile * 32 + j) * 4;
     const int va = (tile0 * 64 + lane) * 4;
     const int sb = 2 * bz.n2pad * 4; // bytes per residue in the planar buffer
-    const int sa = bz.n_tiles * 256; // bytes per residue in the coefficient image
+    const int sa = n_tiles * 256;    // bytes per residue in the coefficient image
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
@@ -154,17 +175,30 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
     // tile * 16 + (q & 1) + 4 (q >> 1) + 2 (lane >> 5)
     const int k2 = ctile * 32 + j;
     if (k2 >= bz.n2) return;
-    const cf *__restrict__ tab = MODE == 0 ? bz.bhat : bz.tl;
-    float *__restrict__ o = out + clip * plane;
+    if (MODE == 0) {
+        float *__restrict__ o = out + clip * plane;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k1 = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
-            if (k1 < bz.n1) {
-                const cf v = c_mul(cf{acc[t][2 * q], acc[t][2 * q + 1]}, tab[(int64_t)k1 * bz.n2 + k2]);
-                o[(int64_t)2 * k1 * bz.n2pad + k2] = v.r;
-                o[(int64_t)(2 * k1 + 1) * bz.n2pad + k2] = MODE == 0 ? -v.i : v.i;
+            for (int q = 0; q < 8; ++q) {
+                const int k1 = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
+                if (k1 < bz.n1) {
+                    const cf v = c_mul(cf{acc[t][2 * q], acc[t][2 * q + 1]}, bz.bhat[(int64_t)k1 * bz.n2 + k2]);
+                    o[(int64_t)2 * k1 * bz.n2pad + k2] = v.r;
+                    o[(int64_t)(2 * k1 + 1) * bz.n2pad + k2] = -v.i;
+                }
+            }
+        }
+    } else {
+        cf *__restrict__ xo = x + (int64_t)clip * (bz.kmax - bz.kmin);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cr = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
+                const int64_t k = (int64_t)bz.n2 * (bz.k1lo + cr) + k2;
+                if (cr < bz.k1n && k >= bz.kmin && k < bz.kmax)
+                    xo[k - bz.kmin] = c_mul(cf{acc[t][2 * q], -acc[t][2 * q + 1]}, bz.wk[k - bz.kmin]);
             }
         }
     }
@@ -172,15 +206,16 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
 
 // host: coefficient image [r][tile][lane] of the full length-n1 DFT for the MFMA A operand: lane l supplies
 // A[row = 32 tile + (l & 31)][k = 2 r + (l >> 5)]; row 2 k1 = Re row (dr, -di), 2 k1 + 1 = Im row (di, dr);
-// n_tiles is a multiple of 3, rows past 2 n1 are zero
-void pack_bz_coefficients(int n1, const float *tw_n1_ri, int n_tiles, float *apack)
+// rows k1_first .. k1_first + k1_count - 1; n_tiles is a multiple of 3, rows past 2 k1_count are zero
+void pack_bz_coefficients(int n1, int k1_first, int k1_count, const float *tw_n1_ri, int n_tiles, float *apack)
 {
     for (int r = 0; r < n1; ++r)
         for (int t = 0; t < n_tiles; ++t)
             for (int l = 0; l < 64; ++l) {
-                const int row = 32 * t + (l & 31), k1 = row >> 1, part = l >> 5;
+                const int row = 32 * t + (l & 31), cr = row >> 1, part = l >> 5;
                 float v = 0.0f;
-                if (k1 < n1) {
+                if (cr < k1_count) {
+                    const int k1 = k1_first + cr;
                     const int64_t idx = ((int64_t)r * k1) % n1;
                     const float dr = tw_n1_ri[2 * idx], di = tw_n1_ri[2 * idx + 1];
                     if ((row & 1) == 0) v = part == 0 ? dr : -di;
@@ -193,25 +228,25 @@ void pack_bz_coefficients(int n1, const float *tw_n1_ri, int n_tiles, float *apa
 size_t bz_plane_bytes(const BzArgs &bz, int n_clips) { return (size_t)n_clips * 2 * bz.n1 * bz.n2pad * sizeof(float); }
 
 template <int MODE, int STEP>
-static void launch_bz_cols_step(const BzArgs &bz, const float *in, float *out, int n_clips, hipStream_t s)
+static void launch_bz_cols_step(const BzArgs &bz, const float *in, float *out, cf *x, int n_clips, hipStream_t s)
 {
-    dim3 grid(((bz.n2 + 31) / 32 + 3) / 4, n_clips, bz.n_tiles / 3);
-    hipLaunchKernelGGL((bz_cols_kernel<MODE, STEP>), grid, dim3(256), 0, s, bz, in, out);
+    dim3 grid(((bz.n2 + 31) / 32 + 3) / 4, n_clips, (MODE == 0 ? bz.n_tiles : bz.n_tiles2) / 3);
+    hipLaunchKernelGGL((bz_cols_kernel<MODE, STEP>), grid, dim3(256), 0, s, bz, in, out, x);
 }
 
 template <int MODE>
-static void launch_bz_cols(const BzArgs &bz, const float *in, float *out, int n_clips, hipStream_t s)
+static void launch_bz_cols_t(const BzArgs &bz, const float *in, float *out, cf *x, int n_clips, hipStream_t s)
 {
     auto padded = [&](int step) { return ((bz.n1 + step - 1) / step + 1) / 2 * 2 * step; }; // residues the loop walks
     int best = 16;
     for (int step : {15, 14})
         if (padded(step) < padded(best)) best = step;
     if (best == 16)
-        launch_bz_cols_step<MODE, 16>(bz, in, out, n_clips, s);
+        launch_bz_cols_step<MODE, 16>(bz, in, out, x, n_clips, s);
     else if (best == 15)
-        launch_bz_cols_step<MODE, 15>(bz, in, out, n_clips, s);
+        launch_bz_cols_step<MODE, 15>(bz, in, out, x, n_clips, s);
     else
-        launch_bz_cols_step<MODE, 14>(bz, in, out, n_clips, s);
+        launch_bz_cols_step<MODE, 14>(bz, in, out, x, n_clips, s);
 }
 
 static void bz_rows_attr()
@@ -222,6 +257,8 @@ static void bz_rows_attr()
                                   160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bz_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bz_transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
         attr_set.mark();
     }
 }
@@ -231,24 +268,37 @@ void launch_bz_rows_first(const RowsArgs &rows, const BzArgs &bz, const i16x2 *d
 {
     bz_rows_attr();
     hipLaunchKernelGGL(bz_rows_kernel<0>, dim3(n_clips, bz.n1), dim3(kBzThreads), (size_t)rows.n2 * sizeof(cf), s, rows, bz,
-                       d_pairs, (const float *)nullptr, d_out, (cf *)nullptr);
+                       d_pairs, (const float *)nullptr, d_out);
 }
 
-// mode 0: Y' -> C = conj(A Bhat); mode 1: C -> E = D T_L; both planar, in and out distinct
-void launch_bz_cols(const BzArgs &bz, int mode, const float *d_in, float *d_out, int n_clips, hipStream_t s)
+// Y' -> C = conj(A Bhat), planar [k1][k2]; in and out distinct
+void launch_bz_cols_full(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s)
 {
-    if (mode == 0)
-        launch_bz_cols<0>(bz, d_in, d_out, n_clips, s);
-    else
-        launch_bz_cols<1>(bz, d_in, d_out, n_clips, s);
+    launch_bz_cols_t<0>(bz, d_in, d_out, nullptr, n_clips, s);
 }
 
-// planar E -> x [n_clips][kmax - kmin]
-void launch_bz_rows_last(const RowsArgs &rows, const BzArgs &bz, const float *d_in, int n_clips, cf *d_x, hipStream_t s)
+// C [k1][k2] -> C' [r][t]; in and out distinct
+void launch_bz_transpose(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s)
+{
+    bz_rows_attr();
+    int tsteps = 64; // time steps per workgroup: 256-byte runs; fewer when n1 is large (the tile lives in LDS)
+    while (tsteps > 1 && (size_t)tsteps * bz.n1 * sizeof(float) > 120 * 1024) tsteps /= 2;
+    hipLaunchKernelGGL(bz_transpose_kernel, dim3((bz.n2 + tsteps - 1) / tsteps, n_clips), dim3(256),
+                       (size_t)tsteps * bz.n1 * sizeof(float), s, bz, tsteps, d_in, d_out);
+}
+
+// C' -> Y'' planar; in and out distinct
+void launch_bz_rows_second(const RowsArgs &rows, const BzArgs &bz, const float *d_in, int n_clips, float *d_out, hipStream_t s)
 {
     bz_rows_attr();
     hipLaunchKernelGGL(bz_rows_kernel<1>, dim3(n_clips, bz.n1), dim3(kBzThreads), (size_t)rows.n2 * sizeof(cf), s, rows, bz,
-                       (const i16x2 *)nullptr, d_in, (float *)nullptr, d_x);
+                       (const i16x2 *)nullptr, d_in, d_out);
+}
+
+// Y'' -> x [n_clips][kmax - kmin]
+void launch_bz_cols_last(const BzArgs &bz, const float *d_in, int n_clips, cf *d_x, hipStream_t s)
+{
+    launch_bz_cols_t<1>(bz, d_in, nullptr, d_x, n_clips, s);
 }
 
 } // namespace hpfw

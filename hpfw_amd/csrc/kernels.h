@@ -47,11 +47,14 @@ struct BzArgs {
     int n1, n2, n2pad;  // n2pad: row stride (floats) of the planar buffers, a multiple of 32
     int kmin, kmax;     // forward bins consumed
     int n_tiles;        // row tiles of 32 in the coefficient image, a multiple of 3, covering 2 n1 rows
+    int k1lo, k1n;      // rows k1lo .. k1lo + k1n - 1 of the second transform hold the consumed bins
+    int n_tiles2;       // row tiles of their coefficient image apack2 (a multiple of 3)
     const cf *w;        // chirp w[r + n1 t], 0 from sample N on
     const cf *tl;       // T_L[r k2]
     const cf *bhat;     // DFT_L(conj chirp)[n2 k1 + k2]
     const cf *wk;       // w[k] / L  [kmax - kmin]
     const float *apack; // coefficient image of the full length-n1 DFT [n1][n_tiles][64]
+    const float *apack2; // ... of the rows k1lo .. k1lo + k1n - 1   [n1][n_tiles2][64]
 };
 
 // One Bluestein size class (all bands whose chirp-z length is p).
@@ -83,13 +86,15 @@ size_t fwd_rows_lds_bytes(const RowsArgs &a);
 // length-n1 DFT across residues on f32 MFMA: planar yp [n_clips][2 n1][hpad] -> x [n_clips][kmax-kmin]
 void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s);
 void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, int n_tiles, float *apack);
-// chirp-z forward transform (k_bluestein.hip): pairs -> Y' -> C -> E -> x; the planar buffers hold
+// chirp-z forward transform (k_bluestein.hip): pairs -> Y' -> C -> C' -> Y'' -> x; the planar buffers hold
 // bz_plane_bytes(bz, n_clips) each
 size_t bz_plane_bytes(const BzArgs &bz, int n_clips);
-void pack_bz_coefficients(int n1, const float *tw_n1_ri, int n_tiles, float *apack);
+void pack_bz_coefficients(int n1, int k1_first, int k1_count, const float *tw_n1_ri, int n_tiles, float *apack);
 void launch_bz_rows_first(const RowsArgs &rows, const BzArgs &bz, const i16x2 *d_pairs, int n_clips, float *d_out, hipStream_t s);
-void launch_bz_cols(const BzArgs &bz, int mode, const float *d_in, float *d_out, int n_clips, hipStream_t s);
-void launch_bz_rows_last(const RowsArgs &rows, const BzArgs &bz, const float *d_in, int n_clips, cf *d_x, hipStream_t s);
+void launch_bz_cols_full(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s);
+void launch_bz_transpose(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s);
+void launch_bz_rows_second(const RowsArgs &rows, const BzArgs &bz, const float *d_in, int n_clips, float *d_out, hipStream_t s);
+void launch_bz_cols_last(const BzArgs &bz, const float *d_in, int n_clips, cf *d_x, hipStream_t s);
 // band chirp-z transforms: x -> mag [n_clips][121][c]; also the maxima each wave saw,
 // d_wavemax [n_clips][121][kCqMaxWaves] (slots of absent waves are written as 0)
 constexpr int kCqMaxWaves = 16;

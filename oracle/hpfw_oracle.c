@@ -829,8 +829,8 @@ void hpfw_oracle_plan_bands(const hpfw_oracle_plan *p, int32_t *start, int32_t *
 /* ------------------------------------------------------------------------------------------ */
 /* S15: the same bins when N has a prime factor above 7.  a[n] = x[n] w[n]; A = DFT_L(a) by rows (length n2
  * over t for every residue r), T_L[r k2], columns (fma chain over r, as above); C = conj(A Bhat);
- * F = DFT_L(C) by columns first (fma chain over j1 for every j2), T_L[j2 k1], rows (length n2 over j2):
- * F[k1 + n1 k2]; X[k] = conj(F[k]) w[k] / L. */
+ * F = DFT_L(C) the same way (rows over the residues of the flat index, T_L, columns) for the rows k1 that hold
+ * consumed bins; X[k] = conj(F[k]) w[k] / L. */
 static void spectrum_bluestein(const hpfw_oracle_plan *p, const int16_t *pcm, float *x_ri)
 {
     const int64_t n = p->info.n_samples, n1 = p->info.n1, n2 = p->info.n2;
@@ -863,32 +863,28 @@ static void spectrum_bluestein(const hpfw_oracle_plan *p, const int16_t *pcm, fl
             yb[k1 * n2 + k2].r = v.r;
             yb[k1 * n2 + k2].i = -v.i;
         }
-    for (int64_t k1 = 0; k1 < n1; ++k1)
-        for (int64_t j2 = 0; j2 < n2; ++j2) {
-            float ar = 0.0f, ai = 0.0f;
-            for (int64_t j1 = 0; j1 < n1; ++j1) {
-                cf d = p->tw_n1[(j1 * k1) % n1];
-                cf y = yb[j1 * n2 + j2];
-                ar = fmaf(d.r, y.r, ar);
-                ar = fmaf(-d.i, y.i, ar);
-                ai = fmaf(d.i, y.r, ai);
-                ai = fmaf(d.r, y.i, ai);
-            }
-            cf acc = {ar, ai};
-            ya[k1 * n2 + j2] = c_mul(acc, p->bz_tl[k1 * n2 + j2]);
-        }
-    for (int64_t k1 = 0; k1 < n1; ++k1) {
-        memcpy(z, ya + k1 * n2, sizeof(cf) * (size_t)n2);
+    /* second transform, F = DFT_L(C) with C[n2 k1 + k2] as it stands: rows first again -- residue r of the flat
+     * index j = r + n1 t -- then T_L, then the column chain for the rows k1 that hold consumed bins only */
+    for (int64_t r = 0; r < n1; ++r) {
+        for (int64_t t = 0; t < n2; ++t) z[t] = yb[r + n1 * t];
         fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
-        for (int64_t k2 = 0; k2 < n2; ++k2) {
-            int64_t k = k1 + n1 * k2;
-            if (k < p->info.kmin || k >= p->info.kmax) continue;
-            cf f = z[p->pos_n2[k2]];
-            cf fc = {f.r, -f.i};
-            cf v = c_mul(fc, p->bz_wk[k - p->info.kmin]);
-            x_ri[2 * (k - p->info.kmin)] = v.r;
-            x_ri[2 * (k - p->info.kmin) + 1] = v.i;
+        for (int64_t k2 = 0; k2 < n2; ++k2) ya[r * n2 + k2] = c_mul(z[p->pos_n2[k2]], p->bz_tl[r * n2 + k2]);
+    }
+    for (int64_t k = p->info.kmin; k < p->info.kmax; ++k) {
+        int64_t k1 = k / n2, k2 = k % n2;
+        float ar = 0.0f, ai = 0.0f;
+        for (int64_t r = 0; r < n1; ++r) {
+            cf d = p->tw_n1[(r * k1) % n1];
+            cf y = ya[r * n2 + k2];
+            ar = fmaf(d.r, y.r, ar);
+            ar = fmaf(-d.i, y.i, ar);
+            ai = fmaf(d.i, y.r, ai);
+            ai = fmaf(d.r, y.i, ai);
         }
+        cf fc = {ar, -ai};
+        cf v = c_mul(fc, p->bz_wk[k - p->info.kmin]);
+        x_ri[2 * (k - p->info.kmin)] = v.r;
+        x_ri[2 * (k - p->info.kmin) + 1] = v.i;
     }
     free(z);
     free(ya);
