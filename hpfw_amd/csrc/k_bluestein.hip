@@ -80,28 +80,34 @@ __global__ __launch_bounds__(kBzThreads, 4) void bz_rows_kernel(RowsArgs a, BzAr
 // C [k1][k2] (planar, n2pad columns) -> C' [r][t] (the same planar shape) with n2 k1 + k2 = r + n1 t: a workgroup takes
 // the flat range of T time steps t (T n1 consecutive flat elements: coalesced reads), one plane at a time through
 // LDS, and writes for every residue its T values side by side.
-__global__ __launch_bounds__(256) void bz_transpose_kernel(BzArgs bz, int tsteps, const float *__restrict__ in, float *__restrict__ out)
+__global__ __launch_bounds__(256) void bz_transpose_kernel(BzArgs bz, int lg_t, const float *__restrict__ in, float *__restrict__ out)
 {
     float *tile = reinterpret_cast<float *>(smem_raw); // [tsteps][n1]
+    const int tsteps = 1 << lg_t;
     const int clip = blockIdx.y, t0 = blockIdx.x * tsteps;
     const int nt = min(tsteps, bz.n2 - t0);
     const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad;
     const int64_t j0 = (int64_t)bz.n1 * t0;
     const int count = bz.n1 * nt;
+    // this thread's first flat element as (k1, k2); every further one is 256 on (no division per element)
+    int k1 = (int)((j0 + threadIdx.x) / bz.n2), k2 = (int)((j0 + threadIdx.x) - (int64_t)k1 * bz.n2);
+    const int tt = threadIdx.x & (tsteps - 1), rstep = 256 >> lg_t;
     for (int part = 0; part < 2; ++part) { // Re plane, then Im plane
         const float *src = in + clip * plane + (int64_t)part * bz.n2pad;
+        int a1 = k1, a2 = k2;
         for (int i = threadIdx.x; i < count; i += 256) {
-            const int64_t j = j0 + i;
-            const int k1 = (int)(j / bz.n2), k2 = (int)(j - (int64_t)k1 * bz.n2);
-            tile[i] = src[(int64_t)2 * k1 * bz.n2pad + k2];
+            tile[i] = src[(int64_t)2 * a1 * bz.n2pad + a2];
+            a2 += 256;
+            while (a2 >= bz.n2) {
+                a2 -= bz.n2;
+                ++a1;
+            }
         }
         __syncthreads();
-        float *dst = out + clip * plane + (int64_t)part * bz.n2pad + t0;
-        // thread -> (residue, time step) with the time step fastest: runs of nt floats per residue
-        for (int i = threadIdx.x; i < count; i += 256) {
-            const int r = i / nt, tt = i - r * nt;
-            dst[(int64_t)2 * r * bz.n2pad + tt] = tile[tt * bz.n1 + r];
-        }
+        float *dst = out + clip * plane + (int64_t)part * bz.n2pad + t0 + tt;
+        // a thread keeps its time step and walks the residues: runs of tsteps floats per residue and wave pass
+        if (tt < nt)
+            for (int r = threadIdx.x >> lg_t; r < bz.n1; r += rstep) dst[(int64_t)2 * r * bz.n2pad] = tile[tt * bz.n1 + r];
         __syncthreads();
     }
 }
@@ -281,10 +287,13 @@ void launch_bz_cols_full(const BzArgs &bz, const float *d_in, float *d_out, int 
 void launch_bz_transpose(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s)
 {
     bz_rows_attr();
-    int tsteps = 64; // time steps per workgroup: 256-byte runs; fewer when n1 is large (the tile lives in LDS)
-    while (tsteps > 1 && (size_t)tsteps * bz.n1 * sizeof(float) > 120 * 1024) tsteps /= 2;
+    // time steps per workgroup (a power of two, at most 256): 128-byte runs with several workgroups per CU; fewer
+    // when n1 is large (the tile lives in LDS)
+    int lg = 5;
+    while (lg > 0 && ((size_t)1 << lg) * bz.n1 * sizeof(float) > 48 * 1024) --lg;
+    const int tsteps = 1 << lg;
     hipLaunchKernelGGL(bz_transpose_kernel, dim3((bz.n2 + tsteps - 1) / tsteps, n_clips), dim3(256),
-                       (size_t)tsteps * bz.n1 * sizeof(float), s, bz, tsteps, d_in, d_out);
+                       (size_t)tsteps * bz.n1 * sizeof(float), s, bz, lg, d_in, d_out);
 }
 
 // C' -> Y'' planar; in and out distinct
