@@ -164,3 +164,15 @@ def test_multi_library_exports_every_declared_symbol():
         for world in (1, 3, 8):
             for r in range(world):
                 assert multi.shard_range(n, r, world) == hdist.shard_range(n, r, world)
+
+
+def test_multi_gpu_host_path_fails_loudly_without_a_gpu():
+    """no device, no fallback: creating a group (or a handle) is an error with a message, never a silent CPU path"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from hpfw_amd import multi
+    with pytest.raises(hpfw_amd.HpfwError):
+        multi.GpuGroup([0])
+    with pytest.raises(hpfw_amd.HpfwError):
+        hpfw_amd.Gpu(0)
