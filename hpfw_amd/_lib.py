@@ -36,7 +36,7 @@ EXPORTS = (
     "hpfw_gpu_cfg_set_filters", "hpfw_gpu_cfg_hashprints", "hpfw_gpu_mel_hashprints_pcm16_host",
     "hpfw_gpu_cfg_cov_reset", "hpfw_gpu_cfg_cov_accumulate", "hpfw_gpu_cfg_cov_get", "hpfw_gpu_cfg_learn_filters",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
-    "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions",
+    "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions", "hpfw_gpu_chirpz_table",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_calc_hashprints", "par_collector_save", "par_collector_load",
     "prepare_result_free", "calc_hashprint_result_free",
@@ -136,6 +136,7 @@ def lib():
     L.hpfw_gpu_get_kernel_timing.argtypes = [vp, vp, vp, vp, ctypes.POINTER(i32)]
     L.hpfw_gpu_plan_checksum.argtypes = [i64, vp]
     L.hpfw_gpu_plan_checksum_ex.argtypes = [i64, i32, u32, vp]
+    L.hpfw_gpu_chirpz_table.argtypes = [vp, i64, i32, vp, i64, vp]
     L.hpfw_gpu_set_conventions.argtypes = [vp, u32]
     L.par_collector_new.restype = vp
     L.par_collector_del.argtypes = [vp]
@@ -218,6 +219,14 @@ class Gpu:
         hp = np.zeros((pcm.shape[0], g.n_hp), np.uint64)
         check(lib().hpfw_gpu_extract_pcm16_host(self._h, _hp(pcm), pcm.shape[1], pcm.shape[0], _hp(hp)))
         return hp
+
+    def chirpz_table(self, n_samples, which):
+        """device-generated table of the chirp-z forward transform as complex64 (0 w, 1 T_L, 2 Bhat, 3 w[k] / L)"""
+        count = ctypes.c_int64(0)
+        check(lib().hpfw_gpu_chirpz_table(self._h, n_samples, which, None, 0, ctypes.byref(count)))
+        out = np.zeros(count.value, np.float32)
+        check(lib().hpfw_gpu_chirpz_table(self._h, n_samples, which, _hp(out), count.value, ctypes.byref(count)))
+        return out.view(np.complex64)
 
     def stage_spectrum_dev(self, d_pcm, n_samples, n_clips, d_x, stream=0):
         check(lib().hpfw_gpu_stage_spectrum(self._h, d_pcm, n_samples, n_clips, d_x, stream))

@@ -287,19 +287,46 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         bz.kmin = p.kmin;
         bz.kmax = p.kmax;
         bz.n_tiles = ((2 * p.n1 + 31) / 32 + 2) / 3 * 3;
-        if ((rc = upload(p.bz_w, reinterpret_cast<const hpfw::HostCf **>(&bz.w), dp->owned))) return rc;
-        if ((rc = upload(p.bz_tl, reinterpret_cast<const hpfw::HostCf **>(&bz.tl), dp->owned))) return rc;
-        if ((rc = upload(p.bz_bhat, reinterpret_cast<const hpfw::HostCf **>(&bz.bhat), dp->owned))) return rc;
-        if ((rc = upload(p.bz_wk, reinterpret_cast<const hpfw::HostCf **>(&bz.wk), dp->owned))) return rc;
-        std::vector<float> apack((size_t)p.n1 * bz.n_tiles * 64);
-        hpfw::pack_bz_coefficients(p.n1, 0, p.n1, reinterpret_cast<const float *>(p.tw_n1.data()), bz.n_tiles, apack.data());
-        if ((rc = upload(apack, &bz.apack, dp->owned))) return rc;
         bz.k1lo = p.kmin / p.n2;
         bz.k1n = (p.kmax - 1) / p.n2 - bz.k1lo + 1;
         bz.n_tiles2 = ((2 * bz.k1n + 31) / 32 + 2) / 3 * 3;
-        std::vector<float> apack2((size_t)p.n1 * bz.n_tiles2 * 64);
-        hpfw::pack_bz_coefficients(p.n1, bz.k1lo, bz.k1n, reinterpret_cast<const float *>(p.tw_n1.data()), bz.n_tiles2, apack2.data());
-        if ((rc = upload(apack2, &bz.apack2, dp->owned))) return rc;
+        // coefficient images of the column transforms (all rows; the rows that hold consumed bins), packed on the device
+        const cf *d_tw_n1 = nullptr;
+        std::vector<void *> tmp_owned;
+        if ((rc = upload(p.tw_n1, reinterpret_cast<const hpfw::HostCf **>(&d_tw_n1), tmp_owned))) return rc;
+        g_uploaded -= p.tw_n1.size() * sizeof(cf);
+        struct FreeTmp {
+            std::vector<void *> &v;
+            ~FreeTmp() { for (void *q : v) (void)hipFree(q); }
+        } free_tmp{tmp_owned};
+        for (int which = 0; which < 2; ++which) {
+            void *d = nullptr;
+            const size_t bytes = (size_t)p.n1 * (which ? bz.n_tiles2 : bz.n_tiles) * 64 * sizeof(float);
+            HIP_TRY(hipMalloc(&d, bytes));
+            dp->owned.push_back(d);
+            g_uploaded += bytes;
+            (which ? bz.apack2 : bz.apack) = static_cast<const float *>(d);
+            hpfw::launch_bz_pack_coefficients(p.n1, which ? bz.k1lo : 0, which ? bz.k1n : p.n1, d_tw_n1, which ? bz.n_tiles2 : bz.n_tiles,
+                                              static_cast<float *>(d), nullptr);
+        }
+        // chirp, T_L, w[k] / L and Bhat are generated on the device (k_bluestein.hip): a corpus of
+        // real recordings brings a new length with every file
+        const size_t big_l = (size_t)p.n1 * p.n2, plane = hpfw::bz_plane_bytes(bz, 1);
+        for (const hpfw::cf **t : {&bz.w, &bz.tl, &bz.bhat, &bz.wk}) {
+            void *d = nullptr;
+            const size_t bytes = (t == &bz.wk ? (size_t)(p.kmax - p.kmin) : big_l) * sizeof(cf);
+            HIP_TRY(hipMalloc(&d, bytes));
+            dp->owned.push_back(d);
+            g_uploaded += bytes;
+            *t = static_cast<const cf *>(d);
+        }
+        void *scratch = nullptr;
+        HIP_TRY(hipMalloc(&scratch, 2 * plane));
+        tmp_owned.push_back(scratch); // freed with T_n1 when this block ends, after the synchronisation below
+        hpfw::launch_bz_make_tables(ra, bz, n, static_cast<float *>(scratch), static_cast<float *>(scratch) + plane / sizeof(float), nullptr);
+        const hipError_t launched = hipGetLastError(), done = hipStreamSynchronize(nullptr);
+        if (launched != hipSuccess || done != hipSuccess)
+            return fail(HPFW_E_HIP, std::string("chirp-z tables: ") + hipGetErrorString(launched != hipSuccess ? launched : done));
     }
     // column DFT: coefficient image for the MFMA A operand
     hpfw::ColsArgs &ca = dp->cols;
@@ -352,10 +379,6 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         std::vector<hpfw::HostCf>().swap(hp.tw_n1);
         std::vector<hpfw::HostCf>().swap(hp.tw_big);
         std::vector<hpfw::HostCf>().swap(hp.g);
-        std::vector<hpfw::HostCf>().swap(hp.bz_w);
-        std::vector<hpfw::HostCf>().swap(hp.bz_tl);
-        std::vector<hpfw::HostCf>().swap(hp.bz_bhat);
-        std::vector<hpfw::HostCf>().swap(hp.bz_wk);
         for (hpfw::BluesteinClass &bc : hp.classes) {
             std::vector<hpfw::HostCf>().swap(bc.tw);
             std::vector<hpfw::HostCf>().swap(bc.gtw);
@@ -722,6 +745,25 @@ int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_sampl
         rc = fail(HPFW_E_HIP, "D2H copy failed");
     if (hipStreamSynchronize(s_comp) != hipSuccess && !rc) rc = fail(HPFW_E_HIP, "kernel execution failed");
     return rc;
+}
+
+// ---- diagnostic: the device-generated tables of the chirp-z forward transform ------------------
+int hpfw_gpu_chirpz_table(hpfw_gpu *h, int64_t n_samples, int which, float *out, int64_t capacity, int64_t *count)
+{
+    if (!h || !count) return fail(HPFW_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    DevPlan *dp;
+    int rc = get_plan(h, n_samples, &dp);
+    if (rc) return rc;
+    if (!dp->hp.bluestein) return fail(HPFW_E_INVALID, "clip length takes the mixed-radix transform: no chirp-z tables");
+    const hpfw::BzArgs &bz = dp->bz;
+    const hpfw::cf *tab[4] = {bz.w, bz.tl, bz.bhat, bz.wk};
+    if (which < 0 || which > 3) return fail(HPFW_E_INVALID, "table index out of range");
+    *count = 2 * (which == 3 ? (int64_t)(bz.kmax - bz.kmin) : (int64_t)bz.n1 * bz.n2);
+    if (!out) return 0;
+    if (capacity < *count) return fail(HPFW_E_INVALID, "table buffer too small");
+    HIP_TRY(hipMemcpy(out, tab[which], (size_t)*count * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 // ---- stages ----------------------------------------------------------------------------------

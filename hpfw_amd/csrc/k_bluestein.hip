@@ -119,10 +119,11 @@ __device__ __forceinline__ float bz_ld(__amdgpu_buffer_rsrc_t r, int voff, int s
 
 // D[row][col] = sum_k A[row][k] B[k][col], k = 2 r + part: B = a planar buffer (row 2r = Re, 2r + 1 = Im of
 // residue r, n2pad columns), A = the DFT coefficients of ALL n1 output rows (Re / Im row pairs), packed by
-// pack_bz_coefficients.  One wave = 32 columns x 3 row tiles of 32 (16 complex rows each); blockIdx.z = the
+// bz_pack_kernel.  One wave = 32 columns x 3 row tiles of 32 (16 complex rows each); blockIdx.z = the
 // group of 3 row tiles.  Same register-blocked operand stream as fwd_cols_kernel (k_forward.hip).
 // MODE 0: all n1 rows, out = conj(D Bhat[k1][k2]) planar; MODE 1: the rows k1lo .. k1lo + k1n - 1 that hold consumed
-// bins, x[k - kmin] = conj(D) w[k] / L for k = n2 k1 + k2 in [kmin, kmax).
+// bins, x[k - kmin] = conj(D) w[k] / L for k = n2 k1 + k2 in [kmin, kmax); MODE 2 (table generation, one "clip"): all
+// n1 rows, x[n2 k1 + k2] = D as it stands -- Bhat, the transform of the conjugate chirp's lags.
 template <int MODE, int kStep>
 __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float *__restrict__ in, float *__restrict__ out,
                                                          cf *__restrict__ x)
@@ -137,9 +138,9 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
     const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad;
     const __amdgpu_buffer_rsrc_t rb =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in + clip * plane), (short)0, (int)(plane * 4), 0x00020000);
-    const int n_tiles = MODE == 0 ? bz.n_tiles : bz.n_tiles2;
+    const int n_tiles = MODE == 1 ? bz.n_tiles2 : bz.n_tiles;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(MODE == 0 ? bz.apack : bz.apack2), (short)0, bz.n1 * n_tiles * 256, 0x00020000); // [r][tile][lane]
+        const_cast<float *>(MODE == 1 ? bz.apack2 : bz.apack), (short)0, bz.n1 * n_tiles * 256, 0x00020000); // [r][tile][lane]
     const int vb = (hb * bz.n2pad + ctile * 32 + j) * 4;
     const int va = (tile0 * 64 + lane) * 4;
     const int sb = 2 * bz.n2pad * 4; // bytes per residue in the planar buffer
@@ -195,6 +196,15 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
                 }
             }
         }
+    } else if (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k1 = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
+                if (k1 < bz.n1) x[(int64_t)k1 * bz.n2 + k2] = cf{acc[t][2 * q], acc[t][2 * q + 1]};
+            }
+        }
     } else {
         cf *__restrict__ xo = x + (int64_t)clip * (bz.kmax - bz.kmin);
 #pragma unroll
@@ -210,25 +220,129 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
     }
 }
 
-// host: coefficient image [r][tile][lane] of the full length-n1 DFT for the MFMA A operand: lane l supplies
+// coefficient image [r][tile][lane] of the length-n1 DFT for the MFMA A operand: lane l supplies
 // A[row = 32 tile + (l & 31)][k = 2 r + (l >> 5)]; row 2 k1 = Re row (dr, -di), 2 k1 + 1 = Im row (di, dr);
-// rows k1_first .. k1_first + k1_count - 1; n_tiles is a multiple of 3, rows past 2 k1_count are zero
-void pack_bz_coefficients(int n1, int k1_first, int k1_count, const float *tw_n1_ri, int n_tiles, float *apack)
+// rows k1_first .. k1_first + k1_count - 1; n_tiles is a multiple of 3, rows past 2 k1_count are zero.  Filled on the
+// device from T_n1 (n1^2 entries: milliseconds of host time for a long clip, and every file brings its own length).
+__global__ __launch_bounds__(256) void bz_pack_kernel(int n1, int k1_first, int k1_count, const cf *__restrict__ tw_n1, int n_tiles,
+                                                      float *__restrict__ apack)
 {
-    for (int r = 0; r < n1; ++r)
-        for (int t = 0; t < n_tiles; ++t)
-            for (int l = 0; l < 64; ++l) {
-                const int row = 32 * t + (l & 31), cr = row >> 1, part = l >> 5;
-                float v = 0.0f;
-                if (cr < k1_count) {
-                    const int k1 = k1_first + cr;
-                    const int64_t idx = ((int64_t)r * k1) % n1;
-                    const float dr = tw_n1_ri[2 * idx], di = tw_n1_ri[2 * idx + 1];
-                    if ((row & 1) == 0) v = part == 0 ? dr : -di;
-                    else v = part == 0 ? di : dr;
-                }
-                apack[((size_t)r * n_tiles + t) * 64 + l] = v;
-            }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n1 * n_tiles * 64) return;
+    const int l = (int)(i & 63), t = (int)((i >> 6) % n_tiles), r = (int)((i >> 6) / n_tiles);
+    const int row = 32 * t + (l & 31), cr = row >> 1, part = l >> 5;
+    float v = 0.0f;
+    if (cr < k1_count) {
+        const cf d = tw_n1[((int64_t)r * (k1_first + cr)) % n1];
+        if ((row & 1) == 0) v = part == 0 ? d.r : -d.i;
+        else v = part == 0 ? d.i : d.r;
+    }
+    apack[i] = v;
+}
+
+void launch_bz_pack_coefficients(int n1, int k1_first, int k1_count, const cf *d_tw_n1, int n_tiles, float *d_apack, hipStream_t s)
+{
+    const int64_t count = (int64_t)n1 * n_tiles * 64;
+    hipLaunchKernelGGL(bz_pack_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, n1, k1_first, k1_count, d_tw_n1, n_tiles,
+                       d_apack);
+}
+
+// ---- the tables of S15, generated where they are used -------------------------------------------------------------
+// A corpus of real recordings has a length of its own per file, so the tables of a length are built once per file:
+// on the host (double DFT of length L) that cost more than the file's whole extraction.  Here they take one pass of
+// double arithmetic per element and one forward transform on the kernels above.
+//
+// S2b: cosine and sine of alpha in [0, pi / 4] in double, as Taylor polynomials in alpha^2 evaluated by explicit fma
+// chains (truncation below 1e-19; coefficients = the correctly rounded 1 / k!): every operation is an IEEE double
+// multiply or fma, so the oracle's C restatement is identical bit for bit, which a libm call would not promise.
+__device__ __forceinline__ void bz_cos_sin(double x, double &c, double &s)
+{
+    const double z = x * x;
+    double ps = 0x1.952c77030ad4ap-49;                 // 1 / 17!
+    ps = __builtin_fma(ps, z, -0x1.ae7f3e733b81fp-41); // -1 / 15!
+    ps = __builtin_fma(ps, z, 0x1.6124613a86d09p-33);
+    ps = __builtin_fma(ps, z, -0x1.ae64567f544e4p-26);
+    ps = __builtin_fma(ps, z, 0x1.71de3a556c734p-19);
+    ps = __builtin_fma(ps, z, -0x1.a01a01a01a01ap-13);
+    ps = __builtin_fma(ps, z, 0x1.1111111111111p-7);
+    ps = __builtin_fma(ps, z, -0x1.5555555555555p-3); // -1 / 3!
+    s = __builtin_fma(x * z, ps, x);
+    double pc = -0x1.6827863b97d97p-53;               // -1 / 18!
+    pc = __builtin_fma(pc, z, 0x1.ae7f3e733b81fp-45); // 1 / 16!
+    pc = __builtin_fma(pc, z, -0x1.93974a8c07c9dp-37);
+    pc = __builtin_fma(pc, z, 0x1.1eed8eff8d898p-29);
+    pc = __builtin_fma(pc, z, -0x1.27e4fb7789f5cp-22);
+    pc = __builtin_fma(pc, z, 0x1.a01a01a01a01ap-16);
+    pc = __builtin_fma(pc, z, -0x1.6c16c16c16c17p-10);
+    pc = __builtin_fma(pc, z, 0x1.5555555555555p-5);
+    pc = __builtin_fma(pc, z, -0.5);
+    c = __builtin_fma(z, pc, 1.0);
+}
+
+// e^{-2 pi i m / n}, 0 <= m < n: the octant reduction of S2 (plan.cpp twiddle_d) in integers, S2b for the octant's angle
+__device__ __forceinline__ void bz_unit(int64_t m, int64_t n, double &re, double &im)
+{
+    const int64_t a = 8 * m;
+    const int oct = (int)(a / n);
+    const int64_t r = a - (int64_t)oct * n;
+    const int64_t t = (oct & 1) ? (n - r) : r;
+    const double alpha = 3.14159265358979323846 * (double)t / (double)(4 * n);
+    double ca, sa, c, s;
+    bz_cos_sin(alpha, ca, sa);
+    switch (oct) {
+    case 0: c = ca; s = sa; break;
+    case 1: c = sa; s = ca; break;
+    case 2: c = -sa; s = ca; break;
+    case 3: c = -ca; s = sa; break;
+    case 4: c = -ca; s = -sa; break;
+    case 5: c = -sa; s = -ca; break;
+    case 6: c = sa; s = -ca; break;
+    default: c = ca; s = -sa; break;
+    }
+    re = c;
+    im = -s;
+}
+
+struct BzGen {
+    int64_t n, big_l; // samples, convolution length n1 n2
+    cf *w, *tl, *wk;  // the tables of BzArgs, written here
+    float *b;         // planar [2 r][n2pad]: the lags b[m mod L] = conj(w[m]), m in [kmin - (N - 1), kmax - 1], by residue
+};
+
+// element i = r n2 + t of the [n1][n2] tables stands for the flat index idx = r + n1 t
+__global__ __launch_bounds__(256) void bz_tables_kernel(BzArgs bz, BzGen g)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double c, s;
+    if (i < bz.kmax - bz.kmin) { // w[k] / L
+        const int64_t k = bz.kmin + i;
+        bz_unit((k * k) % (2 * g.n), 2 * g.n, c, s);
+        g.wk[i] = cf{(float)(c / (double)g.big_l), (float)(s / (double)g.big_l)};
+    }
+    if (i >= g.big_l) return;
+    const int r = (int)(i / bz.n2), t = (int)(i - (int64_t)r * bz.n2);
+    const int64_t idx = r + (int64_t)bz.n1 * t;
+    cf wv{0.0f, 0.0f};
+    float bre = 0.0f, bim = 0.0f;
+    if (idx < g.n) { // w[idx] = e^{-i pi idx^2 / N} = T_2N[idx^2 mod 2N]; idx < 2^26, the square is exact in 64 bits
+        bz_unit((idx * idx) % (2 * g.n), 2 * g.n, c, s);
+        wv = cf{(float)c, (float)s};
+        if (idx <= bz.kmax - 1) { // the lag m = idx
+            bre = (float)c;
+            bim = (float)(-s);
+        }
+    }
+    const int64_t neg = g.big_l - idx; // the lag m = idx - L = -neg; disjoint from the lags m = idx as L >= N + nk - 1
+    if (neg <= g.n - 1 - bz.kmin) {
+        bz_unit((neg * neg) % (2 * g.n), 2 * g.n, c, s);
+        bre = (float)c;
+        bim = (float)(-s);
+    }
+    g.w[i] = wv;
+    g.b[(int64_t)2 * r * bz.n2pad + t] = bre;
+    g.b[(int64_t)(2 * r + 1) * bz.n2pad + t] = bim;
+    bz_unit(((int64_t)r * t) % g.big_l, g.big_l, c, s);
+    g.tl[i] = cf{(float)c, (float)s};
 }
 
 size_t bz_plane_bytes(const BzArgs &bz, int n_clips) { return (size_t)n_clips * 2 * bz.n1 * bz.n2pad * sizeof(float); }
@@ -236,7 +350,7 @@ size_t bz_plane_bytes(const BzArgs &bz, int n_clips) { return (size_t)n_clips * 
 template <int MODE, int STEP>
 static void launch_bz_cols_step(const BzArgs &bz, const float *in, float *out, cf *x, int n_clips, hipStream_t s)
 {
-    dim3 grid(((bz.n2 + 31) / 32 + 3) / 4, n_clips, (MODE == 0 ? bz.n_tiles : bz.n_tiles2) / 3);
+    dim3 grid(((bz.n2 + 31) / 32 + 3) / 4, n_clips, (MODE == 1 ? bz.n_tiles2 : bz.n_tiles) / 3);
     hipLaunchKernelGGL((bz_cols_kernel<MODE, STEP>), grid, dim3(256), 0, s, bz, in, out, x);
 }
 
@@ -302,6 +416,26 @@ void launch_bz_rows_second(const RowsArgs &rows, const BzArgs &bz, const float *
     bz_rows_attr();
     hipLaunchKernelGGL(bz_rows_kernel<1>, dim3(n_clips, bz.n1), dim3(kBzThreads), (size_t)rows.n2 * sizeof(cf), s, rows, bz,
                        (const i16x2 *)nullptr, d_in, d_out);
+}
+
+// Fills bz.w, bz.tl, bz.wk and bz.bhat (device memory of the plan, sizes as in kernels.h) for clips of n samples:
+// chirp, T_L and the lags by bz_tables_kernel, then Bhat = the first transform (rows, T_L, columns) of the lags.
+// d_b and d_y: two planar buffers of bz_plane_bytes(bz, 1) each.  bz.apack must be in place.
+void launch_bz_make_tables(const RowsArgs &rows, const BzArgs &bz, int64_t n, float *d_b, float *d_y, hipStream_t s)
+{
+    bz_rows_attr();
+    BzGen g;
+    g.n = n;
+    g.big_l = (int64_t)bz.n1 * bz.n2;
+    g.w = const_cast<cf *>(bz.w);
+    g.tl = const_cast<cf *>(bz.tl);
+    g.wk = const_cast<cf *>(bz.wk);
+    g.b = d_b;
+    const int64_t nk = bz.kmax - bz.kmin, count = g.big_l > nk ? g.big_l : nk;
+    hipLaunchKernelGGL(bz_tables_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, bz, g);
+    hipLaunchKernelGGL(bz_rows_kernel<1>, dim3(1, bz.n1), dim3(kBzThreads), (size_t)rows.n2 * sizeof(cf), s, rows, bz,
+                       (const i16x2 *)nullptr, (const float *)d_b, d_y);
+    launch_bz_cols_t<2>(bz, d_y, nullptr, const_cast<cf *>(bz.bhat), 1, s);
 }
 
 // Y'' -> x [n_clips][kmax - kmin]

@@ -89,7 +89,10 @@ void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, in
 // chirp-z forward transform (k_bluestein.hip): pairs -> Y' -> C -> C' -> Y'' -> x; the planar buffers hold
 // bz_plane_bytes(bz, n_clips) each
 size_t bz_plane_bytes(const BzArgs &bz, int n_clips);
-void pack_bz_coefficients(int n1, int k1_first, int k1_count, const float *tw_n1_ri, int n_tiles, float *apack);
+// coefficient image [n1][n_tiles][64] of rows k1_first .. k1_first + k1_count - 1 of the length-n1 DFT, from T_n1 on the device
+void launch_bz_pack_coefficients(int n1, int k1_first, int k1_count, const cf *d_tw_n1, int n_tiles, float *d_apack, hipStream_t s);
+// the tables bz.w, bz.tl, bz.wk, bz.bhat of a clip length, generated on the device (two planar scratch buffers of one clip)
+void launch_bz_make_tables(const RowsArgs &rows, const BzArgs &bz, int64_t n, float *d_b, float *d_y, hipStream_t s);
 void launch_bz_rows_first(const RowsArgs &rows, const BzArgs &bz, const i16x2 *d_pairs, int n_clips, float *d_out, hipStream_t s);
 void launch_bz_cols_full(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s);
 void launch_bz_transpose(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s);

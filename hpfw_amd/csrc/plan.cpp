@@ -49,8 +49,7 @@ void chirp_d(int64_t m, int64_t big_m, double &c, double &s)
     const int64_t mm = m < 0 ? -m : m;
     const int64_t r = (int64_t)(((__int128)3 * mm * mm) % (2 * big_m));
     const double ang = M_PI * (double)r / (double)big_m;
-    c = std::cos(ang);
-    s = std::sin(ang);
+    sincos(ang, &s, &c);
 }
 
 // S5: iterative radix-2 decimation-in-time FFT in double, twiddles from twiddle_d, butterfly
@@ -156,7 +155,8 @@ void twiddle_d(int64_t m, int64_t n, double &re, double &im)
     const int64_t r = a - (int64_t)oct * n;
     const int64_t t = (oct & 1) ? (n - r) : r;
     const double alpha = M_PI * (double)t / (double)(4 * n);
-    const double ca = std::cos(alpha), sa = std::sin(alpha);
+    double ca, sa;
+    sincos(alpha, &sa, &ca); // glibc's sincos in the library and in the oracle: cos() and sin() differ from it in the last bit for 0.1 % of arguments
     double c, s;
     switch (oct) {
     case 0: c = ca; s = sa; break;
@@ -221,171 +221,6 @@ static void parallel_rows(int64_t n, F fn)
     for (unsigned t = 1; t < team; ++t) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
-}
-
-// ---- S16: the double-precision DFT behind the Bluestein tables ------------------------------------
-namespace {
-int smallest_prime_factor(int64_t n)
-{
-    for (int64_t f = 2; f * f <= n; ++f)
-        if (n % f == 0) return (int)f;
-    return (int)n;
-}
-
-int largest_prime_factor(int64_t n)
-{
-    int l = 1;
-    while (n > 1) {
-        const int f = smallest_prime_factor(n);
-        l = std::max(l, f);
-        n /= f;
-    }
-    return l;
-}
-
-// levels of the recursion for one length, with the twiddle table T_n' of every level (read-only afterwards,
-// so that many host threads can transform their own sequences at once)
-struct DftPlanD {
-    std::vector<int64_t> ns;
-    std::vector<int> ps;
-    std::vector<std::vector<double>> twr, twi;
-    explicit DftPlanD(int64_t n)
-    {
-        while (n > 1) {
-            const int p = smallest_prime_factor(n);
-            ns.push_back(n);
-            ps.push_back(p);
-            std::vector<double> r((size_t)n), i((size_t)n);
-            for (int64_t j = 0; j < n; ++j) twiddle_d(j, n, r[(size_t)j], i[(size_t)j]);
-            twr.push_back(std::move(r));
-            twi.push_back(std::move(i));
-            n /= p;
-        }
-    }
-    // out-of-place: in (stride `st`) -> out[0..n), tmp[0..n) is scratch
-    void rec(size_t level, const double *ir, const double *ii, int64_t st, double *outr, double *outi, double *tr, double *ti) const
-    {
-        if (level == ns.size()) {
-            outr[0] = ir[0];
-            outi[0] = ii[0];
-            return;
-        }
-        const int64_t n = ns[level], m = n / ps[level];
-        const int p = ps[level];
-        for (int q = 0; q < p; ++q)
-            rec(level + 1, ir + q * st, ii + q * st, st * p, tr + q * m, ti + q * m, outr + q * m, outi + q * m);
-        const double *wr = twr[level].data(), *wi = twi[level].data();
-        // X[k] = F_0[k mod m] + sum_q W_n^{qk} F_q[k mod m]; the indices k mod m and q k mod n are carried along
-        // instead of divided out (the values, and so every rounding, are those of the plain formula)
-        int64_t jq[32]; // q k mod n for q = 1 .. p - 1 (p <= 31)
-        for (int q = 1; q < p; ++q) jq[q] = 0;
-        for (int64_t k = 0, km = 0; k < n; ++k) {
-            double ar = tr[km], ai = ti[km];
-            for (int q = 1; q < p; ++q) {
-                const int64_t j = jq[q];
-                const double fr = tr[q * m + km], fi = ti[q * m + km];
-                ar = ar + (wr[j] * fr - wi[j] * fi);
-                ai = ai + (wr[j] * fi + wi[j] * fr);
-                jq[q] = j + q >= n ? j + q - n : j + q;
-            }
-            outr[k] = ar;
-            outi[k] = ai;
-            if (++km == m) km = 0;
-        }
-    }
-    // in place on re / im [n]; scratch: 2 n doubles each
-    void run(double *re, double *im, std::vector<double> &scratch) const
-    {
-        const int64_t n = ns.empty() ? 1 : ns[0];
-        scratch.resize((size_t)(4 * n));
-        double *outr = scratch.data(), *outi = outr + n, *tr = outi + n, *ti = tr + n;
-        rec(0, re, im, 1, outr, outi, tr, ti);
-        std::memcpy(re, outr, sizeof(double) * (size_t)n);
-        std::memcpy(im, outi, sizeof(double) * (size_t)n);
-    }
-};
-} // namespace
-
-void dft_generic_d(double *re, double *im, int64_t n)
-{
-    DftPlanD plan(n);
-    std::vector<double> scratch;
-    plan.run(re, im, scratch);
-}
-
-// S15: tables of the chirp-z forward transform (see build_plan)
-static void build_bluestein_tables(HostPlan &p)
-{
-    const int64_t n = p.n, n1 = p.n1, n2 = p.n2, big_l = p.bz_l, nk = p.kmax - p.kmin;
-    auto chirp = [&](int64_t m, double &re, double &im) { // w[m] = e^{-i pi m^2 / N} = T_{2N}[m^2 mod 2N]
-        const int64_t mm = m < 0 ? -m : m;
-        // m^2 mod 2N exactly: in 64 bits while m^2 fits (|m| < 3.03e9), in 128 bits beyond
-        const int64_t r = mm < 3037000499ll ? (mm * mm) % (2 * n) : (int64_t)(((__int128)mm * mm) % (2 * n));
-        twiddle_d(r, 2 * n, re, im);
-    };
-    // w in double for n in [0, N): the chirp table, w[k] / L and the lags b[m] = conj(w[|m|]) all take their values here
-    // (every lag has |m| < N), so each phase is evaluated once
-    std::vector<double> wd_r((size_t)n), wd_i((size_t)n);
-    parallel_rows((n + 65535) / 65536, [&](int64_t blk) {
-        for (int64_t i = blk * 65536, e = std::min<int64_t>(n, (blk + 1) * 65536); i < e; ++i) chirp(i, wd_r[(size_t)i], wd_i[(size_t)i]);
-    });
-    p.bz_w.assign((size_t)big_l, HostCf{0.0f, 0.0f});
-    p.bz_tl.resize((size_t)big_l);
-    parallel_rows(n1, [&](int64_t r) {
-        for (int64_t t = 0; t < n2; ++t) {
-            const int64_t idx = r + n1 * t;
-            if (idx < n) p.bz_w[(size_t)(r * n2 + t)] = {(float)wd_r[(size_t)idx], (float)wd_i[(size_t)idx]};
-        }
-    });
-    p.bz_wk.resize((size_t)nk);
-    for (int64_t k = p.kmin; k < p.kmax; ++k)
-        p.bz_wk[(size_t)(k - p.kmin)] = {(float)(wd_r[(size_t)k] / (double)big_l), (float)(wd_i[(size_t)k] / (double)big_l)};
-    // Bhat = DFT_L(b), b[m mod L] = conj(w[m]) for the lags m in [kmin - (N - 1), kmax - 1], in double:
-    // rows (length n2 over t for every residue r), times W_L^{r k2}, columns (length n1 over r for every k2)
-    std::vector<double> yr((size_t)big_l, 0.0), yi((size_t)big_l, 0.0); // [r][t], then [r][k2]
-    const int64_t mlo = p.kmin - (n - 1), mhi = p.kmax - 1;
-    {
-        const int64_t count = mhi - mlo + 1, blk = 1 << 16; // every lag has its own slot: blocks of lags side by side
-        parallel_rows((count + blk - 1) / blk, [&](int64_t b) {
-            for (int64_t m = mlo + b * blk, e = std::min(mhi + 1, mlo + (b + 1) * blk); m < e; ++m) {
-                const int64_t idx = ((m % big_l) + big_l) % big_l, mm = m < 0 ? -m : m;
-                yr[(size_t)((idx % n1) * n2 + idx / n1)] = wd_r[(size_t)mm];
-                yi[(size_t)((idx % n1) * n2 + idx / n1)] = -wd_i[(size_t)mm];
-            }
-        });
-    }
-    std::vector<double>().swap(wd_r);
-    std::vector<double>().swap(wd_i);
-    const DftPlanD rows_plan(n2), cols_plan(n1);
-    parallel_rows(n1, [&](int64_t r) {
-        std::vector<double> scratch;
-        double *re = yr.data() + r * n2, *im = yi.data() + r * n2;
-        rows_plan.run(re, im, scratch);
-        for (int64_t k2 = 0; k2 < n2; ++k2) {
-            double wr, wi;
-            twiddle_d((r * k2) % big_l, big_l, wr, wi); // W_L^{r k2}: in double for Bhat, rounded for the device's T_L table
-            p.bz_tl[(size_t)(r * n2 + k2)] = {(float)wr, (float)wi};
-            const double gr = re[k2], gi = im[k2];
-            re[k2] = gr * wr - gi * wi;
-            im[k2] = gr * wi + gi * wr;
-        }
-    });
-    p.bz_bhat.resize((size_t)big_l);
-    // columns in blocks of 8: a cache line of eight doubles of every row feeds eight column transforms
-    constexpr int64_t kCb = 8;
-    parallel_rows((n2 + kCb - 1) / kCb, [&](int64_t cb) {
-        const int64_t k0 = cb * kCb, nc = std::min(kCb, n2 - k0);
-        std::vector<double> scratch, cr((size_t)(kCb * n1)), ci((size_t)(kCb * n1));
-        for (int64_t r = 0; r < n1; ++r)
-            for (int64_t c = 0; c < nc; ++c) {
-                cr[(size_t)(c * n1 + r)] = yr[(size_t)(r * n2 + k0 + c)];
-                ci[(size_t)(c * n1 + r)] = yi[(size_t)(r * n2 + k0 + c)];
-            }
-        for (int64_t c = 0; c < nc; ++c) cols_plan.run(cr.data() + c * n1, ci.data() + c * n1, scratch);
-        for (int64_t k1 = 0; k1 < n1; ++k1)
-            for (int64_t c = 0; c < nc; ++c)
-                p.bz_bhat[(size_t)(k1 * n2 + k0 + c)] = {(float)cr[(size_t)(c * n1 + k1)], (float)ci[(size_t)(c * n1 + k1)]};
-    });
 }
 
 bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bool force_bluestein, unsigned conv)
@@ -458,11 +293,10 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
     }
     if (p.bluestein) {
         // S15: a chirp-z convolution of length L = n1 * 6300 >= N + (kmax - kmin) - 1; the column DFT over the
-        // n1 residues is dense (matrix cores), so n1 only has to keep the host's table DFT cheap: its prime
-        // factors stay at or below 31
+        // n1 residues is dense (matrix cores) and the tables are generated by the same kernels (k_bluestein.hip),
+        // so n1 is simply the smallest that fits
         const int64_t need = n + (kmax - kmin) - 1;
         n1 = (need + 6299) / 6300;
-        while (largest_prime_factor(n1) > 31) ++n1;
         p.bz_l = n1 * 6300;
     }
     for (int64_t d = 1; !p.bluestein && d <= n; ++d) {
@@ -531,9 +365,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
             len /= g.first * g.second;
         }
     }
-    if (p.bluestein) {
-        build_bluestein_tables(p);
-    } else {
+    if (!p.bluestein) { // the chirp-z path's own tables (chirp, T_L, Bhat, w[k] / L) are generated on the device
         p.tw_big.resize((size_t)n1 * p.h);
         parallel_rows(n1, [&](int64_t a) {
             for (int64_t k2 = 0; k2 < p.h; ++k2) p.tw_big[(size_t)(a * p.h + k2)] = twiddle_f(a * k2, n);
@@ -798,12 +630,8 @@ extern "C" int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein,
     out8[0] = fnv1a(p.tw_n2.data(), p.tw_n2.size() * 8);
     out8[1] = fnv1a(p.tw_n1.data(), p.tw_n1.size() * 8);
     out8[2] = fnv1a(p.tw_big.data(), p.tw_big.size() * 8);
-    if (p.bluestein) { // the chirp-z tables stand where T_N stands for 7-smooth lengths
-        uint64_t hb = fnv1a(p.bz_w.data(), p.bz_w.size() * 8);
-        hb = fnv1a(p.bz_tl.data(), p.bz_tl.size() * 8, hb);
-        hb = fnv1a(p.bz_bhat.data(), p.bz_bhat.size() * 8, hb);
-        out8[2] = fnv1a(p.bz_wk.data(), p.bz_wk.size() * 8, hb);
-    }
+    // chirp-z lengths: no T_N (slot 2 = the hash of nothing); the tables that stand in its place are generated on the
+    // device and checked there (hpfw_gpu_chirpz_table_checksums)
     out8[3] = fnv1a(p.pos_n2.data(), p.pos_n2.size() * 4);
     uint64_t h = fnv1a(p.start, sizeof(p.start));
     h = fnv1a(p.lg, sizeof(p.lg), h);

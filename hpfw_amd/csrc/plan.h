@@ -47,10 +47,7 @@ struct HostPlan {
     // length bz_l = n1 * n2 >= N + (kmax - kmin) - 1, n2 = 6300; n1 need not be smooth
     bool bluestein = false;
     int64_t bz_l = 0;
-    std::vector<HostCf> bz_w;               // [n1][n2]: w[r + n1 t] = e^{-i pi n^2 / N}, 0 from n = N on
-    std::vector<HostCf> bz_tl;              // [n1][n2]: T_L[r k2]
-    std::vector<HostCf> bz_bhat;            // [n1][n2]: DFT_L(conj chirp)[n2 k1 + k2]
-    std::vector<HostCf> bz_wk;              // [kmax - kmin]: w[k] / L
+    // its tables (chirp, T_L, Bhat, w[k] / L) are generated on the device: kernels.h BzArgs
 };
 
 // Returns false (and a reason) when the clip length is unsupported.
@@ -68,9 +65,6 @@ enum : unsigned {
 // force_bluestein: take the chirp-z forward transform even when the length is 7-smooth (tests)
 bool build_plan(int64_t n_samples, HostPlan &out, std::string &why, bool geometry_only = false,
                 bool force_bluestein = false, unsigned conventions = 0);
-// S16: DFT of length n in double, in place (n's prime factors at most 31): recursive decimation in time by
-// the smallest prime factor, X[k] = F_0[k mod m] + sum_q W_n^{qk} F_q[k mod m] in ascending q, plain products
-void dft_generic_d(double *re, double *im, int64_t n);
 
 // the row transform alone for frames of n2 samples (STFT of the Mel front-end): radix, groups, rows_gtw,
 // pos_n2 of `out`, and tw_big = two rows of ones

@@ -275,10 +275,16 @@ int hpfw_gpu_get_kernel_timing(hpfw_gpu *h, const char **names, float *ms, int *
 
 /* ---- host-only diagnostic: FNV-1a checksums of the eight groups of constant tables built for
  * clips of n_samples samples (twiddles, digit reversal, bands, window*chirp, chirp spectra).
- * No device is touched. */
+ * No device is touched.  (For a chirp-z length slot 2, T_N, is the hash of nothing: see hpfw_gpu_chirpz_table.) */
 int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8);
 /* the same with the chirp-z forward transform forced and under given conventions (HPFW_CONV_*) */
 int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein, unsigned conventions, uint64_t *out8);
+
+/* ---- diagnostic: the tables of the chirp-z forward transform (clip lengths with a prime factor above 7), which are
+ * generated on the device.  which: 0 = chirp w [n1][n2], 1 = T_L [n1][n2], 2 = Bhat [n1][n2],
+ * 3 = w[k] / L [kmax - kmin]; complex as (re, im) float pairs.  *count = floats in the table; out may be NULL to
+ * ask for the count only.  HPFW_E_INVALID for a 7-smooth length (unless HPFW_FORCE_BLUESTEIN is set). */
+int hpfw_gpu_chirpz_table(hpfw_gpu *h, int64_t n_samples, int which, float *out, int64_t capacity, int64_t *count);
 
 /* ---- legacy FFI: modules/python/parallel_collector_wrapper.hpp:12-38, same shapes --------- */
 typedef struct {

@@ -66,7 +66,8 @@ static void twiddle_d(int64_t m, int64_t n, double *re, double *im)
     int64_t r = a - (int64_t)oct * n;
     int64_t t = (oct & 1) ? (n - r) : r;
     double alpha = M_PI * (double)t / (double)(4 * n);
-    double ca = cos(alpha), sa = sin(alpha), c, s;
+    double ca, sa, c, s;
+    sincos(alpha, &sa, &ca); /* glibc's sincos here and in plan.cpp: cos() and sin() differ from it in the last bit for 0.1 % of arguments */
     switch (oct) {
     case 0: c = ca; s = sa; break;
     case 1: c = sa; s = ca; break;
@@ -456,8 +457,7 @@ static void chirp_d(int64_t m, int64_t big_m, double *c, double *s)
     int64_t mm = m < 0 ? -m : m;
     int64_t r = (int64_t)(((__int128)3 * mm * mm) % (2 * big_m));
     double ang = M_PI * (double)r / (double)big_m;
-    *c = cos(ang);
-    *s = sin(ang);
+    sincos(ang, s, c);
 }
 
 static int make_bluestein(hpfw_oracle_plan *p)
@@ -515,173 +515,134 @@ static int make_bluestein(hpfw_oracle_plan *p)
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* S16: DFT of length n in double (prime factors of n at most 31), used only to build tables:    */
-/* recursive decimation in time by the smallest prime factor p (m = n / p):                       */
-/*   X[k] = F_0[k mod m] + sum_{q=1}^{p-1} W_n^{q k} F_q[k mod m],  F_q = DFT_m(x[q + p t]),     */
-/* the sum in ascending q, every product as (wr fr - wi fi, wr fi + wi fr), W from twiddle_d.     */
+/* S15 tables.  X[k] = w[k] sum_n (x[n] w[n]) conj(w[k - n]), w[n] = e^{-i pi n^2 / N}: a convolution with the   */
+/* lags m = k - n in [kmin - (N - 1), kmax - 1], evaluated cyclically at length L >= N + (kmax - kmin) - 1.      */
+/* The product generates these tables on the device, one pass of double arithmetic per element and one forward   */
+/* transform of the lags in float; this is the same arithmetic written out on the CPU.                           */
 /* ------------------------------------------------------------------------------------------ */
-static int smallest_prime_factor(int64_t n)
+
+/* S2b: cos and sin of x in [0, pi/4] in double: Taylor polynomials in x^2 as explicit fma chains, coefficients the
+ * correctly rounded (-1)^j / k!.  IEEE multiply and fma only, so a CPU and a GPU agree bit for bit. */
+static void bz_cos_sin(double x, double *c, double *s)
 {
-    for (int64_t f = 2; f * f <= n; ++f)
-        if (n % f == 0) return (int)f;
-    return (int)n;
+    static const double sc[8] = {0x1.952c77030ad4ap-49, -0x1.ae7f3e733b81fp-41, 0x1.6124613a86d09p-33, -0x1.ae64567f544e4p-26,
+                                 0x1.71de3a556c734p-19, -0x1.a01a01a01a01ap-13, 0x1.1111111111111p-7,   -0x1.5555555555555p-3};
+    static const double cc[9] = {-0x1.6827863b97d97p-53, 0x1.ae7f3e733b81fp-45,  -0x1.93974a8c07c9dp-37,
+                                 0x1.1eed8eff8d898p-29,  -0x1.27e4fb7789f5cp-22, 0x1.a01a01a01a01ap-16,
+                                 -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5,   -0.5};
+    double z = x * x, ps = sc[0], pc = cc[0];
+    for (int i = 1; i < 8; ++i) ps = fma(ps, z, sc[i]);
+    for (int i = 1; i < 9; ++i) pc = fma(pc, z, cc[i]);
+    *s = fma(x * z, ps, x);
+    *c = fma(z, pc, 1.0);
 }
 
-typedef struct {
-    int levels;
-    int64_t n[64];
-    int p[64];
-    double *wr[64], *wi[64];
-} dftd_plan;
-
-static void dftd_init(dftd_plan *d, int64_t n)
+/* e^{-2 pi i m / n}, 0 <= m < n: the octant reduction of S2, S2b for the octant's angle */
+static void bz_unit(int64_t m, int64_t n, double *re, double *im)
 {
-    d->levels = 0;
-    while (n > 1) {
-        int p = smallest_prime_factor(n), l = d->levels++;
-        d->n[l] = n;
-        d->p[l] = p;
-        d->wr[l] = (double *)malloc(sizeof(double) * (size_t)n);
-        d->wi[l] = (double *)malloc(sizeof(double) * (size_t)n);
-        for (int64_t j = 0; j < n; ++j) twiddle_d(j, n, &d->wr[l][j], &d->wi[l][j]);
-        n /= p;
+    int64_t a = 8 * m;
+    int oct = (int)(a / n);
+    int64_t r = a - (int64_t)oct * n;
+    int64_t t = (oct & 1) ? (n - r) : r;
+    double alpha = M_PI * (double)t / (double)(4 * n);
+    double ca, sa, c, s;
+    bz_cos_sin(alpha, &ca, &sa);
+    switch (oct) {
+    case 0: c = ca; s = sa; break;
+    case 1: c = sa; s = ca; break;
+    case 2: c = -sa; s = ca; break;
+    case 3: c = -ca; s = sa; break;
+    case 4: c = -ca; s = -sa; break;
+    case 5: c = -sa; s = -ca; break;
+    case 6: c = sa; s = -ca; break;
+    default: c = ca; s = -sa; break;
     }
+    *re = c;
+    *im = -s;
 }
 
-static void dftd_free(dftd_plan *d)
-{
-    for (int l = 0; l < d->levels; ++l) {
-        free(d->wr[l]);
-        free(d->wi[l]);
-    }
-}
+/* w[m] = e^{-i pi m^2 / N} = e^{-2 pi i (m^2 mod 2N) / 2N}, m >= 0 */
+static void bz_chirp_d(int64_t m, int64_t n, double *re, double *im) { bz_unit((m * m) % (2 * n), 2 * n, re, im); }
 
-/* in (stride st) -> out[0..n); tmp[0..n) scratch */
-static void dftd_rec(const dftd_plan *d, int level, const double *ir, const double *ii, int64_t st, double *outr,
-                     double *outi, double *tr, double *ti)
-{
-    if (level == d->levels) {
-        outr[0] = ir[0];
-        outi[0] = ii[0];
-        return;
-    }
-    int64_t n = d->n[level];
-    int p = d->p[level];
-    int64_t m = n / p;
-    for (int q = 0; q < p; ++q)
-        dftd_rec(d, level + 1, ir + q * st, ii + q * st, st * p, tr + q * m, ti + q * m, outr + q * m, outi + q * m);
-    const double *wr = d->wr[level], *wi = d->wi[level];
-    for (int64_t k = 0; k < n; ++k) {
-        int64_t km = k % m;
-        double ar = tr[km], ai = ti[km];
-        for (int q = 1; q < p; ++q) {
-            int64_t j = (q * k) % n;
-            double fr = tr[q * m + km], fi = ti[q * m + km];
-            ar = ar + (wr[j] * fr - wi[j] * fi);
-            ai = ai + (wr[j] * fi + wi[j] * fr);
-        }
-        outr[k] = ar;
-        outi[k] = ai;
-    }
-}
-
-/* in place on re / im [n]; scratch holds 4 n doubles */
-static void dftd_run(const dftd_plan *d, double *re, double *im, double *scratch)
-{
-    int64_t n = d->levels ? d->n[0] : 1;
-    double *outr = scratch, *outi = outr + n, *tr = outi + n, *ti = tr + n;
-    dftd_rec(d, 0, re, im, 1, outr, outi, tr, ti);
-    memcpy(re, outr, sizeof(double) * (size_t)n);
-    memcpy(im, outi, sizeof(double) * (size_t)n);
-}
-
-void hpfw_oracle_dft_double(double *re, double *im, int64_t n)
-{
-    dftd_plan d;
-    dftd_init(&d, n);
-    double *scratch = (double *)malloc(sizeof(double) * (size_t)(4 * n));
-    dftd_run(&d, re, im, scratch);
-    free(scratch);
-    dftd_free(&d);
-}
-
-/* w[m] = e^{-i pi m^2 / N} = T_{2N}[m^2 mod 2N] in double */
-static void bz_chirp_d(int64_t m, int64_t n, double *re, double *im)
-{
-    int64_t mm = m < 0 ? -m : m;
-    twiddle_d((int64_t)(((__int128)mm * mm) % (2 * n)), 2 * n, re, im);
-}
-
-/* S15 tables.  X[k] = w[k] sum_n (x[n] w[n]) conj(w[k - n]): a convolution with the lags
- * m = k - n in [kmin - (N - 1), kmax - 1], evaluated cyclically at length L >= N + (kmax - kmin) - 1. */
 static void make_forward_bluestein(hpfw_oracle_plan *p)
 {
     const int64_t n = p->info.n_samples, n1 = p->info.n1, n2 = p->info.n2, big_l = p->bz_l;
     const int64_t nk = p->info.kmax - p->info.kmin;
     p->bz_w = (cf *)calloc((size_t)big_l, sizeof(cf));
     p->bz_tl = (cf *)malloc(sizeof(cf) * (size_t)big_l);
+    p->bz_wk = (cf *)malloc(sizeof(cf) * (size_t)nk);
+    cf *b = (cf *)calloc((size_t)big_l, sizeof(cf)); /* the lags by residue: b[r][t] stands at the cyclic index r + n1 t */
+    double c, s;
+    for (int64_t k = p->info.kmin; k < p->info.kmax; ++k) {
+        bz_chirp_d(k, n, &c, &s);
+        p->bz_wk[k - p->info.kmin].r = (float)(c / (double)big_l);
+        p->bz_wk[k - p->info.kmin].i = (float)(s / (double)big_l);
+    }
     for (int64_t r = 0; r < n1; ++r)
         for (int64_t t = 0; t < n2; ++t) {
-            int64_t idx = r + n1 * t;
+            int64_t i = r * n2 + t, idx = r + n1 * t;
             if (idx < n) {
-                double c, s2;
-                bz_chirp_d(idx, n, &c, &s2);
-                p->bz_w[r * n2 + t].r = (float)c;
-                p->bz_w[r * n2 + t].i = (float)s2;
+                bz_chirp_d(idx, n, &c, &s);
+                p->bz_w[i].r = (float)c;
+                p->bz_w[i].i = (float)s;
+                if (idx <= p->info.kmax - 1) { /* the lag m = idx: conj(w[m]) */
+                    b[i].r = (float)c;
+                    b[i].i = (float)(-s);
+                }
             }
-            hpfw_oracle_twiddle(r * t, big_l, &p->bz_tl[r * n2 + t].r, &p->bz_tl[r * n2 + t].i);
+            int64_t neg = big_l - idx; /* the lag m = idx - L */
+            if (neg <= n - 1 - p->info.kmin) {
+                bz_chirp_d(neg, n, &c, &s);
+                b[i].r = (float)c;
+                b[i].i = (float)(-s);
+            }
+            bz_unit((r * t) % big_l, big_l, &c, &s);
+            p->bz_tl[i].r = (float)c;
+            p->bz_tl[i].i = (float)s;
         }
-    p->bz_wk = (cf *)malloc(sizeof(cf) * (size_t)nk);
-    for (int64_t k = p->info.kmin; k < p->info.kmax; ++k) {
-        double c, s2;
-        bz_chirp_d(k, n, &c, &s2);
-        p->bz_wk[k - p->info.kmin].r = (float)(c / (double)big_l);
-        p->bz_wk[k - p->info.kmin].i = (float)(s2 / (double)big_l);
-    }
-    double *yr = (double *)calloc((size_t)big_l, sizeof(double)), *yi = (double *)calloc((size_t)big_l, sizeof(double));
-    for (int64_t m = p->info.kmin - (n - 1); m <= p->info.kmax - 1; ++m) {
-        int64_t idx = ((m % big_l) + big_l) % big_l;
-        double c, s2;
-        bz_chirp_d(m, n, &c, &s2);
-        yr[(idx % n1) * n2 + idx / n1] = c;
-        yi[(idx % n1) * n2 + idx / n1] = -s2;
-    }
-    dftd_plan rows, cols;
-    dftd_init(&rows, n2);
-    dftd_init(&cols, n1);
-    int64_t big = n1 > n2 ? n1 : n2;
-    double *scratch = (double *)malloc(sizeof(double) * (size_t)(4 * big));
+    /* Bhat = the first transform of spectrum_bluestein applied to the lags: rows over t (S3/S4), T_L, the column
+     * chain over the residues (S6) */
+    cf *z = (cf *)malloc(sizeof(cf) * (size_t)n2);
     for (int64_t r = 0; r < n1; ++r) {
-        double *re = yr + r * n2, *im = yi + r * n2;
-        dftd_run(&rows, re, im, scratch);
-        for (int64_t k2 = 0; k2 < n2; ++k2) {
-            double wr, wi;
-            twiddle_d((r * k2) % big_l, big_l, &wr, &wi);
-            double gr = re[k2], gi = im[k2];
-            re[k2] = gr * wr - gi * wi;
-            im[k2] = gr * wi + gi * wr;
-        }
+        memcpy(z, b + r * n2, sizeof(cf) * (size_t)n2);
+        fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
+        for (int64_t k2 = 0; k2 < n2; ++k2) b[r * n2 + k2] = c_mul(z[p->pos_n2[k2]], p->bz_tl[r * n2 + k2]);
     }
+    free(z);
     p->bz_bhat = (cf *)malloc(sizeof(cf) * (size_t)big_l);
-    double *cr = (double *)malloc(sizeof(double) * (size_t)n1), *ci = (double *)malloc(sizeof(double) * (size_t)n1);
-    for (int64_t k2 = 0; k2 < n2; ++k2) {
+    /* per (k1, k2) the chain runs over r in ascending order; written with k2 innermost so that it vectorises */
+    float *yr = (float *)malloc(sizeof(float) * (size_t)big_l), *yi = (float *)malloc(sizeof(float) * (size_t)big_l);
+    for (int64_t i = 0; i < big_l; ++i) {
+        yr[i] = b[i].r;
+        yi[i] = b[i].i;
+    }
+    float *ar = (float *)malloc(sizeof(float) * (size_t)n2), *ai = (float *)malloc(sizeof(float) * (size_t)n2);
+    for (int64_t k1 = 0; k1 < n1; ++k1) {
+        memset(ar, 0, sizeof(float) * (size_t)n2);
+        memset(ai, 0, sizeof(float) * (size_t)n2);
+        int64_t idx = 0; /* (r k1) mod n1 */
         for (int64_t r = 0; r < n1; ++r) {
-            cr[r] = yr[r * n2 + k2];
-            ci[r] = yi[r * n2 + k2];
+            const float dr = p->tw_n1[idx].r, di = p->tw_n1[idx].i, ndi = -di;
+            const float *pr = yr + r * n2, *pi = yi + r * n2;
+            for (int64_t k2 = 0; k2 < n2; ++k2) {
+                ar[k2] = fmaf(dr, pr[k2], ar[k2]);
+                ar[k2] = fmaf(ndi, pi[k2], ar[k2]);
+                ai[k2] = fmaf(di, pr[k2], ai[k2]);
+                ai[k2] = fmaf(dr, pi[k2], ai[k2]);
+            }
+            idx += k1;
+            if (idx >= n1) idx -= n1;
         }
-        dftd_run(&cols, cr, ci, scratch);
-        for (int64_t k1 = 0; k1 < n1; ++k1) {
-            p->bz_bhat[k1 * n2 + k2].r = (float)cr[k1];
-            p->bz_bhat[k1 * n2 + k2].i = (float)ci[k1];
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            p->bz_bhat[k1 * n2 + k2].r = ar[k2];
+            p->bz_bhat[k1 * n2 + k2].i = ai[k2];
         }
     }
-    free(cr);
-    free(ci);
-    free(scratch);
-    dftd_free(&rows);
-    dftd_free(&cols);
+    free(ar);
+    free(ai);
     free(yr);
     free(yi);
+    free(b);
 }
 
 hpfw_oracle_plan *hpfw_oracle_plan_create2(int64_t n, int force_bluestein) { return hpfw_oracle_plan_create3(n, force_bluestein, 0); }
@@ -705,17 +666,8 @@ hpfw_oracle_plan *hpfw_oracle_plan_create3(int64_t n, int force_bluestein, unsig
             free(p);
             return NULL;
         }
-        /* n2 = 6300; n1 = the smallest integer >= (N + nk - 1) / 6300 whose prime factors are <= 31 */
+        /* n2 = 6300; n1 = the smallest integer >= (N + nk - 1) / 6300 (the column transform is a dense chain: any n1) */
         int64_t need = n + (p->info.kmax - p->info.kmin) - 1, n1 = (need + 6299) / 6300;
-        for (;; ++n1) {
-            int64_t r = n1, big = 1;
-            while (r > 1) {
-                int f = smallest_prime_factor(r);
-                if (f > big) big = f;
-                r /= f;
-            }
-            if (big <= 31) break;
-        }
         if (n1 > 8192) {
             free(p);
             return NULL;
@@ -1479,18 +1431,23 @@ static uint64_t fnv1a(const void *data, size_t bytes, uint64_t h)
     return h;
 }
 
+/* the chirp-z tables (0 w, 1 T_L, 2 Bhat: [n1][n2]; 3 w[k] / L: [kmax - kmin]) as (re, im) floats; returns the
+ * number of floats, 0 for a plan without them; out may be NULL */
+int64_t hpfw_oracle_chirpz_table(const hpfw_oracle_plan *p, int which, float *out)
+{
+    if (!p->bluestein || which < 0 || which > 3) return 0;
+    const cf *tab[4] = {p->bz_w, p->bz_tl, p->bz_bhat, p->bz_wk};
+    int64_t count = 2 * (which == 3 ? p->info.kmax - p->info.kmin : p->bz_l);
+    if (out) memcpy(out, tab[which], sizeof(float) * (size_t)count);
+    return count;
+}
+
 void hpfw_oracle_plan_checksum(const hpfw_oracle_plan *p, uint64_t *out8)
 {
     const uint64_t seed = 1469598103934665603ULL;
     out8[0] = fnv1a(p->tw_n2, (size_t)p->info.n2 * 8, seed);
     out8[1] = fnv1a(p->tw_n1, (size_t)p->info.n1 * 8, seed);
     out8[2] = p->tw_big ? fnv1a(p->tw_big, (size_t)(p->info.n1 * p->info.h) * 8, seed) : seed;
-    if (p->bluestein) { /* the chirp-z tables stand where T_N stands for 7-smooth lengths */
-        uint64_t hb = fnv1a(p->bz_w, (size_t)p->bz_l * 8, seed);
-        hb = fnv1a(p->bz_tl, (size_t)p->bz_l * 8, hb);
-        hb = fnv1a(p->bz_bhat, (size_t)p->bz_l * 8, hb);
-        out8[2] = fnv1a(p->bz_wk, (size_t)(p->info.kmax - p->info.kmin) * 8, hb);
-    }
     out8[3] = fnv1a(p->pos_n2, (size_t)p->info.n2 * 4, seed);
     uint64_t h = fnv1a(p->start, sizeof(p->start), seed);
     h = fnv1a(p->lg, sizeof(p->lg), h);

@@ -62,8 +62,9 @@ hpfw_oracle_plan *hpfw_oracle_plan_create2(int64_t n_samples, int force_bluestei
 #define HPFW_O_CONV_FLOAT_GEOMETRY 4u /* fftres, f_j, posit_j, Lg_j in float (essentia's Real), not double */
 #define HPFW_O_CONV_NO_IFFT_SCALE 8u  /* band transforms without the inverse FFT's 1/M                     */
 hpfw_oracle_plan *hpfw_oracle_plan_create3(int64_t n_samples, int force_bluestein, unsigned conventions);
-/* S16: the double-precision DFT the chirp-z tables are built with, in place */
-void hpfw_oracle_dft_double(double *re, double *im, int64_t n);
+/* S15: the chirp-z tables (0 w, 1 T_L, 2 Bhat: [n1][n2]; 3 w[k] / L: [kmax - kmin]) as (re, im) floats; returns the
+ * number of floats (0 for a plan without them); out may be NULL */
+int64_t hpfw_oracle_chirpz_table(const hpfw_oracle_plan *p, int which, float *out);
 void hpfw_oracle_plan_destroy(hpfw_oracle_plan *p);
 void hpfw_oracle_plan_get_info(const hpfw_oracle_plan *p, hpfw_oracle_plan_info *out);
 /* per band j = 0..120: slice start in the forward DFT, window length Lg_j, Bluestein size P_j */

@@ -51,7 +51,8 @@ def lib():
         L.hpfw_oracle_plan_create2.argtypes = [i64, i32]
         L.hpfw_oracle_plan_create3.restype = vp
         L.hpfw_oracle_plan_create3.argtypes = [i64, i32, ctypes.c_uint32]
-        L.hpfw_oracle_dft_double.argtypes = [vp, vp, i64]
+        L.hpfw_oracle_chirpz_table.restype = i64
+        L.hpfw_oracle_chirpz_table.argtypes = [vp, i32, vp]
         L.hpfw_oracle_plan_destroy.argtypes = [vp]
         L.hpfw_oracle_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
         L.hpfw_oracle_plan_bands.argtypes = [vp, vp, vp, vp]
@@ -120,6 +121,15 @@ class Plan:
         if getattr(self, "_h", None):
             lib().hpfw_oracle_plan_destroy(self._h)
             self._h = None
+
+    def chirpz_table(self, which):
+        """S15 table of a chirp-z plan as complex64: 0 w, 1 T_L, 2 Bhat ([n1 * n2]), 3 w[k] / L ([kmax - kmin])"""
+        count = lib().hpfw_oracle_chirpz_table(self._h, which, None)
+        if count == 0:
+            raise ValueError("no chirp-z tables: the length takes the mixed-radix transform")
+        out = np.zeros(count, np.float32)
+        lib().hpfw_oracle_chirpz_table(self._h, which, _p(out))
+        return out.view(np.complex64)
 
     # ---- stages -------------------------------------------------------------------------
     def spectrum(self, pcm):
@@ -281,14 +291,6 @@ def vote_windows(keys, db_off):
 
 def search_votes(db_hp, db_off, q_hp, win=64, nn=5):
     return vote_windows(knn_windows(db_hp, db_off, q_hp, win, nn), db_off)
-
-
-def dft_double(x):
-    """S16: the table-building DFT in double"""
-    x = np.asarray(x, np.complex128)
-    re, im = np.ascontiguousarray(x.real), np.ascontiguousarray(x.imag)
-    lib().hpfw_oracle_dft_double(_p(re), _p(im), x.size)
-    return re + 1j * im
 
 
 def log10(x):

@@ -504,6 +504,20 @@ def test_arbitrary_clip_lengths(gpu, torch_cuda, oracle, filters, n):
         assert np.array_equal(gpu.extract(clips), np.stack([plan.extract(filters, c) for c in clips]))
 
 
+@pytest.mark.parametrize("n", [99991, 352799, 1323001])
+def test_chirpz_tables_generated_on_device(gpu, oracle, n):
+    """S15: chirp, T_L, Bhat and w[k] / L of a clip length are generated on the device (double arithmetic with an own
+    cosine / sine, S2b, then one forward transform of the lags): each table identical to the oracle's, bit for bit"""
+    plan = oracle.Plan(n)
+    for which, name in enumerate(("w", "T_L", "Bhat", "w[k]/L")):
+        got, want = gpu.chirpz_table(n, which), plan.chirpz_table(which)
+        assert got.shape == want.shape, name
+        bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
+        assert bad.size == 0, (name, bad.size, bad[:5], got[bad[:5]], want[bad[:5]])
+    with pytest.raises(hpfw_amd.HpfwError):
+        gpu.chirpz_table(132300, 0)                               # a 7-smooth length has none
+
+
 def test_chirpz_path_agrees_with_mixed_radix_path(oracle, filters, monkeypatch):
     """a 7-smooth length through both forward transforms (HPFW_FORCE_BLUESTEIN=1): each bit-exact against its
     own oracle twin; the two spectrograms agree to float rounding and the hashprints differ in a handful of

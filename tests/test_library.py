@@ -48,9 +48,10 @@ def test_plan_tables_identical_to_oracle(oracle, n):
 
 @pytest.mark.parametrize("n", [1323001, 352799, 99991, -220500])
 def test_chirpz_plan_tables_identical_to_oracle(oracle, n):
-    """lengths with a prime factor above 7 (and, negative, a 7-smooth length forced down the same path): chirp,
-    T_L, the double-precision DFT of the conjugate chirp and w[k] / L are built independently by plan.cpp and
-    the oracle; FNV-1a checksums agree"""
+    """lengths with a prime factor above 7 (and, negative, a 7-smooth length forced down the same path): geometry,
+    band tables and the tables of the constant-Q stage are built independently by plan.cpp and the oracle; FNV-1a
+    checksums agree.  (The chirp-z transform's own tables are generated on the device: tests/test_gpu_parity.py
+    test_chirpz_tables_generated_on_device.)"""
     want = np.zeros(8, np.uint64)
     plan = oracle.Plan(abs(n), force_bluestein=n < 0)
     oracle.lib().hpfw_oracle_plan_checksum.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -228,13 +228,33 @@ def test_mel_front_end_against_float64(oracle):
     assert mel.spectrogram(np.zeros(10000, np.int16)).shape == (33, 0)      # all frames silent
 
 
-def test_table_dft_in_double_against_numpy(oracle):
-    """S16: the double-precision DFT the chirp-z tables are built with (any length with prime factors <= 31)"""
-    rng = np.random.default_rng(7)
-    for n in (1, 2, 23, 230, 6300, 31 * 29 * 3):
-        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
-        ref = np.fft.fft(x)
-        assert np.abs(oracle.dft_double(x) - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
+@pytest.mark.parametrize("n", [99991, -132300])
+def test_chirpz_tables_against_float64(oracle, n):
+    """S15: chirp, T_L, w[k] / L (S2b: own cosine and sine, explicit fma chains) and Bhat (the f32 forward transform of
+    the conjugate chirp's lags) against numpy in float64"""
+    plan = oracle.Plan(abs(n), force_bluestein=n < 0)
+    n = abs(n)
+    n1, n2, big_l = plan.n1, plan.n2, plan.n1 * plan.n2
+    assert n2 == 6300 and n1 == -(-(n + (plan.kmax - plan.kmin) - 1) // 6300)
+    idx = np.arange(n1)[:, None] + n1 * np.arange(n2)[None, :]           # table element [r][t] stands for r + n1 t
+
+    def chirp(m):
+        m = np.asarray(m, np.int64)
+        return np.exp(-1j * np.pi * ((m * m) % (2 * n)) / n)
+
+    w = np.where(idx < n, chirp(np.minimum(idx, n - 1)), 0).ravel()
+    assert np.abs(plan.chirpz_table(0) - w).max() < 1e-7
+    tl = np.exp(-2j * np.pi * ((np.arange(n1)[:, None] * np.arange(n2)[None, :]) % big_l) / big_l).ravel()
+    assert np.abs(plan.chirpz_table(1) - tl).max() < 1e-7
+    k = np.arange(plan.kmin, plan.kmax)
+    assert np.abs(plan.chirpz_table(3) * big_l - chirp(k)).max() < 1e-7
+    b = np.zeros(big_l, np.complex128)
+    m = np.arange(plan.kmin - (n - 1), plan.kmax)
+    b[m % big_l] = np.conj(chirp(np.abs(m)))
+    bhat = np.fft.fft(b)                                                   # flat index n2 k1 + k2: the table's layout
+    got = plan.chirpz_table(2).astype(np.complex128)
+    assert np.abs(got - bhat).max() < 2e-6 * np.abs(bhat).max()
+    assert np.sqrt(np.mean(np.abs(got - bhat) ** 2)) < 3e-7 * np.sqrt(np.mean(np.abs(bhat) ** 2))
 
 
 @pytest.mark.parametrize("n", [132301, 88211, 99991, 132300])
