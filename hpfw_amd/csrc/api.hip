@@ -286,11 +286,13 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         bz.n2pad = (p.n2 + 31) / 32 * 32;
         bz.kmin = p.kmin;
         bz.kmax = p.kmax;
-        bz.n_tiles = ((2 * p.n1 + 31) / 32 + 2) / 3 * 3;
+        bz.a = p.n1 / 16;
+        bz.n_tiles1 = (bz.a + 15) / 16;
         bz.k1lo = p.kmin / p.n2;
         bz.k1n = (p.kmax - 1) / p.n2 - bz.k1lo + 1;
         bz.n_tiles2 = ((2 * bz.k1n + 31) / 32 + 2) / 3 * 3;
-        // coefficient images of the column transforms (all rows; the rows that hold consumed bins), packed on the device
+        // coefficient images of the column transforms (the first one's two stages; the second one's rows that hold
+        // consumed bins), packed on the device
         const cf *d_tw_n1 = nullptr;
         std::vector<void *> tmp_owned;
         if ((rc = upload(p.tw_n1, reinterpret_cast<const hpfw::HostCf **>(&d_tw_n1), tmp_owned))) return rc;
@@ -299,15 +301,19 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
             std::vector<void *> &v;
             ~FreeTmp() { for (void *q : v) (void)hipFree(q); }
         } free_tmp{tmp_owned};
-        for (int which = 0; which < 2; ++which) {
-            void *d = nullptr;
-            const size_t bytes = (size_t)p.n1 * (which ? bz.n_tiles2 : bz.n_tiles) * 64 * sizeof(float);
-            HIP_TRY(hipMalloc(&d, bytes));
-            dp->owned.push_back(d);
-            g_uploaded += bytes;
-            (which ? bz.apack2 : bz.apack) = static_cast<const float *>(d);
-            hpfw::launch_bz_pack_coefficients(p.n1, which ? bz.k1lo : 0, which ? bz.k1n : p.n1, d_tw_n1, which ? bz.n_tiles2 : bz.n_tiles,
-                                              static_cast<float *>(d), nullptr);
+        {
+            const size_t bytes[3] = {(size_t)bz.a * bz.n_tiles1 * 64 * sizeof(float), (size_t)bz.a * 16 * 64 * sizeof(float),
+                                     (size_t)p.n1 * bz.n_tiles2 * 64 * sizeof(float)};
+            const float **slot[3] = {&bz.apack1, &bz.apack3, &bz.apack2};
+            for (int i = 0; i < 3; ++i) {
+                void *d = nullptr;
+                HIP_TRY(hipMalloc(&d, bytes[i]));
+                dp->owned.push_back(d);
+                g_uploaded += bytes[i];
+                *slot[i] = static_cast<const float *>(d);
+            }
+            hpfw::launch_bz_pack_stages(bz, d_tw_n1, const_cast<float *>(bz.apack1), const_cast<float *>(bz.apack3), nullptr);
+            hpfw::launch_bz_pack_coefficients(p.n1, bz.k1lo, bz.k1n, d_tw_n1, bz.n_tiles2, const_cast<float *>(bz.apack2), nullptr);
         }
         // chirp, T_L, w[k] / L and Bhat are generated on the device (k_bluestein.hip): a corpus of
         // real recordings brings a new length with every file

@@ -9,12 +9,14 @@
 // dense DFT on the matrix cores and does not care about n1's factors):
 //   pcm_pairs    (k_forward.hip) PCM -> residue streams, zeros beyond N
 //   bz_rows<0>   per residue r: a[r + n1 t] = x w, FFT_n2 in LDS, times T_L[r k2]           -> Y'  planar
-//   bz_cols<0>   A[n2 k1 + k2] = sum_r T_n1[r k1] Y'[r][k2] (f32 MFMA, all n1 rows), C = conj(A Bhat) -> C planar [k1][k2]
+//   bz_cols2<0>  A[n2 k1 + k2] = sum_r T_n1[r k1] Y'[r][k2] for all n1 = 16 a rows, in two stages on f32 MFMA (length a
+//                over r2, length 16 over r1, r = 16 r2 + r1), C = conj(A Bhat)                 -> C planar [k1][k2]
 //   bz_transpose the flat index j = n2 k1 + k2 = r + n1 t regrouped by residue                  -> C' planar [r][t]
 //   bz_rows<1>   per residue r: FFT_n2 over t in LDS, times T_L[r k2]                          -> Y'' planar
 //   bz_cols<1>   F[n2 k1 + k2] = sum_r T_n1[r k1] Y''[r][k2] for the rows k1 that hold consumed bins only (about a
 //                tenth of them, as in fwd_cols); X[k] = conj(F[k]) w[k] / L
-// Only the first transform's column stage is a full n1 x n1 contraction.  Arithmetic order = the oracle's, bit for
+// Only the first transform's column stage needs all n1 output rows: a dense n1 x n1 contraction there took more time
+// than every other kernel of the path together, hence its two stages.  Arithmetic order = the oracle's, bit for
 // bit: MFMA chains its k index (Re then Im part of each residue) in ascending order (S6).
 #include "kernels.h"
 
@@ -37,12 +39,13 @@ __global__ __launch_bounds__(kBzThreads, 4) void bz_rows_kernel(RowsArgs a, BzAr
     const int n2 = a.n2, nthreads = kBzThreads, tid = threadIdx.x;
     const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad; // floats per clip of a planar buffer
     if (MODE == 0) {
-        const i16x2 *__restrict__ src = pairs + ((int64_t)clip * ((bz.n1 + 1) / 2) + (row >> 1)) * n2;
+        // the pair word as a plain 32-bit integer (an array of 16-bit vectors ends up in scratch memory)
+        const int *__restrict__ src = reinterpret_cast<const int *>(pairs + ((int64_t)clip * ((bz.n1 + 1) / 2) + (row >> 1)) * n2);
         const cf *__restrict__ w = bz.w + (int64_t)row * n2;
-        const bool odd = row & 1;
+        const int sh = (row & 1) ? 0 : 16; // odd residue: the high half (arithmetic shift); even: the low half moved up first
         constexpr int kLd = 13;
         for (int t0 = tid; t0 < n2; t0 += kLd * nthreads) {
-            i16x2 p[kLd];
+            int p[kLd];
             cf ww[kLd];
 #pragma unroll
             for (int e = 0; e < kLd; ++e) {
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(kBzThreads, 4) void bz_rows_kernel(RowsArgs a, BzAr
             for (int e = 0; e < kLd; ++e) {
                 const int t = t0 + e * nthreads;
                 if (t < n2) {
-                    const float xs = (float)(odd ? p[e].y : p[e].x) / 32768.0f;
+                    const float xs = (float)((p[e] << sh) >> 16) / 32768.0f;
                     lds[t] = {xs * ww[e].r, xs * ww[e].i};
                 }
             }
@@ -117,13 +120,11 @@ __device__ __forceinline__ float bz_ld(__amdgpu_buffer_rsrc_t r, int voff, int s
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-// D[row][col] = sum_k A[row][k] B[k][col], k = 2 r + part: B = a planar buffer (row 2r = Re, 2r + 1 = Im of
-// residue r, n2pad columns), A = the DFT coefficients of ALL n1 output rows (Re / Im row pairs), packed by
-// bz_pack_kernel.  One wave = 32 columns x 3 row tiles of 32 (16 complex rows each); blockIdx.z = the
-// group of 3 row tiles.  Same register-blocked operand stream as fwd_cols_kernel (k_forward.hip).
-// MODE 0: all n1 rows, out = conj(D Bhat[k1][k2]) planar; MODE 1: the rows k1lo .. k1lo + k1n - 1 that hold consumed
-// bins, x[k - kmin] = conj(D) w[k] / L for k = n2 k1 + k2 in [kmin, kmax); MODE 2 (table generation, one "clip"): all
-// n1 rows, x[n2 k1 + k2] = D as it stands -- Bhat, the transform of the conjugate chirp's lags.
+// The second transform's column stage.  D[row][col] = sum_k A[row][k] B[k][col], k = 2 r + part: B = a planar buffer
+// (row 2r = Re, 2r + 1 = Im of residue r, n2pad columns), A = the DFT coefficients of the rows k1lo .. k1lo + k1n - 1
+// that hold consumed bins (Re / Im row pairs), packed by bz_pack_kernel.  One wave = 32 columns x 3 row tiles of 32
+// (16 complex rows each); blockIdx.z = the group of 3 row tiles.  Same register-blocked operand stream as
+// fwd_cols_kernel (k_forward.hip).  x[k - kmin] = conj(D) w[k] / L for k = n2 k1 + k2 in [kmin, kmax).
 template <int MODE, int kStep>
 __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float *__restrict__ in, float *__restrict__ out,
                                                          cf *__restrict__ x)
@@ -138,9 +139,10 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
     const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad;
     const __amdgpu_buffer_rsrc_t rb =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in + clip * plane), (short)0, (int)(plane * 4), 0x00020000);
-    const int n_tiles = MODE == 1 ? bz.n_tiles2 : bz.n_tiles;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(MODE == 1 ? bz.apack2 : bz.apack), (short)0, bz.n1 * n_tiles * 256, 0x00020000); // [r][tile][lane]
+    static_assert(MODE == 1, "the full column stage is bz_cols2_kernel");
+    const int n_tiles = bz.n_tiles2;
+    const __amdgpu_buffer_rsrc_t ra =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bz.apack2), (short)0, bz.n1 * n_tiles * 256, 0x00020000); // [r][tile][lane]
     const int vb = (hb * bz.n2pad + ctile * 32 + j) * 4;
     const int va = (tile0 * 64 + lane) * 4;
     const int sb = 2 * bz.n2pad * 4; // bytes per residue in the planar buffer
@@ -182,30 +184,7 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
     // tile * 16 + (q & 1) + 4 (q >> 1) + 2 (lane >> 5)
     const int k2 = ctile * 32 + j;
     if (k2 >= bz.n2) return;
-    if (MODE == 0) {
-        float *__restrict__ o = out + clip * plane;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k1 = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
-                if (k1 < bz.n1) {
-                    const cf v = c_mul(cf{acc[t][2 * q], acc[t][2 * q + 1]}, bz.bhat[(int64_t)k1 * bz.n2 + k2]);
-                    o[(int64_t)2 * k1 * bz.n2pad + k2] = v.r;
-                    o[(int64_t)(2 * k1 + 1) * bz.n2pad + k2] = -v.i;
-                }
-            }
-        }
-    } else if (MODE == 2) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k1 = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
-                if (k1 < bz.n1) x[(int64_t)k1 * bz.n2 + k2] = cf{acc[t][2 * q], acc[t][2 * q + 1]};
-            }
-        }
-    } else {
+    {
         cf *__restrict__ xo = x + (int64_t)clip * (bz.kmax - bz.kmin);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -218,6 +197,203 @@ __global__ __launch_bounds__(256, 2) void bz_cols_kernel(BzArgs bz, const float 
             }
         }
     }
+}
+
+// stage 2 of bz_cols2_kernel for the outputs k_a = 16 tile + I, 16 tile + I + 1 (see there); c3 = the tile's slice of
+// the stage-2 coefficient image in LDS [16 k_a][16 r1][64 lanes]
+template <int MODE>
+struct Cols2Out {
+    const BzArgs &bz;
+    float *__restrict__ o;
+    cf *__restrict__ x;
+    int k2, hb, lane, tile;
+    const float *c3;
+
+    // Bhat of pair I's 2 x 8 outputs (issued one pair ahead: in flight while the previous pair's chains run)
+    template <int I>
+    __device__ __forceinline__ void fetch(cf (&bh)[2][8]) const
+    {
+        if (MODE != 0 || I >= 16) return;
+        const int ka = tile * 16 + I;
+        const bool live = k2 < bz.n2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k1 = ka + u + bz.a * ((q & 1) + 4 * (q >> 1) + 2 * hb);
+                bh[u][q] = (live && ka + u < bz.a) ? bz.bhat[(int64_t)k1 * bz.n2 + k2] : cf{0.0f, 0.0f};
+            }
+    }
+
+    template <int I>
+    __device__ __forceinline__ void pair(const f32x16 (&z)[16], const cf (&bh)[2][8]) const
+    {
+        const int ka = tile * 16 + I;
+        if (ka >= bz.a) return; // uniform
+        const bool two = ka + 1 < bz.a;
+        f32x16 d0 = f32x16{0}, d1 = f32x16{0};
+#pragma unroll
+        for (int r1 = 0; r1 < 16; ++r1) {
+            d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c3[(I * 16 + r1) * 64 + lane], z[r1][I], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c3[((I + 1) * 16 + r1) * 64 + lane], z[r1][I + 1], d1, 0, 0, 0);
+        }
+        // D layout: column = lane & 31; registers (2q, 2q+1) = Re / Im of k_b = (q & 1) + 4 (q >> 1) + 2 (lane >> 5)
+        if (k2 >= bz.n2) return;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) continue;
+            const f32x16 &d = u ? d1 : d0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k1 = ka + u + bz.a * ((q & 1) + 4 * (q >> 1) + 2 * hb);
+                if (MODE == 0) {
+                    const cf v = c_mul(cf{d[2 * q], d[2 * q + 1]}, bh[u][q]);
+                    o[(int64_t)2 * k1 * bz.n2pad + k2] = v.r;
+                    o[(int64_t)(2 * k1 + 1) * bz.n2pad + k2] = -v.i;
+                } else {
+                    x[(int64_t)k1 * bz.n2 + k2] = cf{d[2 * q], d[2 * q + 1]};
+                }
+            }
+        }
+    }
+};
+
+// The first transform's column stage: all n1 = 16 a output rows, A[k1] = sum_r T_n1[r k1] Y'[r], per column k2.
+// With r = 16 r2 + r1 (r1 < 16, r2 < a) and k1 = k_a + a k_b (k_a < a, k_b < 16):
+//   stage 1   Z[r1][k_a] = sum_{r2} T_a[r2 k_a] Y'[16 r2 + r1]              (16 transforms of length a)
+//   stage 2   A[k_a + a k_b] = sum_{r1} T_n1[r1 (k_a + a k_b)] Z[r1][k_a]   (a transforms of length 16, twiddles folded in)
+// -- n1 (a + 16) complex products per column where the dense contraction takes n1^2, both stages as fma chains on
+// v_mfma_f32_32x32x2_f32 in ascending order of the summed index (Re, then Im part of each term), nothing between
+// them: stage 1's rows are laid out so that accumulator register i of the tile of r1 holds Re Z[r1][k_a = 16 T + i] in
+// lanes 0-31 and Im in lanes 32-63, which is exactly the B operand of stage 2's k-step r1 (k = 2 r1, 2 r1 + 1).
+// One wave = 32 columns x one tile T of 16 outputs k_a; the 16 stage-1 tiles (r1) stay in registers (256 of them:
+// one wave per SIMD).  MODE 0: out = conj(A Bhat[k1][k2]) planar [k1][k2]; MODE 2 (table generation): x[n2 k1 + k2] = A.
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void bz_cols2_kernel(BzArgs bz, const float *__restrict__ in, float *__restrict__ out,
+                                                          cf *__restrict__ x)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // column groups along blockIdx.x (measured against clips along x, which would share Bhat in L2: 3.25 vs 3.41 ms)
+    const int ctile = blockIdx.x * 4 + wave;
+    const int clip = blockIdx.y;
+    const int tile = blockIdx.z;
+    // the tile's slice of the stage-2 image (zeros past k_a = a) into LDS while stage 1 runs; all four waves share it
+    float *c3 = reinterpret_cast<float *>(smem_raw);
+    {
+        // 16 x 16 bytes per thread, all in flight before the first is stored
+        const float4 *src = reinterpret_cast<const float4 *>(bz.apack3) + (int64_t)tile * 16 * 256;
+        const int limit = (bz.a - tile * 16) * 256; // float4 pieces that exist (a k_a = 1024 floats)
+        float4 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = threadIdx.x + 256 * e;
+            v[e] = i < limit ? src[i] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) reinterpret_cast<float4 *>(c3)[threadIdx.x + 256 * e] = v[e];
+    }
+    const bool active = ctile * 32 < bz.n2; // (every wave reaches the barrier below)
+    const int hb = lane >> 5, j = lane & 31;
+    const int64_t plane = (int64_t)2 * bz.n1 * bz.n2pad;
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in + clip * plane), (short)0, (int)(plane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bz.apack1), (short)0,
+                                                                        bz.a * bz.n_tiles1 * 256, 0x00020000); // [r2][tile][lane]
+    const int vb = (hb * bz.n2pad + ctile * 32 + j) * 4;
+    const int va = (tile * 64 + lane) * 4;
+    const int sb = 2 * bz.n2pad * 4;   // bytes per residue in the planar buffer
+    const int sa = bz.n_tiles1 * 256;  // bytes per r2 in the stage-1 image
+    f32x16 z[16];
+#pragma unroll
+    for (int r1 = 0; r1 < 16; ++r1) z[r1] = f32x16{0};
+    if (active) {
+        // stage 1: k-step r2 feeds the sixteen chains (r1) with one coefficient operand; the operands of the next
+        // kDepth - 1 steps are in flight (one wave per SIMD: nothing else hides the latency).  Loads past the last
+        // residue fall outside the buffers and return 0: the steps that pad a to a multiple of kDepth add 0 * 0 to
+        // every chain, which changes no value (an accumulator that started at +0 is never -0).
+        constexpr int kDepth = 4;
+        float ca[kDepth], cb[kDepth][16];
+#pragma unroll
+        for (int d = 0; d < kDepth - 1; ++d) {
+            ca[d] = bz_ld(ra1, va, d * sa);
+#pragma unroll
+            for (int r1 = 0; r1 < 16; ++r1) cb[d][r1] = bz_ld(rb, vb, (16 * d + r1) * sb);
+        }
+#pragma unroll 1
+        for (int r2 = 0; r2 < bz.a; r2 += kDepth) {
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) {
+                constexpr int kAhead = kDepth - 1;
+                const int nd = (d + kAhead) % kDepth, nr = r2 + d + kAhead;
+                ca[nd] = bz_ld(ra1, va, nr * sa);
+#pragma unroll
+                for (int r1 = 0; r1 < 16; ++r1) cb[nd][r1] = bz_ld(rb, vb, (16 * nr + r1) * sb);
+#pragma unroll
+                for (int r1 = 0; r1 < 16; ++r1) z[r1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[d], cb[d][r1], z[r1], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    // stage 2: per output k_a = 16 tile + i the chain over r1, two outputs side by side (independent accumulators);
+    // i is a template constant: z must be indexed by compile-time constants to stay in registers
+    const int k2 = ctile * 32 + j;
+    Cols2Out<MODE> epi{bz, out + clip * plane, x, k2, hb, lane, tile, c3};
+    cf bha[2][8], bhb[2][8];
+    epi.template fetch<0>(bha);
+    epi.template fetch<2>(bhb);
+    epi.template pair<0>(z, bha);
+    epi.template fetch<4>(bha);
+    epi.template pair<2>(z, bhb);
+    epi.template fetch<6>(bhb);
+    epi.template pair<4>(z, bha);
+    epi.template fetch<8>(bha);
+    epi.template pair<6>(z, bhb);
+    epi.template fetch<10>(bhb);
+    epi.template pair<8>(z, bha);
+    epi.template fetch<12>(bha);
+    epi.template pair<10>(z, bhb);
+    epi.template fetch<14>(bhb);
+    epi.template pair<12>(z, bha);
+    epi.template pair<14>(z, bhb);
+}
+
+// coefficient images of bz_cols2_kernel, from T_n1 (T_a[j] = T_n1[16 j] exactly: S2 reduces the same fraction):
+// apack1 [r2][tile][lane]: lane l supplies A[row = l & 31 of the tile][k = 2 r2 + (l >> 5)]; row 8 g + u of tile T:
+//   u < 4: the Re row of k_a = 16 T + 4 g + u -> (dr, -di); u >= 4: the Im row of k_a = 16 T + 4 g + u - 4 -> (di, dr),
+//   d = T_a[r2 k_a]; zero rows for k_a >= a
+// apack3 [k_a][r1][lane]: row l & 31 = 2 k_b (Re) / 2 k_b + 1 (Im), d = T_n1[r1 (k_a + a k_b)]
+__global__ __launch_bounds__(256) void bz_pack_stages_kernel(BzArgs bz, const cf *__restrict__ tw_n1, float *__restrict__ apack1,
+                                                             float *__restrict__ apack3)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n_a1 = (int64_t)bz.a * bz.n_tiles1 * 64, n_a3 = (int64_t)bz.a * 16 * 64;
+    const int l = (int)(i & 63), part = l >> 5, row = l & 31;
+    if (i < n_a1) {
+        const int t = (int)((i >> 6) % bz.n_tiles1), r2 = (int)((i >> 6) / bz.n_tiles1);
+        const int g = row >> 3, u = row & 7, ka = 16 * t + 4 * g + (u & 3);
+        float v = 0.0f;
+        if (ka < bz.a) {
+            const cf d = tw_n1[16 * (int)(((int64_t)r2 * ka) % bz.a)];
+            if (u < 4) v = part == 0 ? d.r : -d.i;
+            else v = part == 0 ? d.i : d.r;
+        }
+        apack1[i] = v;
+    }
+    if (i < n_a3) {
+        const int r1 = (int)((i >> 6) & 15), ka = (int)(i >> 10), kb = row >> 1;
+        const cf d = tw_n1[((int64_t)r1 * (ka + (int64_t)bz.a * kb)) % bz.n1];
+        float v;
+        if ((row & 1) == 0) v = part == 0 ? d.r : -d.i;
+        else v = part == 0 ? d.i : d.r;
+        apack3[i] = v;
+    }
+}
+
+void launch_bz_pack_stages(const BzArgs &bz, const cf *d_tw_n1, float *d_apack1, float *d_apack3, hipStream_t s)
+{
+    const int64_t n_a1 = (int64_t)bz.a * bz.n_tiles1 * 64, n_a3 = (int64_t)bz.a * 16 * 64, count = n_a1 > n_a3 ? n_a1 : n_a3;
+    hipLaunchKernelGGL(bz_pack_stages_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, bz, d_tw_n1, d_apack1, d_apack3);
 }
 
 // coefficient image [r][tile][lane] of the length-n1 DFT for the MFMA A operand: lane l supplies
@@ -350,7 +526,7 @@ size_t bz_plane_bytes(const BzArgs &bz, int n_clips) { return (size_t)n_clips * 
 template <int MODE, int STEP>
 static void launch_bz_cols_step(const BzArgs &bz, const float *in, float *out, cf *x, int n_clips, hipStream_t s)
 {
-    dim3 grid(((bz.n2 + 31) / 32 + 3) / 4, n_clips, (MODE == 1 ? bz.n_tiles2 : bz.n_tiles) / 3);
+    dim3 grid(((bz.n2 + 31) / 32 + 3) / 4, n_clips, bz.n_tiles2 / 3);
     hipLaunchKernelGGL((bz_cols_kernel<MODE, STEP>), grid, dim3(256), 0, s, bz, in, out, x);
 }
 
@@ -379,6 +555,8 @@ static void bz_rows_attr()
                                   160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bz_transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bz_cols2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(bz_cols2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         attr_set.mark();
     }
 }
@@ -394,7 +572,9 @@ void launch_bz_rows_first(const RowsArgs &rows, const BzArgs &bz, const i16x2 *d
 // Y' -> C = conj(A Bhat), planar [k1][k2]; in and out distinct
 void launch_bz_cols_full(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s)
 {
-    launch_bz_cols_t<0>(bz, d_in, d_out, nullptr, n_clips, s);
+    bz_rows_attr();
+    hipLaunchKernelGGL(bz_cols2_kernel<0>, dim3(((bz.n2 + 31) / 32 + 3) / 4, n_clips, bz.n_tiles1), dim3(256), 64 * 1024, s, bz, d_in, d_out,
+                       (cf *)nullptr);
 }
 
 // C [k1][k2] -> C' [r][t]; in and out distinct
@@ -435,7 +615,8 @@ void launch_bz_make_tables(const RowsArgs &rows, const BzArgs &bz, int64_t n, fl
     hipLaunchKernelGGL(bz_tables_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, bz, g);
     hipLaunchKernelGGL(bz_rows_kernel<1>, dim3(1, bz.n1), dim3(kBzThreads), (size_t)rows.n2 * sizeof(cf), s, rows, bz,
                        (const i16x2 *)nullptr, (const float *)d_b, d_y);
-    launch_bz_cols_t<2>(bz, d_y, nullptr, const_cast<cf *>(bz.bhat), 1, s);
+    hipLaunchKernelGGL(bz_cols2_kernel<2>, dim3(((bz.n2 + 31) / 32 + 3) / 4, 1, bz.n_tiles1), dim3(256), 64 * 1024, s, bz, (const float *)d_y,
+                       (float *)nullptr, const_cast<cf *>(bz.bhat));
 }
 
 // Y'' -> x [n_clips][kmax - kmin]

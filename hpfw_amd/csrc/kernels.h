@@ -46,14 +46,16 @@ struct ColsArgs {
 struct BzArgs {
     int n1, n2, n2pad;  // n2pad: row stride (floats) of the planar buffers, a multiple of 32
     int kmin, kmax;     // forward bins consumed
-    int n_tiles;        // row tiles of 32 in the coefficient image, a multiple of 3, covering 2 n1 rows
+    int a;              // n1 = 16 a: the first transform's column stage splits into length-a and length-16 transforms
+    int n_tiles1;       // row tiles of 32 (16 outputs k_a each) of the length-a stage
     int k1lo, k1n;      // rows k1lo .. k1lo + k1n - 1 of the second transform hold the consumed bins
     int n_tiles2;       // row tiles of their coefficient image apack2 (a multiple of 3)
     const cf *w;        // chirp w[r + n1 t], 0 from sample N on
     const cf *tl;       // T_L[r k2]
     const cf *bhat;     // DFT_L(conj chirp)[n2 k1 + k2]
     const cf *wk;       // w[k] / L  [kmax - kmin]
-    const float *apack; // coefficient image of the full length-n1 DFT [n1][n_tiles][64]
+    const float *apack1; // coefficient image of the length-a DFT          [a][n_tiles1][64]
+    const float *apack3; // ... of the length-16 stage with its twiddles, per k_a  [a][16][64]
     const float *apack2; // ... of the rows k1lo .. k1lo + k1n - 1   [n1][n_tiles2][64]
 };
 
@@ -89,6 +91,8 @@ void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, in
 // chirp-z forward transform (k_bluestein.hip): pairs -> Y' -> C -> C' -> Y'' -> x; the planar buffers hold
 // bz_plane_bytes(bz, n_clips) each
 size_t bz_plane_bytes(const BzArgs &bz, int n_clips);
+// coefficient images of the first transform's two column stages (apack1, apack3), from T_n1 on the device
+void launch_bz_pack_stages(const BzArgs &bz, const cf *d_tw_n1, float *d_apack1, float *d_apack3, hipStream_t s);
 // coefficient image [n1][n_tiles][64] of rows k1_first .. k1_first + k1_count - 1 of the length-n1 DFT, from T_n1 on the device
 void launch_bz_pack_coefficients(int n1, int k1_first, int k1_count, const cf *d_tw_n1, int n_tiles, float *d_apack, hipStream_t s);
 // the tables bz.w, bz.tl, bz.wk, bz.bhat of a clip length, generated on the device (two planar scratch buffers of one clip)

@@ -292,11 +292,10 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
         p.bluestein = force_bluestein || rest != 1;
     }
     if (p.bluestein) {
-        // S15: a chirp-z convolution of length L = n1 * 6300 >= N + (kmax - kmin) - 1; the column DFT over the
-        // n1 residues is dense (matrix cores) and the tables are generated by the same kernels (k_bluestein.hip),
-        // so n1 is simply the smallest that fits
+        // S15: a chirp-z convolution of length L = n1 * 6300 >= N + (kmax - kmin) - 1 with n1 = 16 a, the smallest
+        // that fits: the first transform's column stage splits into transforms of length a and 16 (k_bluestein.hip)
         const int64_t need = n + (kmax - kmin) - 1;
-        n1 = (need + 6299) / 6300;
+        n1 = (need + 16 * 6300 - 1) / (16 * 6300) * 16;
         p.bz_l = n1 * 6300;
     }
     for (int64_t d = 1; !p.bluestein && d <= n; ++d) {

@@ -564,6 +564,54 @@ static void bz_unit(int64_t m, int64_t n, double *re, double *im)
 /* w[m] = e^{-i pi m^2 / N} = e^{-2 pi i (m^2 mod 2N) / 2N}, m >= 0 */
 static void bz_chirp_d(int64_t m, int64_t n, double *re, double *im) { bz_unit((m * m) % (2 * n), 2 * n, re, im); }
 
+/* S15, the first transform's column stage: A[k1][k2] = sum_r T_n1[r k1] y[r][k2] for all n1 = 16 a rows k1, in two
+ * stages with r = 16 r2 + r1 and k1 = k_a + a k_b:
+ *   Z[r1][k_a] = chain over r2 ascending of T_a[r2 k_a] y[16 r2 + r1]          (T_a[j] = T_n1[16 j])
+ *   A[k_a + a k_b] = chain over r1 ascending of T_n1[r1 (k_a + a k_b)] Z[r1][k_a]
+ * every chain from 0 with the four fmas of S6 per term (re += dr yr; re += -di yi; im += di yr; im += dr yi).
+ * Planar float arrays [n1][n2]; k2 innermost so that the loops vectorise. */
+static void bz_columns_two_stage(const hpfw_oracle_plan *p, const float *yr, const float *yi, float *ar, float *ai)
+{
+    const int64_t n1 = p->info.n1, n2 = p->info.n2, a = n1 / 16;
+    float *zr = (float *)calloc((size_t)(n1 * n2), sizeof(float)), *zi = (float *)calloc((size_t)(n1 * n2), sizeof(float));
+    for (int64_t r1 = 0; r1 < 16; ++r1)
+        for (int64_t ka = 0; ka < a; ++ka) {
+            float *qr = zr + (r1 * a + ka) * n2, *qi = zi + (r1 * a + ka) * n2;
+            int64_t idx = 0; /* (r2 ka) mod a */
+            for (int64_t r2 = 0; r2 < a; ++r2) {
+                const float dr = p->tw_n1[16 * idx].r, di = p->tw_n1[16 * idx].i, ndi = -di;
+                const float *pr = yr + (16 * r2 + r1) * n2, *pi = yi + (16 * r2 + r1) * n2;
+                for (int64_t k2 = 0; k2 < n2; ++k2) {
+                    qr[k2] = fmaf(dr, pr[k2], qr[k2]);
+                    qr[k2] = fmaf(ndi, pi[k2], qr[k2]);
+                    qi[k2] = fmaf(di, pr[k2], qi[k2]);
+                    qi[k2] = fmaf(dr, pi[k2], qi[k2]);
+                }
+                idx += ka;
+                if (idx >= a) idx -= a;
+            }
+        }
+    for (int64_t k1 = 0; k1 < n1; ++k1) {
+        const int64_t ka = k1 % a;
+        float *or_ = ar + k1 * n2, *oi = ai + k1 * n2;
+        memset(or_, 0, sizeof(float) * (size_t)n2);
+        memset(oi, 0, sizeof(float) * (size_t)n2);
+        for (int64_t r1 = 0; r1 < 16; ++r1) {
+            const cf d = p->tw_n1[(r1 * k1) % n1];
+            const float dr = d.r, di = d.i, ndi = -d.i;
+            const float *pr = zr + (r1 * a + ka) * n2, *pi = zi + (r1 * a + ka) * n2;
+            for (int64_t k2 = 0; k2 < n2; ++k2) {
+                or_[k2] = fmaf(dr, pr[k2], or_[k2]);
+                or_[k2] = fmaf(ndi, pi[k2], or_[k2]);
+                oi[k2] = fmaf(di, pr[k2], oi[k2]);
+                oi[k2] = fmaf(dr, pi[k2], oi[k2]);
+            }
+        }
+    }
+    free(zr);
+    free(zi);
+}
+
 static void make_forward_bluestein(hpfw_oracle_plan *p)
 {
     const int64_t n = p->info.n_samples, n1 = p->info.n1, n2 = p->info.n2, big_l = p->bz_l;
@@ -610,33 +658,16 @@ static void make_forward_bluestein(hpfw_oracle_plan *p)
     }
     free(z);
     p->bz_bhat = (cf *)malloc(sizeof(cf) * (size_t)big_l);
-    /* per (k1, k2) the chain runs over r in ascending order; written with k2 innermost so that it vectorises */
     float *yr = (float *)malloc(sizeof(float) * (size_t)big_l), *yi = (float *)malloc(sizeof(float) * (size_t)big_l);
+    float *ar = (float *)malloc(sizeof(float) * (size_t)big_l), *ai = (float *)malloc(sizeof(float) * (size_t)big_l);
     for (int64_t i = 0; i < big_l; ++i) {
         yr[i] = b[i].r;
         yi[i] = b[i].i;
     }
-    float *ar = (float *)malloc(sizeof(float) * (size_t)n2), *ai = (float *)malloc(sizeof(float) * (size_t)n2);
-    for (int64_t k1 = 0; k1 < n1; ++k1) {
-        memset(ar, 0, sizeof(float) * (size_t)n2);
-        memset(ai, 0, sizeof(float) * (size_t)n2);
-        int64_t idx = 0; /* (r k1) mod n1 */
-        for (int64_t r = 0; r < n1; ++r) {
-            const float dr = p->tw_n1[idx].r, di = p->tw_n1[idx].i, ndi = -di;
-            const float *pr = yr + r * n2, *pi = yi + r * n2;
-            for (int64_t k2 = 0; k2 < n2; ++k2) {
-                ar[k2] = fmaf(dr, pr[k2], ar[k2]);
-                ar[k2] = fmaf(ndi, pi[k2], ar[k2]);
-                ai[k2] = fmaf(di, pr[k2], ai[k2]);
-                ai[k2] = fmaf(dr, pi[k2], ai[k2]);
-            }
-            idx += k1;
-            if (idx >= n1) idx -= n1;
-        }
-        for (int64_t k2 = 0; k2 < n2; ++k2) {
-            p->bz_bhat[k1 * n2 + k2].r = ar[k2];
-            p->bz_bhat[k1 * n2 + k2].i = ai[k2];
-        }
+    bz_columns_two_stage(p, yr, yi, ar, ai);
+    for (int64_t i = 0; i < big_l; ++i) {
+        p->bz_bhat[i].r = ar[i];
+        p->bz_bhat[i].i = ai[i];
     }
     free(ar);
     free(ai);
@@ -666,8 +697,9 @@ hpfw_oracle_plan *hpfw_oracle_plan_create3(int64_t n, int force_bluestein, unsig
             free(p);
             return NULL;
         }
-        /* n2 = 6300; n1 = the smallest integer >= (N + nk - 1) / 6300 (the column transform is a dense chain: any n1) */
-        int64_t need = n + (p->info.kmax - p->info.kmin) - 1, n1 = (need + 6299) / 6300;
+        /* n2 = 6300; n1 = 16 a, the smallest such that n1 n2 >= N + nk - 1 (the first transform's column stage splits
+         * into transforms of length a and 16) */
+        int64_t need = n + (p->info.kmax - p->info.kmin) - 1, n1 = (need + 16 * 6300 - 1) / (16 * 6300) * 16;
         if (n1 > 8192) {
             free(p);
             return NULL;
@@ -799,22 +831,26 @@ static void spectrum_bluestein(const hpfw_oracle_plan *p, const int16_t *pcm, fl
         fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
         for (int64_t k2 = 0; k2 < n2; ++k2) ya[r * n2 + k2] = c_mul(z[p->pos_n2[k2]], p->bz_tl[r * n2 + k2]);
     }
-    for (int64_t k1 = 0; k1 < n1; ++k1)
-        for (int64_t k2 = 0; k2 < n2; ++k2) {
-            float ar = 0.0f, ai = 0.0f;
-            for (int64_t r = 0; r < n1; ++r) {
-                cf d = p->tw_n1[(r * k1) % n1];
-                cf y = ya[r * n2 + k2];
-                ar = fmaf(d.r, y.r, ar);
-                ar = fmaf(-d.i, y.i, ar);
-                ai = fmaf(d.i, y.r, ai);
-                ai = fmaf(d.r, y.i, ai);
-            }
-            cf acc = {ar, ai};
-            cf v = c_mul(acc, p->bz_bhat[k1 * n2 + k2]);
-            yb[k1 * n2 + k2].r = v.r;
-            yb[k1 * n2 + k2].i = -v.i;
+    {
+        const int64_t big_l = n1 * n2;
+        float *yr = (float *)malloc(sizeof(float) * (size_t)big_l), *yi = (float *)malloc(sizeof(float) * (size_t)big_l);
+        float *ar = (float *)malloc(sizeof(float) * (size_t)big_l), *ai = (float *)malloc(sizeof(float) * (size_t)big_l);
+        for (int64_t i = 0; i < big_l; ++i) {
+            yr[i] = ya[i].r;
+            yi[i] = ya[i].i;
         }
+        bz_columns_two_stage(p, yr, yi, ar, ai);
+        for (int64_t i = 0; i < big_l; ++i) {
+            cf acc = {ar[i], ai[i]};
+            cf v = c_mul(acc, p->bz_bhat[i]);
+            yb[i].r = v.r;
+            yb[i].i = -v.i;
+        }
+        free(ar);
+        free(ai);
+        free(yr);
+        free(yi);
+    }
     /* second transform, F = DFT_L(C) with C[n2 k1 + k2] as it stands: rows first again -- residue r of the flat
      * index j = r + n1 t -- then T_L, then the column chain for the rows k1 that hold consumed bins only */
     for (int64_t r = 0; r < n1; ++r) {

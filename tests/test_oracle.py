@@ -26,7 +26,7 @@ def test_geometry_of_baseline_configs(oracle):
     posit, lg = nsgt_f64.bands(1323000)
     assert np.array_equal(lg, p.lg) and np.array_equal(posit - lg // 2, p.start)
     r = oracle.Plan(1323001)                                 # 11 * 120273: the chirp-z forward transform (S15)
-    assert (r.n2, r.n1) == (6300, 230) and (r.m, r.c) == (7255, 2419)
+    assert (r.n2, r.n1) == (6300, 240) and (r.m, r.c) == (7255, 2419)   # n1 = 16 a: two-stage column transform
     with pytest.raises(ValueError):
         oracle.Plan(4410)                                    # bands leave the half spectrum
 
@@ -235,7 +235,7 @@ def test_chirpz_tables_against_float64(oracle, n):
     plan = oracle.Plan(abs(n), force_bluestein=n < 0)
     n = abs(n)
     n1, n2, big_l = plan.n1, plan.n2, plan.n1 * plan.n2
-    assert n2 == 6300 and n1 == -(-(n + (plan.kmax - plan.kmin) - 1) // 6300)
+    assert n2 == 6300 and n1 == 16 * -(-(n + (plan.kmax - plan.kmin) - 1) // (16 * 6300))
     idx = np.arange(n1)[:, None] + n1 * np.arange(n2)[None, :]           # table element [r][t] stands for r + n1 t
 
     def chirp(m):
