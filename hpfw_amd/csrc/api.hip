@@ -318,18 +318,22 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         // chirp, T_L, w[k] / L and Bhat are generated on the device (k_bluestein.hip): a corpus of
         // real recordings brings a new length with every file
         const size_t big_l = (size_t)p.n1 * p.n2, plane = hpfw::bz_plane_bytes(bz, 1);
-        for (const hpfw::cf **t : {&bz.w, &bz.tl, &bz.bhat, &bz.wk}) {
-            void *d = nullptr;
-            const size_t bytes = (t == &bz.wk ? (size_t)(p.kmax - p.kmin) : big_l) * sizeof(cf);
-            HIP_TRY(hipMalloc(&d, bytes));
-            dp->owned.push_back(d);
-            g_uploaded += bytes;
-            *t = static_cast<const cf *>(d);
+        {
+            const size_t bytes[4] = {big_l * sizeof(cf), big_l * sizeof(cf), big_l * sizeof(cf), (size_t)(p.kmax - p.kmin) * sizeof(cf)};
+            const void **slot[4] = {reinterpret_cast<const void **>(&bz.wp), reinterpret_cast<const void **>(&bz.tl),
+                                    reinterpret_cast<const void **>(&bz.bhat), reinterpret_cast<const void **>(&bz.wk)};
+            for (int i = 0; i < 4; ++i) {
+                void *d = nullptr;
+                HIP_TRY(hipMalloc(&d, bytes[i]));
+                dp->owned.push_back(d);
+                g_uploaded += bytes[i];
+                *slot[i] = d;
+            }
         }
         void *scratch = nullptr;
-        HIP_TRY(hipMalloc(&scratch, 2 * plane));
+        HIP_TRY(hipMalloc(&scratch, big_l * 8 + plane));
         tmp_owned.push_back(scratch); // freed with T_n1 when this block ends, after the synchronisation below
-        hpfw::launch_bz_make_tables(ra, bz, n, static_cast<float *>(scratch), static_cast<float *>(scratch) + plane / sizeof(float), nullptr);
+        hpfw::launch_bz_make_tables(ra, bz, n, static_cast<float *>(scratch), static_cast<float *>(scratch) + 2 * big_l, nullptr);
         const hipError_t launched = hipGetLastError(), done = hipStreamSynchronize(nullptr);
         if (launched != hipSuccess || done != hipSuccess)
             return fail(HPFW_E_HIP, std::string("chirp-z tables: ") + hipGetErrorString(launched != hipSuccess ? launched : done));
@@ -442,7 +446,8 @@ int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
     const size_t need[7] = {p.bluestein ? planar : (size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4,
                             (size_t)nb * (p.kmax - p.kmin) * 8,
                             (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4,
-                            (size_t)ns * 121 * hpfw::kCqMaxWaves * 4, (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4, planar};
+                            (size_t)ns * 121 * hpfw::kCqMaxWaves * 4,
+                            p.bluestein ? 0 : (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4, planar}; // (the chirp-z path reads the PCM as it lies)
     for (int i = 0; i < 7; ++i) {
         int rc = ensure(&h->ws[i], &h->ws_bytes[i], need[i]);
         if (rc) return rc;
@@ -457,22 +462,15 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
     float *yp = (float *)h->ws[0];
     int rc;
     if (p.bluestein) { // S15: the clip length has a prime factor above 7
-        {
-            Timed t(h, K_ROWS, s);
-            hpfw::launch_pcm_pairs(p.n, p.n1, p.n2, d_pcm, nb, (hpfw::i16x2 *)h->ws[5], s);
-            hpfw::launch_bz_rows_first(dp->rows, dp->bz, (const hpfw::i16x2 *)h->ws[5], nb, yp, s);
-        }
-        if ((rc = check_launch("bz_rows"))) return rc;
         float *other = (float *)h->ws[6];
         {
             Timed t(h, K_COLS, s);
-            hpfw::launch_bz_cols_full(dp->bz, yp, other, nb, s); // Y' -> C [k1][k2]
+            hpfw::launch_bz_cols_first(dp->bz, d_pcm, p.n, nb, yp, s); // pcm as it lies -> G' [q1][k2']
         }
         if ((rc = check_launch("bz_cols"))) return rc;
         {
             Timed t(h, K_ROWS, s);
-            hpfw::launch_bz_transpose(dp->bz, other, yp, nb, s);            // C -> C' [r][t]
-            hpfw::launch_bz_rows_second(dp->rows, dp->bz, yp, nb, other, s); // C' -> Y''
+            hpfw::launch_bz_rows_both(dp->rows, dp->bz, yp, nb, other, s); // G' -> A -> C -> H' [q1][m2]
         }
         if ((rc = check_launch("bz_rows"))) return rc;
         {
@@ -763,11 +761,21 @@ int hpfw_gpu_chirpz_table(hpfw_gpu *h, int64_t n_samples, int which, float *out,
     if (rc) return rc;
     if (!dp->hp.bluestein) return fail(HPFW_E_INVALID, "clip length takes the mixed-radix transform: no chirp-z tables");
     const hpfw::BzArgs &bz = dp->bz;
-    const hpfw::cf *tab[4] = {bz.w, bz.tl, bz.bhat, bz.wk};
+    const void *tab[4] = {bz.wp, bz.tl, bz.bhat, bz.wk};
     if (which < 0 || which > 3) return fail(HPFW_E_INVALID, "table index out of range");
     *count = 2 * (which == 3 ? (int64_t)(bz.kmax - bz.kmin) : (int64_t)bz.n1 * bz.n2);
     if (!out) return 0;
     if (capacity < *count) return fail(HPFW_E_INVALID, "table buffer too small");
+    if (which == 0) { // the chirp lies in two planes on the device
+        std::vector<float> planar((size_t)*count);
+        HIP_TRY(hipMemcpy(planar.data(), tab[0], planar.size() * sizeof(float), hipMemcpyDeviceToHost));
+        const size_t big_l = planar.size() / 2;
+        for (size_t j = 0; j < big_l; ++j) {
+            out[2 * j] = planar[j];
+            out[2 * j + 1] = planar[big_l + j];
+        }
+        return 0;
+    }
     HIP_TRY(hipMemcpy(out, tab[which], (size_t)*count * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }

@@ -195,75 +195,8 @@ __global__ __launch_bounds__(256, 2) void fwd_cols_kernel(ColsArgs ca, int tile0
     }
 }
 
-// The chirp-z path's pre-pass: clips of n samples (any n: a clip starts wherever the one before ends, 2-byte aligned
-// at best) into the [n2][n1] matrix padded with zeros, n1 even.  The tile is staged in 16-byte pieces from the
-// 16-byte-aligned address at or below its first sample (delta samples earlier); pieces that reach outside the whole
-// PCM array [0, total) are fetched sample by sample, and samples past the clip's end read as zero when the pairs are
-// formed.
-__global__ __launch_bounds__(256) void pcm_pairs_pad_kernel(int64_t n, int64_t total, int n1, int n2, int kPairsTile,
-                                                            const int16_t *__restrict__ pcm, i16x2 *__restrict__ pairs)
-{
-    int16_t *raw = reinterpret_cast<int16_t *>(smem_raw); // [8 + kPairsTile * n1 + 8]
-    const int tid = threadIdx.x;
-    const int clip = blockIdx.y;
-    const int t0 = blockIdx.x * kPairsTile;
-    const int nt = min(kPairsTile, n2 - t0);
-    const int np = n1 / 2;
-    const int64_t off = (int64_t)clip * n + (int64_t)t0 * n1; // first sample of the tile in the array
-    const int delta = (int)((reinterpret_cast<uintptr_t>(pcm + off) & 15) >> 1);
-    const int64_t g0 = off - delta; // first staged sample
-    const int chunks = (delta + nt * n1 + 7) / 8;
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(pcm + g0);
-    uint4 *t4 = reinterpret_cast<uint4 *>(raw);
-    for (int c = tid; c < chunks; c += 256) {
-        const int64_t g = g0 + 8 * (int64_t)c;
-        if (g >= 0 && g + 8 <= total) {
-            t4[c] = s4[c];
-        } else {
-            for (int e = 0; e < 8; ++e) raw[8 * c + e] = (g + e >= 0 && g + e < total) ? pcm[g + e] : (int16_t)0;
-        }
-    }
-    __syncthreads();
-    i16x2 *dst = pairs + (int64_t)clip * np * n2 + t0;
-    const int lg = 31 - __builtin_clz((unsigned)kPairsTile);
-    const int tt = tid & (kPairsTile - 1), pstep = 256 >> lg;
-    if (tt >= nt) return;
-    const int64_t left = n - (int64_t)(t0 + tt) * n1; // samples of this time step's row that exist
-    const int base = delta + tt * n1;
-    i16x2 *out = dst + tt;
-    if ((delta & 1) == 0) {
-        const i16x2 *row = reinterpret_cast<const i16x2 *>(raw + base);
-        for (int p = tid >> lg; p < np; p += pstep) {
-            i16x2 v = row[p];
-            if (2 * p + 1 >= left) {
-                v.y = 0;
-                if (2 * p >= left) v.x = 0;
-            }
-            out[(int64_t)p * n2] = v;
-        }
-    } else {
-        for (int p = tid >> lg; p < np; p += pstep) {
-            i16x2 v;
-            v.x = 2 * p < left ? raw[base + 2 * p] : (short)0;
-            v.y = 2 * p + 1 < left ? raw[base + 2 * p + 1] : (short)0;
-            out[(int64_t)p * n2] = v;
-        }
-    }
-}
-
 void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s)
 {
-    if (n != (int64_t)n1 * n2) { // a clip shorter than the matrix (chirp-z path, n1 = 16 a): zeros beyond the clip
-        int tile = kPairsTileMax;
-        while (tile > 1 && (size_t)tile * n1 * sizeof(int16_t) > 60 * 1024) tile /= 2;
-        dim3 grid((n2 + tile - 1) / tile, n_clips);
-        const size_t lds = (size_t)tile * n1 * sizeof(int16_t) + 32;
-        if (n1 % 2 == 0 && tile <= 256)
-            hipLaunchKernelGGL(pcm_pairs_pad_kernel, grid, dim3(256), lds, s, n, (int64_t)n_clips * n, n1, n2, tile, d_pcm, d_pairs);
-        else
-            hipLaunchKernelGGL(pcm_pairs_kernel<false>, grid, dim3(256), lds, s, n, n, n1, n2, tile, d_pcm, d_pairs);
-        return;
-    }
     int kPairsTile = kPairsTileMax;
     while (kPairsTile > 1 && (size_t)kPairsTile * n1 * sizeof(int16_t) > 60 * 1024) kPairsTile /= 2;
     dim3 grid((n2 + kPairsTile - 1) / kPairsTile, n_clips);

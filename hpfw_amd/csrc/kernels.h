@@ -50,9 +50,9 @@ struct BzArgs {
     int n_tiles1;       // row tiles of 32 (16 outputs k_a each) of the length-a stage
     int k1lo, k1n;      // rows k1lo .. k1lo + k1n - 1 of the second transform hold the consumed bins
     int n_tiles2;       // row tiles of their coefficient image apack2 (a multiple of 3)
-    const cf *w;        // chirp w[r + n1 t], 0 from sample N on
-    const cf *tl;       // T_L[r k2]
-    const cf *bhat;     // DFT_L(conj chirp)[n2 k1 + k2]
+    const float *wp;    // chirp w[j], planar [2][L] (Re plane, Im plane), 0 from sample N on
+    const cf *tl;       // T_L[q1 k2] at [q1 n2 + k2]
+    const cf *bhat;     // DFT_L(conj chirp)[q1 + n1 q2] at [q1 n2 + q2]
     const cf *wk;       // w[k] / L  [kmax - kmin]
     const float *apack1; // coefficient image of the length-a DFT          [a][n_tiles1][64]
     const float *apack3; // ... of the length-16 stage with its twiddles, per k_a  [a][16][64]
@@ -88,19 +88,16 @@ size_t fwd_rows_lds_bytes(const RowsArgs &a);
 // length-n1 DFT across residues on f32 MFMA: planar yp [n_clips][2 n1][hpad] -> x [n_clips][kmax-kmin]
 void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s);
 void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, int n_tiles, float *apack);
-// chirp-z forward transform (k_bluestein.hip): pairs -> Y' -> C -> C' -> Y'' -> x; the planar buffers hold
-// bz_plane_bytes(bz, n_clips) each
+// chirp-z forward transform (k_bluestein.hip): pcm -> G' -> H' -> x; the planar buffers hold bz_plane_bytes(bz, n_clips) each
 size_t bz_plane_bytes(const BzArgs &bz, int n_clips);
 // coefficient images of the first transform's two column stages (apack1, apack3), from T_n1 on the device
 void launch_bz_pack_stages(const BzArgs &bz, const cf *d_tw_n1, float *d_apack1, float *d_apack3, hipStream_t s);
 // coefficient image [n1][n_tiles][64] of rows k1_first .. k1_first + k1_count - 1 of the length-n1 DFT, from T_n1 on the device
 void launch_bz_pack_coefficients(int n1, int k1_first, int k1_count, const cf *d_tw_n1, int n_tiles, float *d_apack, hipStream_t s);
-// the tables bz.w, bz.tl, bz.wk, bz.bhat of a clip length, generated on the device (two planar scratch buffers of one clip)
+// the tables bz.wp, bz.tl, bz.wk, bz.bhat of a clip length, generated on the device (d_b: 2 L floats, d_y: one planar buffer)
 void launch_bz_make_tables(const RowsArgs &rows, const BzArgs &bz, int64_t n, float *d_b, float *d_y, hipStream_t s);
-void launch_bz_rows_first(const RowsArgs &rows, const BzArgs &bz, const i16x2 *d_pairs, int n_clips, float *d_out, hipStream_t s);
-void launch_bz_cols_full(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s);
-void launch_bz_transpose(const BzArgs &bz, const float *d_in, float *d_out, int n_clips, hipStream_t s);
-void launch_bz_rows_second(const RowsArgs &rows, const BzArgs &bz, const float *d_in, int n_clips, float *d_out, hipStream_t s);
+void launch_bz_cols_first(const BzArgs &bz, const int16_t *d_pcm, int64_t n, int n_clips, float *d_out, hipStream_t s);
+void launch_bz_rows_both(const RowsArgs &rows, const BzArgs &bz, const float *d_in, int n_clips, float *d_out, hipStream_t s);
 void launch_bz_cols_last(const BzArgs &bz, const float *d_in, int n_clips, cf *d_x, hipStream_t s);
 // band chirp-z transforms: x -> mag [n_clips][121][c]; also the maxima each wave saw,
 // d_wavemax [n_clips][121][kCqMaxWaves] (slots of absent waves are written as 0)

@@ -612,68 +612,68 @@ static void bz_columns_two_stage(const hpfw_oracle_plan *p, const float *yr, con
     free(zi);
 }
 
+/* S15 steps A + B of the first transform on a sequence of length L given by rows (planar y [n1][n2], flat index
+ * j = n2 k1' + k2'): the two-stage column chains over k1' -> q1, times T_L[q1 k2'], then per q1 the row transform over
+ * k2' -> q2.  Leaves A[q1 + n1 q2] at out[q1 n2 + q2]. */
+static void bz_first_transform(const hpfw_oracle_plan *p, const float *yr, const float *yi, cf *out)
+{
+    const int64_t n1 = p->info.n1, n2 = p->info.n2, big_l = n1 * n2;
+    float *gr = (float *)malloc(sizeof(float) * (size_t)big_l), *gi = (float *)malloc(sizeof(float) * (size_t)big_l);
+    bz_columns_two_stage(p, yr, yi, gr, gi);
+    cf *z = (cf *)malloc(sizeof(cf) * (size_t)n2);
+    for (int64_t q1 = 0; q1 < n1; ++q1) {
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            cf g = {gr[q1 * n2 + k2], gi[q1 * n2 + k2]};
+            z[k2] = c_mul(g, p->bz_tl[q1 * n2 + k2]);
+        }
+        fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
+        for (int64_t q2 = 0; q2 < n2; ++q2) out[q1 * n2 + q2] = z[p->pos_n2[q2]];
+    }
+    free(z);
+    free(gr);
+    free(gi);
+}
+
 static void make_forward_bluestein(hpfw_oracle_plan *p)
 {
-    const int64_t n = p->info.n_samples, n1 = p->info.n1, n2 = p->info.n2, big_l = p->bz_l;
+    const int64_t n = p->info.n_samples, n2 = p->info.n2, big_l = p->bz_l;
     const int64_t nk = p->info.kmax - p->info.kmin;
-    p->bz_w = (cf *)calloc((size_t)big_l, sizeof(cf));
-    p->bz_tl = (cf *)malloc(sizeof(cf) * (size_t)big_l);
+    p->bz_w = (cf *)calloc((size_t)big_l, sizeof(cf));   /* w[j], 0 from j = N on */
+    p->bz_tl = (cf *)malloc(sizeof(cf) * (size_t)big_l); /* T_L[q1 k2] at q1 n2 + k2 */
     p->bz_wk = (cf *)malloc(sizeof(cf) * (size_t)nk);
-    cf *b = (cf *)calloc((size_t)big_l, sizeof(cf)); /* the lags by residue: b[r][t] stands at the cyclic index r + n1 t */
+    /* the lags at their cyclic index j = m mod L, planar */
+    float *br = (float *)calloc((size_t)big_l, sizeof(float)), *bi = (float *)calloc((size_t)big_l, sizeof(float));
     double c, s;
     for (int64_t k = p->info.kmin; k < p->info.kmax; ++k) {
         bz_chirp_d(k, n, &c, &s);
         p->bz_wk[k - p->info.kmin].r = (float)(c / (double)big_l);
         p->bz_wk[k - p->info.kmin].i = (float)(s / (double)big_l);
     }
-    for (int64_t r = 0; r < n1; ++r)
-        for (int64_t t = 0; t < n2; ++t) {
-            int64_t i = r * n2 + t, idx = r + n1 * t;
-            if (idx < n) {
-                bz_chirp_d(idx, n, &c, &s);
-                p->bz_w[i].r = (float)c;
-                p->bz_w[i].i = (float)s;
-                if (idx <= p->info.kmax - 1) { /* the lag m = idx: conj(w[m]) */
-                    b[i].r = (float)c;
-                    b[i].i = (float)(-s);
-                }
+    for (int64_t j = 0; j < big_l; ++j) {
+        if (j < n) {
+            bz_chirp_d(j, n, &c, &s);
+            p->bz_w[j].r = (float)c;
+            p->bz_w[j].i = (float)s;
+            if (j <= p->info.kmax - 1) { /* the lag m = j: conj(w[m]) */
+                br[j] = (float)c;
+                bi[j] = (float)(-s);
             }
-            int64_t neg = big_l - idx; /* the lag m = idx - L */
-            if (neg <= n - 1 - p->info.kmin) {
-                bz_chirp_d(neg, n, &c, &s);
-                b[i].r = (float)c;
-                b[i].i = (float)(-s);
-            }
-            bz_unit((r * t) % big_l, big_l, &c, &s);
-            p->bz_tl[i].r = (float)c;
-            p->bz_tl[i].i = (float)s;
         }
-    /* Bhat = the first transform of spectrum_bluestein applied to the lags: rows over t (S3/S4), T_L, the column
-     * chain over the residues (S6) */
-    cf *z = (cf *)malloc(sizeof(cf) * (size_t)n2);
-    for (int64_t r = 0; r < n1; ++r) {
-        memcpy(z, b + r * n2, sizeof(cf) * (size_t)n2);
-        fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
-        for (int64_t k2 = 0; k2 < n2; ++k2) b[r * n2 + k2] = c_mul(z[p->pos_n2[k2]], p->bz_tl[r * n2 + k2]);
+        int64_t neg = big_l - j; /* the lag m = j - L */
+        if (neg <= n - 1 - p->info.kmin) {
+            bz_chirp_d(neg, n, &c, &s);
+            br[j] = (float)c;
+            bi[j] = (float)(-s);
+        }
+        bz_unit(((j / n2) * (j % n2)) % big_l, big_l, &c, &s);
+        p->bz_tl[j].r = (float)c;
+        p->bz_tl[j].i = (float)s;
     }
-    free(z);
+    /* Bhat[q1 + n1 q2] at [q1 n2 + q2] = the first transform itself applied to the lags */
     p->bz_bhat = (cf *)malloc(sizeof(cf) * (size_t)big_l);
-    float *yr = (float *)malloc(sizeof(float) * (size_t)big_l), *yi = (float *)malloc(sizeof(float) * (size_t)big_l);
-    float *ar = (float *)malloc(sizeof(float) * (size_t)big_l), *ai = (float *)malloc(sizeof(float) * (size_t)big_l);
-    for (int64_t i = 0; i < big_l; ++i) {
-        yr[i] = b[i].r;
-        yi[i] = b[i].i;
-    }
-    bz_columns_two_stage(p, yr, yi, ar, ai);
-    for (int64_t i = 0; i < big_l; ++i) {
-        p->bz_bhat[i].r = ar[i];
-        p->bz_bhat[i].i = ai[i];
-    }
-    free(ar);
-    free(ai);
-    free(yr);
-    free(yi);
-    free(b);
+    bz_first_transform(p, br, bi, p->bz_bhat);
+    free(br);
+    free(bi);
 }
 
 hpfw_oracle_plan *hpfw_oracle_plan_create2(int64_t n, int force_bluestein) { return hpfw_oracle_plan_create3(n, force_bluestein, 0); }
@@ -817,53 +817,37 @@ void hpfw_oracle_plan_bands(const hpfw_oracle_plan *p, int32_t *start, int32_t *
  * consumed bins; X[k] = conj(F[k]) w[k] / L. */
 static void spectrum_bluestein(const hpfw_oracle_plan *p, const int16_t *pcm, float *x_ri)
 {
-    const int64_t n = p->info.n_samples, n1 = p->info.n1, n2 = p->info.n2;
-    cf *ya = (cf *)malloc(sizeof(cf) * (size_t)(n1 * n2)), *yb = (cf *)malloc(sizeof(cf) * (size_t)(n1 * n2));
+    const int64_t n = p->info.n_samples, n1 = p->info.n1, n2 = p->info.n2, big_l = n1 * n2;
+    /* a[j] = x[j] w[j] by rows of n2 samples (flat index j = n2 k1' + k2'), zeros from j = N on */
+    float *yr = (float *)malloc(sizeof(float) * (size_t)big_l), *yi = (float *)malloc(sizeof(float) * (size_t)big_l);
+    for (int64_t j = 0; j < big_l; ++j) {
+        float x = j < n ? (float)pcm[j] / 32768.0f : 0.0f;
+        yr[j] = x * p->bz_w[j].r;
+        yi[j] = x * p->bz_w[j].i;
+    }
+    /* first transform: columns (k1' -> q1), T_L, rows (k2' -> q2): A[q1 + n1 q2] at [q1][q2] */
+    cf *ya = (cf *)malloc(sizeof(cf) * (size_t)big_l);
+    bz_first_transform(p, yr, yi, ya);
+    free(yr);
+    free(yi);
+    /* C = conj(A Bhat); second transform F = DFT_L(C), C indexed q1 + n1 q2: per q1 the row transform over q2 -> m2,
+     * times T_L[q1 m2]; then the column chain over q1 for the rows m1 that hold consumed bins (m = m2 + n2 m1) */
     cf *z = (cf *)malloc(sizeof(cf) * (size_t)n2);
-    for (int64_t r = 0; r < n1; ++r) {
-        for (int64_t t = 0; t < n2; ++t) {
-            int64_t idx = r + n1 * t;
-            float x = idx < n ? (float)pcm[idx] / 32768.0f : 0.0f;
-            cf w = p->bz_w[r * n2 + t];
-            z[t].r = x * w.r;
-            z[t].i = x * w.i;
+    for (int64_t q1 = 0; q1 < n1; ++q1) {
+        for (int64_t q2 = 0; q2 < n2; ++q2) {
+            cf v = c_mul(ya[q1 * n2 + q2], p->bz_bhat[q1 * n2 + q2]);
+            z[q2].r = v.r;
+            z[q2].i = -v.i;
         }
         fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
-        for (int64_t k2 = 0; k2 < n2; ++k2) ya[r * n2 + k2] = c_mul(z[p->pos_n2[k2]], p->bz_tl[r * n2 + k2]);
-    }
-    {
-        const int64_t big_l = n1 * n2;
-        float *yr = (float *)malloc(sizeof(float) * (size_t)big_l), *yi = (float *)malloc(sizeof(float) * (size_t)big_l);
-        float *ar = (float *)malloc(sizeof(float) * (size_t)big_l), *ai = (float *)malloc(sizeof(float) * (size_t)big_l);
-        for (int64_t i = 0; i < big_l; ++i) {
-            yr[i] = ya[i].r;
-            yi[i] = ya[i].i;
-        }
-        bz_columns_two_stage(p, yr, yi, ar, ai);
-        for (int64_t i = 0; i < big_l; ++i) {
-            cf acc = {ar[i], ai[i]};
-            cf v = c_mul(acc, p->bz_bhat[i]);
-            yb[i].r = v.r;
-            yb[i].i = -v.i;
-        }
-        free(ar);
-        free(ai);
-        free(yr);
-        free(yi);
-    }
-    /* second transform, F = DFT_L(C) with C[n2 k1 + k2] as it stands: rows first again -- residue r of the flat
-     * index j = r + n1 t -- then T_L, then the column chain for the rows k1 that hold consumed bins only */
-    for (int64_t r = 0; r < n1; ++r) {
-        for (int64_t t = 0; t < n2; ++t) z[t] = yb[r + n1 * t];
-        fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
-        for (int64_t k2 = 0; k2 < n2; ++k2) ya[r * n2 + k2] = c_mul(z[p->pos_n2[k2]], p->bz_tl[r * n2 + k2]);
+        for (int64_t m2 = 0; m2 < n2; ++m2) ya[q1 * n2 + m2] = c_mul(z[p->pos_n2[m2]], p->bz_tl[q1 * n2 + m2]);
     }
     for (int64_t k = p->info.kmin; k < p->info.kmax; ++k) {
-        int64_t k1 = k / n2, k2 = k % n2;
+        int64_t m1 = k / n2, m2 = k % n2;
         float ar = 0.0f, ai = 0.0f;
-        for (int64_t r = 0; r < n1; ++r) {
-            cf d = p->tw_n1[(r * k1) % n1];
-            cf y = ya[r * n2 + k2];
+        for (int64_t q1 = 0; q1 < n1; ++q1) {
+            cf d = p->tw_n1[(q1 * m1) % n1];
+            cf y = ya[q1 * n2 + m2];
             ar = fmaf(d.r, y.r, ar);
             ar = fmaf(-d.i, y.i, ar);
             ai = fmaf(d.i, y.r, ai);
@@ -876,7 +860,6 @@ static void spectrum_bluestein(const hpfw_oracle_plan *p, const int16_t *pcm, fl
     }
     free(z);
     free(ya);
-    free(yb);
 }
 
 void hpfw_oracle_spectrum(const hpfw_oracle_plan *p, const int16_t *pcm, float *x_ri)

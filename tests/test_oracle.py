@@ -236,13 +236,13 @@ def test_chirpz_tables_against_float64(oracle, n):
     n = abs(n)
     n1, n2, big_l = plan.n1, plan.n2, plan.n1 * plan.n2
     assert n2 == 6300 and n1 == 16 * -(-(n + (plan.kmax - plan.kmin) - 1) // (16 * 6300))
-    idx = np.arange(n1)[:, None] + n1 * np.arange(n2)[None, :]           # table element [r][t] stands for r + n1 t
+    j = np.arange(big_l)                                                 # w, the lags: flat index j = n2 k1' + k2'
 
     def chirp(m):
         m = np.asarray(m, np.int64)
         return np.exp(-1j * np.pi * ((m * m) % (2 * n)) / n)
 
-    w = np.where(idx < n, chirp(np.minimum(idx, n - 1)), 0).ravel()
+    w = np.where(j < n, chirp(np.minimum(j, n - 1)), 0)
     assert np.abs(plan.chirpz_table(0) - w).max() < 1e-7
     tl = np.exp(-2j * np.pi * ((np.arange(n1)[:, None] * np.arange(n2)[None, :]) % big_l) / big_l).ravel()
     assert np.abs(plan.chirpz_table(1) - tl).max() < 1e-7
@@ -251,7 +251,7 @@ def test_chirpz_tables_against_float64(oracle, n):
     b = np.zeros(big_l, np.complex128)
     m = np.arange(plan.kmin - (n - 1), plan.kmax)
     b[m % big_l] = np.conj(chirp(np.abs(m)))
-    bhat = np.fft.fft(b)                                                   # flat index n2 k1 + k2: the table's layout
+    bhat = np.fft.fft(b).reshape(n2, n1).T.ravel()                         # the table holds frequency q1 + n1 q2 at [q1][q2]
     got = plan.chirpz_table(2).astype(np.complex128)
     assert np.abs(got - bhat).max() < 2e-6 * np.abs(bhat).max()
     assert np.sqrt(np.mean(np.abs(got - bhat) ** 2)) < 3e-7 * np.sqrt(np.mean(np.abs(bhat) ** 2))
