@@ -466,9 +466,10 @@ def test_extreme_signals(torch_cuda, oracle, filters):
     g.close()
 
 
-@pytest.mark.parametrize("n", [1323001, 352799, 99991, 220499, 54254])
+@pytest.mark.parametrize("n", [1323001, 352799, 99991, 220499, 54254, 1764001])
 def test_arbitrary_clip_lengths(gpu, torch_cuda, oracle, filters, n):
-    """clip lengths with a prime factor above 7 (1323001 = 11 * 120273, 13 | 352799, 99991 prime, ...): the
+    """clip lengths with a prime factor above 7 (1323001 = 11 * 120273, 13 | 352799, 99991 prime, ...; 1764001: 40 s,
+    two row tiles of the two-stage column transform): the
     reference transforms the file's exact sample count (cqt.h:54-55) and so does the chirp-z forward transform
     (k_bluestein.hip): forward bins and dB spectrogram bit-exact against the oracle, |CQ| within
     1e-4 of every band's maximum against the float64 definition at that exact length, hashprints identical"""

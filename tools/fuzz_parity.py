@@ -32,8 +32,8 @@ for r in range(rounds):
     if r % 2 == 0:   # a 7-smooth length (mixed-radix forward transform), 1.4 s to 75 s
         smooth = [m for m in range(10, 526) if all(p in (2, 3, 5, 7) for p in _factors(m))]
         n = 6300 * int(rng.choice(smooth))
-    else:            # any length (almost surely with a prime factor above 7: the chirp-z forward transform); the
-        n = int(rng.integers(60000, 44100 * 20))   # oracle's dense column DFT costs n1^2, so these stay below 20 s
+    else:            # any length (almost surely with a prime factor above 7: the chirp-z forward transform), up to
+        n = int(rng.integers(60000, 44100 * 75))   # 75 s: one to three row tiles of the two-stage column transform
     nb = int(rng.integers(1, 5))
     g.set_batch(int(rng.integers(1, 4)))
     clips = np.stack([synth.gen_clip(int(rng.integers(1, 1 << 30)), n / 44100.0)[:n] for _ in range(nb)])
