@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the oracle altogether (profiling runs: nothing but the product in the process)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) section")
+    ap.add_argument("--no-any-length", action="store_true",
+                    help="skip the section on clips whose length is not 7-smooth (chirp-z forward transform)")
     ap.add_argument("--cpu-clips-per-core", type=int, default=4,
                     help="CPU baseline sample: clips per host thread (about 10 s of CPU work)")
     args = ap.parse_args()
@@ -236,6 +238,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_pcie:
         pcie = bench_pcie(torch, gpu, pcm, n_samples, geo, hp)
 
+    any_len = None
+    if rank == 0 and world == 1 and not args.no_any_length:
+        any_len = bench_any_length(torch, gpu, pcm, n_samples, None if args.no_parity else __import__("oracle.oracle").oracle, filt)
+
     search = None
     if not args.no_search:
         search = bench_search(torch, tdist if world > 1 else None, gpu, hdist, synth, args, rank, world, device,
@@ -267,7 +273,7 @@ def main():
             "event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
             "kernel_ms_one_pass": split,
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
-            "pcie_inclusive": pcie, "search": search,
+            "pcie_inclusive": pcie, "any_length": any_len, "search": search,
             "stream": stream_res, "filter_learning": learn,
         }
         print(json.dumps(line), flush=True)
@@ -350,6 +356,38 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
             "ms_per_search": round(dt * 1e3 / reps, 3), "queries_per_s": round(nq * reps / dt, 1),
             "planted_queries_found": ok,
             "scan_kernel": _scan_roofline(scan_rate)}
+
+
+def bench_any_length(torch, gpu, pcm, n_samples, oracle_mod, filt, n=256):
+    """the same clips one sample longer: a length with a prime factor above 7, which takes the chirp-z forward transform
+    (real recordings have whatever length they have).  Reports the first use of the length (its tables are generated on
+    the device) and the steady state; two clips against the oracle.  Never `value`."""
+    n = min(n, pcm.shape[0] - 1)
+    m = n_samples + 1
+    flat = pcm.reshape(-1)
+    odd = flat[: n * m].reshape(n, m)           # n clips of m samples cut from the same signal
+    t0 = time.perf_counter()
+    geo = gpu.geometry(m)                       # builds the plan: host tables of the constant-Q stage + device tables
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    hp = torch.empty((n, geo.n_hp), dtype=torch.int64, device=pcm.device)
+    gpu.extract_dev(odd.data_ptr(), m, n, hp.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        gpu.extract_dev(odd.data_ptr(), m, n, hp.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out = {"clip_samples": m, "n1": geo.n1, "n2": geo.n2, "clips": n, "clips_per_s": round(n / dt, 1),
+           "hashprints_per_s": round(n * geo.n_hp / dt, 1), "first_use_ms": round(first_ms, 2),
+           "note": "clip length with a prime factor above 7: chirp-z forward transform on the exact length (no padding)"}
+    if oracle_mod is not None:
+        plan = oracle_mod.Plan(m)
+        idx = [0, n - 1]
+        want = np.stack([plan.extract(filt, odd[i].cpu().numpy()) for i in idx])
+        out["bit_identical_clips_checked"] = 2 if np.array_equal(hp[idx].cpu().numpy().view(np.uint64), want) else 0
+    return out
 
 
 def bench_pcie(torch, gpu, pcm, n_samples, geo, hp_dev, n=256):

@@ -14,7 +14,7 @@ rm -rf gpurun_out/prof
 mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace -o p --output-format csv -- python3 bench.py > gpurun_out/prof/bench_trace.log 2> gpurun_out/prof/bench_trace.err || { echo "trace run failed"; tail -5 gpurun_out/prof/bench_trace.err; exit 1; }
 echo "trace done"
-LIGHT="--no-parity --no-cpu-baseline --no-pcie --no-learn --steps 2 --warmup 1"
+LIGHT="--no-parity --no-cpu-baseline --no-pcie --no-any-length --no-learn --steps 2 --warmup 1"
 for c in fetch:FETCH_SIZE write:WRITE_SIZE \
          "sq1:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
          "sq2:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
