@@ -9,8 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -94,6 +97,11 @@ struct hpfw_gpu {
     bool has_filters = false;
     float *d_fpack = nullptr;
     std::map<int64_t, std::unique_ptr<DevPlan>> plans; // one per clip length, least recently used evicted
+    // host halves of plans prepared ahead by other threads (hpfw_gpu_prepare_length): a null entry is being built
+    std::mutex host_mtx;
+    std::condition_variable host_cv;
+    std::map<int64_t, std::unique_ptr<hpfw::HostPlan>> host_ready;
+    std::set<int64_t> host_seen; // lengths prepared or planned at least once (never prepared twice)
     size_t plan_bytes = 0;
     uint64_t plan_clock = 0;
     unsigned conventions = 0; // hpfw_gpu_set_conventions: essentia conventions that cannot be checked offline
@@ -251,8 +259,22 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     g_uploaded = 0;
     auto dp = std::make_unique<DevPlan>();
     std::string why;
+    bool have_host = false;
+    {
+        // the host half may have been prepared (or be in preparation) by a reader thread: take it, or wait for it
+        std::unique_lock<std::mutex> lock(h->host_mtx);
+        auto ready = h->host_ready.find(n);
+        if (ready != h->host_ready.end()) {
+            h->host_cv.wait(lock, [&] { return h->host_ready.find(n)->second != nullptr; });
+            ready = h->host_ready.find(n);
+            have_host = ready->second->n == n;     // (a failed preparation leaves an empty plan: rebuilt below for its message)
+            if (have_host) dp->hp = std::move(*ready->second);
+            h->host_ready.erase(ready);
+        }
+        h->host_seen.insert(n);
+    }
     // HPFW_FORCE_BLUESTEIN=1 (tests): the chirp-z forward transform for 7-smooth lengths too
-    if (!hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions))
+    if (!have_host && !hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions))
         return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n) + ": " + why);
     const hpfw::HostPlan &p = dp->hp;
     using hpfw::cf;
@@ -661,6 +683,14 @@ int hpfw_gpu_set_conventions(hpfw_gpu *h, unsigned flags)
         HIP_TRY(hipDeviceSynchronize());
         h->plans.clear();
         h->plan_bytes = 0;
+        std::unique_lock<std::mutex> lock(h->host_mtx);
+        h->host_cv.wait(lock, [&] { // (preparations in flight finish first: their threads write into the map)
+            for (auto &kv : h->host_ready)
+                if (!kv.second) return false;
+            return true;
+        });
+        h->host_ready.clear();
+        h->host_seen.clear();
     }
     h->conventions = flags;
     return 0;
@@ -749,6 +779,33 @@ int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_sampl
         rc = fail(HPFW_E_HIP, "D2H copy failed");
     if (hipStreamSynchronize(s_comp) != hipSuccess && !rc) rc = fail(HPFW_E_HIP, "kernel execution failed");
     return rc;
+}
+
+// Host half of the tables of a clip length, built on the CALLING thread and kept for the next entry point that meets
+// the length (which then only generates / uploads the device tables).  Thread-safe against every other call on the
+// handle: the collectors' reader threads call it for each file they have decoded.
+int hpfw_gpu_prepare_length(hpfw_gpu *h, int64_t n_samples)
+{
+    if (!h) return fail(HPFW_E_INVALID, "null handle");
+    {
+        std::scoped_lock lock(h->host_mtx);
+        if (!h->host_seen.insert(n_samples).second) return 0; // known already
+        h->host_ready[n_samples] = nullptr;                   // in preparation
+    }
+    auto hp = std::make_unique<hpfw::HostPlan>();
+    std::string why;
+    bool ok;
+    {
+        hpfw::PlanSerial serial;
+        ok = hpfw::build_plan(n_samples, *hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions);
+    }
+    if (!ok) *hp = hpfw::HostPlan(); // n = 0: get_plan builds it again and reports why
+    {
+        std::scoped_lock lock(h->host_mtx);
+        h->host_ready[n_samples] = std::move(hp);
+    }
+    h->host_cv.notify_all();
+    return ok ? 0 : fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n_samples) + ": " + why);
 }
 
 // ---- diagnostic: the device-generated tables of the chirp-z forward transform ------------------

@@ -306,7 +306,11 @@ struct Loaded {
 
 // the reference reads its files on a taskflow pool (parallel_collector.h:95-108); here a team of host
 // threads decodes one window of files while the device stages take whole groups of clips
-void read_window(const char **filenames, const std::vector<int> &files, size_t first, size_t last, std::vector<Loaded> &out)
+// gpu: the reader threads also prepare the host half of the tables of every length they meet (hpfw_gpu_prepare_length:
+// a corpus of full-length tracks brings a new length with almost every file, and that half costs more than the file's
+// extraction), so that the device stages find them ready
+void read_window(const char **filenames, const std::vector<int> &files, size_t first, size_t last, std::vector<Loaded> &out,
+                 hpfw_gpu *gpu)
 {
     std::mutex why_mtx;
     std::string first_why; // the reader threads' messages are thread-local: keep the first failure for the caller
@@ -319,6 +323,7 @@ void read_window(const char **filenames, const std::vector<int> &files, size_t f
         for (int i; (i = next.fetch_add(1)) < count;) {
             std::string why;
             out[(size_t)i].ok = read_clip(filenames[files[first + (size_t)i]], out[(size_t)i].pcm, why);
+            if (out[(size_t)i].ok && gpu) (void)hpfw_gpu_prepare_length(gpu, (int64_t)out[(size_t)i].pcm.size()); // (too short: skipped later)
             if (!out[(size_t)i].ok) {
                 std::scoped_lock lock(why_mtx);
                 if (first_why.empty()) first_why = why;
@@ -441,7 +446,7 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
             ++end;
         }
         std::vector<Loaded> clips;
-        read_window(filenames, files, at, end, clips);
+        read_window(filenames, files, at, end, clips, c->gpu);
         std::map<int64_t, std::vector<int>> by_len; // length -> positions in the window, in input order
         for (size_t i = 0; i < clips.size(); ++i)
             if (clips[i].ok) by_len[(int64_t)clips[i].pcm.size()].push_back((int)i);

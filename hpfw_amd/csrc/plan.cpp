@@ -204,10 +204,12 @@ bool make_radix_list(int64_t n, std::vector<int> &radix)
 // fn(i) for i in [0, n) on a small team of host threads: the table entries are pure functions of their
 // index, so the result does not depend on the split (a new clip length costs one table build, and a
 // corpus of full-length tracks brings a new length with almost every file)
+thread_local bool g_plan_serial = false; // PlanSerial: the caller is itself one of many host threads
+
 template <class F>
 static void parallel_rows(int64_t n, F fn)
 {
-    unsigned team = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned team = g_plan_serial ? 1u : std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     if ((int64_t)team > n) team = (unsigned)n;
     if (team <= 1) {
         for (int64_t i = 0; i < n; ++i) fn(i);
@@ -222,6 +224,9 @@ static void parallel_rows(int64_t n, F fn)
     work();
     for (auto &t : th) t.join();
 }
+
+PlanSerial::PlanSerial() : before(g_plan_serial) { g_plan_serial = true; }
+PlanSerial::~PlanSerial() { g_plan_serial = before; }
 
 bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bool force_bluestein, unsigned conv)
 {

@@ -62,6 +62,13 @@ enum : unsigned {
     kConvNoIfftScale = 8u,    // band transforms without the 1/M of the inverse FFT (only the 1e-10 power floor sees it)
     kConvAll = 15u
 };
+// While one of these lives, build_plan on this thread does not spawn its own team of host threads (the caller is
+// already one of many: the collectors' reader threads prepare the tables of their files' lengths)
+struct PlanSerial {
+    PlanSerial();
+    ~PlanSerial();
+    bool before;
+};
 // force_bluestein: take the chirp-z forward transform even when the length is 7-smooth (tests)
 bool build_plan(int64_t n_samples, HostPlan &out, std::string &why, bool geometry_only = false,
                 bool force_bluestein = false, unsigned conventions = 0);

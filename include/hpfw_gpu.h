@@ -280,6 +280,14 @@ int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8);
 /* the same with the chirp-z forward transform forced and under given conventions (HPFW_CONV_*) */
 int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein, unsigned conventions, uint64_t *out8);
 
+/* ---- table preparation ahead of time.  A corpus of real recordings brings a new clip length with almost every file,
+ * and the host half of a length's tables (constant-Q windows and chirp spectra, twiddles) costs more than the
+ * extraction of the file: 3 ms for 30 s, 15 ms for 3 minutes.  hpfw_gpu_prepare_length builds that half on the
+ * CALLING thread and keeps it for the next call that meets the length; it may be called from any number of threads
+ * concurrently with any other call on the handle (the collectors' file-reader threads do so for every file they
+ * decode).  Returns HPFW_E_UNSUPPORTED for a length outside the supported range. */
+int hpfw_gpu_prepare_length(hpfw_gpu *h, int64_t n_samples);
+
 /* ---- diagnostic: the tables of the chirp-z forward transform (clip lengths with a prime factor above 7), which are
  * generated on the device.  which: 0 = chirp w [n1][n2], 1 = T_L [n1][n2], 2 = Bhat [n1][n2],
  * 3 = w[k] / L [kmax - kmin]; complex as (re, im) float pairs.  *count = floats in the table; out may be NULL to

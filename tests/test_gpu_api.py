@@ -323,3 +323,40 @@ def test_streams_mixed_without_sync(torch_cuda, oracle, filters):
     hp, off = g.index_get()
     assert np.array_equal(hp.view(np.int64).reshape(n, per), clips.cpu().numpy())
     g.close()
+
+
+def test_tables_prepared_by_other_threads(torch_cuda, oracle, filters):
+    """hpfw_gpu_prepare_length: host threads build the host half of the tables of the lengths they meet while the
+    calling thread extracts -- lengths prepared ahead, a length in preparation at the moment it is needed, a length
+    never prepared, a length prepared twice and an unsupported one; every hashprint equals the oracle's"""
+    import threading
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filters)
+    lengths = [132300, 132301, 99991, 88211, 220501, 176400]     # 7-smooth and not
+    clips = {n: np.stack([synth.gen_clip(700 + i, n / 44100.0 + 0.1)[:n] for i in range(2)]) for n in lengths}
+    errors = []
+
+    def prepare(ns):
+        try:
+            for n in ns:
+                g.prepare_length(n)
+        except Exception as e:                                    # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=prepare, args=(lengths[i::3] + lengths[:2],)) for i in range(3)]   # overlaps: twice
+    for t in th:
+        t.start()
+    got = {n: g.extract(clips[n]) for n in lengths[::-1]}         # may meet lengths still in preparation
+    for t in th:
+        t.join()
+    assert not errors, errors
+    extra = 352799                                                # never prepared: built by the extracting thread
+    c = np.stack([synth.gen_clip(777, 8.1)[:extra]])
+    assert np.array_equal(g.extract(c), np.stack([oracle.Plan(extra).extract(filters, c[0])]))
+    for n in lengths:
+        plan = oracle.Plan(n)
+        assert np.array_equal(got[n], np.stack([plan.extract(filters, x) for x in clips[n]])), n
+    with pytest.raises(hpfw_amd.HpfwError):
+        g.prepare_length(1000)                                    # too short
+    g.prepare_length(132300)                                      # known already: nothing happens
+    g.close()
