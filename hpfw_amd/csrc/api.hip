@@ -803,6 +803,7 @@ int hpfw_gpu_prepare_length(hpfw_gpu *h, int64_t n_samples)
     {
         std::scoped_lock lock(h->host_mtx);
         h->host_ready[n_samples] = std::move(hp);
+        if (!ok) h->host_seen.erase(n_samples); // an unsupported length says so every time it is asked for
     }
     h->host_cv.notify_all();
     return ok ? 0 : fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n_samples) + ": " + why);
