@@ -519,6 +519,24 @@ def test_chirpz_tables_generated_on_device(gpu, oracle, n):
         gpu.chirpz_table(132300, 0)                               # a 7-smooth length has none
 
 
+def test_three_minute_clip_of_a_non_smooth_length(gpu, torch_cuda, oracle, filters):
+    """3 minutes + 1 sample (n1 = 1392: six row tiles of the two-stage column transform; constant-Q classes above the
+    LDS, k_cq_big.hip): the device-generated tables, the forward bins and the hashprints, bit for bit"""
+    torch = torch_cuda
+    n = 180 * 44100 + 1
+    plan = oracle.Plan(n)
+    assert gpu.geometry(n).n1 == plan.n1 == 1392
+    for which in range(4):
+        assert np.array_equal(gpu.chirpz_table(n, which).view(np.uint64), plan.chirpz_table(which).view(np.uint64)), which
+    clip = synth.gen_clip(4242, 180.1)[:n]
+    d_pcm = _dev(torch, clip[None])
+    d_x = torch.empty((1, plan.kmax - plan.kmin, 2), dtype=torch.float32, device="cuda")
+    gpu.stage_spectrum_dev(d_pcm.data_ptr(), n, 1, d_x.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_x.cpu().numpy()[0], plan.spectrum(clip))
+    assert np.array_equal(gpu.extract(clip[None]), plan.extract(filters, clip)[None])
+
+
 def test_chirpz_path_agrees_with_mixed_radix_path(oracle, filters, monkeypatch):
     """a 7-smooth length through both forward transforms (HPFW_FORCE_BLUESTEIN=1): each bit-exact against its
     own oracle twin; the two spectrograms agree to float rounding and the hashprints differ in a handful of
