@@ -51,7 +51,11 @@ for i in range(nb):
 inp, out = "/tmp/mfma_probe_in.bin", "/tmp/mfma_probe_out.bin"
 with open(inp, "wb") as f:
     f.write(A.tobytes()); f.write(B.tobytes()); f.write(C.tobytes())
-subprocess.check_call([os.path.join(here, "mfma_bf16_probe.bin"), inp, out, str(nb)])
+exe = os.path.join(here, "mfma_bf16_probe.bin")
+if not os.path.exists(exe):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-Wno-unused-value",
+                           os.path.join(here, "mfma_bf16_probe.hip"), "-o", exe])
+subprocess.check_call([exe, inp, out, str(nb)])
 D = np.fromfile(out, np.float32).reshape(nb, 32, 32)
 if os.environ.get("MFMA_PROBE_DUMP"):
     np.savez_compressed(os.environ["MFMA_PROBE_DUMP"], A=A, B=B, C=C, D=D)
