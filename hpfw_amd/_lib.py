@@ -36,7 +36,8 @@ EXPORTS = (
     "hpfw_gpu_cfg_set_filters", "hpfw_gpu_cfg_hashprints", "hpfw_gpu_mel_hashprints_pcm16_host",
     "hpfw_gpu_cfg_cov_reset", "hpfw_gpu_cfg_cov_accumulate", "hpfw_gpu_cfg_cov_get", "hpfw_gpu_cfg_learn_filters",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
-    "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions", "hpfw_gpu_chirpz_table", "hpfw_gpu_prepare_length",
+    "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions", "hpfw_gpu_chirpz_table", "hpfw_gpu_prepare_length", "hpfw_gpu_set_projection", "hpfw_gpu_get_projection",
+    "hpfw_gpu_hashprints_from_db",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_calc_hashprints", "par_collector_save", "par_collector_load",
     "prepare_result_free", "calc_hashprint_result_free",
@@ -138,6 +139,9 @@ def lib():
     L.hpfw_gpu_plan_checksum_ex.argtypes = [i64, i32, u32, vp]
     L.hpfw_gpu_chirpz_table.argtypes = [vp, i64, i32, vp, i64, vp]
     L.hpfw_gpu_prepare_length.argtypes = [vp, i64]
+    L.hpfw_gpu_set_projection.argtypes = [vp, i32]
+    L.hpfw_gpu_get_projection.argtypes = [vp]
+    L.hpfw_gpu_hashprints_from_db.argtypes = [vp, vp, i64, i64, vp, vp]
     L.hpfw_gpu_set_conventions.argtypes = [vp, u32]
     L.par_collector_new.restype = vp
     L.par_collector_del.argtypes = [vp]
@@ -220,6 +224,16 @@ class Gpu:
         hp = np.zeros((pcm.shape[0], g.n_hp), np.uint64)
         check(lib().hpfw_gpu_extract_pcm16_host(self._h, _hp(pcm), pcm.shape[1], pcm.shape[0], _hp(hp)))
         return hp
+
+    def set_projection(self, mode):
+        """1 (default): fixed-point projection, exact integer sums (S9q); 0: the f32 fma chain (S9)"""
+        check(lib().hpfw_gpu_set_projection(self._h, int(mode)))
+
+    def get_projection(self):
+        return int(lib().hpfw_gpu_get_projection(self._h))
+
+    def hashprints_from_db_dev(self, d_db, n_clips, c, d_hp, stream=0):
+        check(lib().hpfw_gpu_hashprints_from_db(self._h, d_db, n_clips, c, d_hp, stream))
 
     def prepare_length(self, n_samples):
         """build the host half of the tables of a clip length on the calling thread (thread-safe; see hpfw_gpu.h)"""

@@ -96,6 +96,8 @@ struct hpfw_gpu {
     int device = 0;
     bool has_filters = false;
     float *d_fpack = nullptr;
+    void *d_fq_image = nullptr; // the filters' fixed-point digits (k_project_q.hip)
+    int projection = 1;         // 1: fixed point (S9q), 0: the f32 fma chain (S9); hpfw_gpu_set_projection
     std::map<int64_t, std::unique_ptr<DevPlan>> plans; // one per clip length, least recently used evicted
     // host halves of plans prepared ahead by other threads (hpfw_gpu_prepare_length): a null entry is being built
     std::mutex host_mtx;
@@ -446,7 +448,7 @@ int pass_clips(hpfw_gpu *h, const DevPlan *dp, int64_t n_clips)
 {
     const hpfw::HostPlan &p = dp->hp;
     size_t per_clip = (size_t)2 * p.n1 * ((p.h + 31) / 32 * 32) * 4 + (size_t)(p.kmax - p.kmin) * 8 + (size_t)121 * p.c * 4 +
-                      (size_t)64 * std::max(p.n_frames, 1) * 4 + (size_t)((p.n1 + 1) / 2) * p.n2 * 4;
+                      (size_t)64 * std::max(p.n_frames, 1) * 8 + (size_t)((p.n1 + 1) / 2) * p.n2 * 4;
     if (p.bluestein) per_clip += 2 * hpfw::bz_plane_bytes(dp->bz, 1);
     size_t work = 0;
     for (const hpfw::CqClassDev &cd : dp->cls) work = std::max(work, hpfw::cq_big_work_bytes(cd, 1));
@@ -467,7 +469,7 @@ int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
     const size_t planar = p.bluestein ? hpfw::bz_plane_bytes(dp->bz, nb) : 0;
     const size_t need[7] = {p.bluestein ? planar : (size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4,
                             (size_t)nb * (p.kmax - p.kmin) * 8,
-                            (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4,
+                            (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 8, // (P as int64 for the fixed-point projection)
                             (size_t)ns * 121 * hpfw::kCqMaxWaves * 4,
                             p.bluestein ? 0 : (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4, planar}; // (the chirp-z path reads the PCM as it lies)
     for (int i = 0; i < 7; ++i) {
@@ -553,6 +555,18 @@ int run_back(hpfw_gpu *h, DevPlan *dp, int ns, uint64_t *d_hp, hipStream_t s)
     float *sdb = (float *)h->ws[2];
     float *proj = (float *)h->ws[3];
     int rc;
+    if (h->projection) { // S9q: exact integer sums on the int8 matrix pipe
+        {
+            Timed t(h, K_PROJECT, s);
+            hpfw::launch_project_q(h->d_fq_image, sdb, h->d_clipmax, ns, p.c, (long long *)h->ws[3], s);
+        }
+        if ((rc = check_launch("project"))) return rc;
+        {
+            Timed t(h, K_PACK, s);
+            hpfw::launch_pack_q((const long long *)h->ws[3], ns, p.n_frames, d_hp, s);
+        }
+        return check_launch("delta_pack");
+    }
     {
         Timed t(h, K_PROJECT, s);
         hpfw::launch_project(h->d_fpack, sdb, h->d_clipmax, ns, p.c, proj, s);
@@ -607,6 +621,7 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     for (void *p : h->ws)
         if (p) (void)hipFree(p);
     if (h->d_fpack) (void)hipFree(h->d_fpack);
+    if (h->d_fq_image) (void)hipFree(h->d_fq_image);
     if (h->d_cov) (void)hipFree(h->d_cov);
     if (h->d_cov_ws) (void)hipFree(h->d_cov_ws);
     if (h->d_cqwork) (void)hipFree(h->d_cqwork);
@@ -659,7 +674,47 @@ int hpfw_gpu_set_filters(hpfw_gpu *h, const float *f)
     hpfw::pack_filters_for_mfma(f, packed.data());
     if (!h->d_fpack) HIP_TRY(hipMalloc((void **)&h->d_fpack, packed.size() * 4));
     HIP_TRY(hipMemcpy(h->d_fpack, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+    std::vector<int8_t> image;
+    hpfw::pack_filters_q(f, image);
+    if (!h->d_fq_image) HIP_TRY(hipMalloc(&h->d_fq_image, image.size()));
+    HIP_TRY(hipMemcpy(h->d_fq_image, image.data(), image.size(), hipMemcpyHostToDevice));
     h->has_filters = true;
+    return 0;
+}
+
+int hpfw_gpu_set_projection(hpfw_gpu *h, int mode)
+{
+    if (!h || (mode != 0 && mode != 1)) return fail(HPFW_E_INVALID, "projection mode must be 0 (f32 chain) or 1 (fixed point)");
+    h->projection = mode;
+    return 0;
+}
+
+int hpfw_gpu_get_projection(hpfw_gpu *h) { return h ? h->projection : -1; }
+
+// dB spectrograms [n_clips][121][c] (device) -> hashprints [n_clips][c - 99] with the handle's projection
+int hpfw_gpu_hashprints_from_db(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c, uint64_t *d_hp, void *stream)
+{
+    if (!h || !d_db || !d_hp) return fail(HPFW_E_INVALID, "null argument");
+    if (!h->has_filters) return fail(HPFW_E_NOFILTERS, "no filters: call hpfw_gpu_set_filters or hpfw_gpu_learn_filters first");
+    const int64_t nf = c - (hpfw::kCtx - 1), nhp = nf - hpfw::kLag;
+    if (nhp <= 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
+    int rc;
+    const int nbmax = 256;
+    if ((rc = ensure(&h->ws[3], &h->ws_bytes[3], (size_t)nbmax * 64 * (size_t)nf * 8))) return rc;
+    for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
+        const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
+        if (h->projection) {
+            hpfw::launch_project_q(h->d_fq_image, d_db + c0 * 121 * c, nullptr, nb, (int)c, (long long *)h->ws[3], s);
+            hpfw::launch_pack_q((const long long *)h->ws[3], nb, (int)nf, d_hp + c0 * nhp, s);
+        } else {
+            hpfw::launch_project(h->d_fpack, d_db + c0 * 121 * c, nullptr, nb, (int)c, (float *)h->ws[3], s);
+            hpfw::launch_pack((const float *)h->ws[3], nb, (int)nf, d_hp + c0 * nhp, s);
+        }
+        if ((rc = check_launch("project"))) return rc;
+    }
     return 0;
 }
 
@@ -955,19 +1010,16 @@ int hpfw_gpu_extract_db_host(hpfw_gpu *h, const float *s_colmajor, int32_t rows,
     std::vector<float> binmajor((size_t)rows * cols);
     for (int32_t c = 0; c < cols; ++c)
         for (int32_t b = 0; b < rows; ++b) binmajor[(size_t)b * cols + c] = s_colmajor[(size_t)c * rows + b];
-    float *d_s = nullptr, *d_p = nullptr;
+    float *d_s = nullptr;
     uint64_t *d_h = nullptr;
     int rc = 0;
-    if (hipMalloc((void **)&d_s, binmajor.size() * 4) != hipSuccess || hipMalloc((void **)&d_p, (size_t)64 * nf * 4) != hipSuccess ||
-        hipMalloc((void **)&d_h, (size_t)nh * 8) != hipSuccess)
+    if (hipMalloc((void **)&d_s, binmajor.size() * 4) != hipSuccess || hipMalloc((void **)&d_h, (size_t)nh * 8) != hipSuccess)
         rc = fail(HPFW_E_HIP, "out of device memory");
     if (!rc && hipMemcpy(d_s, binmajor.data(), binmajor.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(HPFW_E_HIP, "H2D copy failed");
-    if (!rc) rc = hpfw_gpu_stage_project(h, d_s, 1, cols, d_p, nullptr);
-    if (!rc) rc = hpfw_gpu_stage_pack(h, d_p, 1, nf, d_h, nullptr);
+    if (!rc) rc = hpfw_gpu_hashprints_from_db(h, d_s, 1, cols, d_h, nullptr);
     if (!rc && hipMemcpy(hp, d_h, (size_t)nh * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(HPFW_E_HIP, "D2H copy failed");
     if (d_s) (void)hipFree(d_s);
-    if (d_p) (void)hipFree(d_p);
     if (d_h) (void)hipFree(d_h);
     return rc;
 }

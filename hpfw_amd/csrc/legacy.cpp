@@ -375,14 +375,12 @@ float *group_spectrograms(hpfw_gpu *gpu, const std::vector<Loaded> &clips, const
 // hashprints of n clips from their dB spectrograms: out[k] = new uint64_t[g.n_hp]
 bool group_hashprints(hpfw_gpu *gpu, const float *d_db, size_t n, const hpfw_geometry &g, uint64_t **out)
 {
-    DevMem proj, hp;
-    if (!proj.alloc(n * 64 * (size_t)g.n_frames * 4) || !hp.alloc(n * (size_t)g.n_hp * 8)) {
+    DevMem hp;
+    if (!hp.alloc(n * (size_t)g.n_hp * 8)) {
         hpfw_internal_set_error("prepare: out of device memory");
         return false;
     }
-    if (hpfw_gpu_stage_project(gpu, d_db, (int64_t)n, g.c, (float *)proj.p, nullptr) != 0 ||
-        hpfw_gpu_stage_pack(gpu, (const float *)proj.p, (int64_t)n, g.n_frames, (uint64_t *)hp.p, nullptr) != 0)
-        return false;
+    if (hpfw_gpu_hashprints_from_db(gpu, d_db, (int64_t)n, g.c, (uint64_t *)hp.p, nullptr) != 0) return false;
     std::vector<uint64_t> host(n * (size_t)g.n_hp);
     if (hipMemcpy(host.data(), hp.p, host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) {
         hpfw_internal_set_error("prepare: D2H copy failed");

@@ -280,6 +280,18 @@ int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8);
 /* the same with the chirp-z forward transform forced and under given conventions (HPFW_CONV_*) */
 int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein, unsigned conventions, uint64_t *out8);
 
+/* ---- the projection's arithmetic.  The reference multiplies filters and frames in f32 (an Eigen/MKL sgemm,
+ * parallel_collector.h:57,127) and keeps only the sign of P[r,i] - P[r,i+80].  mode 1 (default): both factors rounded
+ * once to 24-bit fixed point, the 2420-term sums exact integers on the int8 matrix pipe (closer to the
+ * real-number product than an f32 sgemm in any order, and 3x faster than mode 0).  mode 0: the f32 fma chain in
+ * ascending k on the f32 matrix pipe.  The two differ in a hashprint bit only where the difference of
+ * the two projections is within rounding of zero. */
+int hpfw_gpu_set_projection(hpfw_gpu *h, int mode);
+int hpfw_gpu_get_projection(hpfw_gpu *h);
+/* dB spectrograms [n_clips][121][c] (device, as hpfw_gpu_stage_spectrogram writes them) -> hashprints
+ * [n_clips][c - 99] with the handle's filters and projection mode */
+int hpfw_gpu_hashprints_from_db(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c, uint64_t *d_hp, void *stream);
+
 /* ---- table preparation ahead of time.  A corpus of real recordings brings a new clip length with almost every file,
  * and the host half of a length's tables (constant-Q windows and chirp spectra, twiddles) costs more than the
  * extraction of the file: 3 ms for 30 s, 15 ms for 3 minutes.  hpfw_gpu_prepare_length builds that half on the

@@ -1059,6 +1059,68 @@ void hpfw_oracle_pack_cfg(const float *proj, int bits, int lag, int64_t n_frames
     }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* S9q / S10q: the projection in fixed point, exactly.                                           */
+/* The reference multiplies filters and frames in f32 (an Eigen/MKL sgemm, parallel_collector.h:57,127) and keeps    */
+/* only the SIGN of P[r,i] - P[r,i+80] (hashprint_handle.h:119-122).  Here both factors are rounded once to 24-bit   */
+/* fixed point and the 2420-term sums are exact integers:                                                             */
+/*   u[b][c]  = rint(S[b][c] * 2^17) + 40 * 2^17          (S in [-80, 0] dB; the offset centres the range and cancels */
+/*                                                          in the difference of two columns of the same filter)     */
+/*   fq[r][k] = rint(F[r][k] * 2^(21 - ilogb(max_k |F[r][k]|)))   (a positive power of two per filter row: it cannot  */
+/*                                                          change a sign)                                            */
+/*   Pq[r][n] = sum_{b,t} fq[r][20 b + t] * u[b][n + t]    (int64, |Pq| < 2^57)                                       */
+/*   bit (63 - r) of hp[i] = (Pq[r][i] - Pq[r][i + 80] >= 0)                                                          */
+/* The distance to the real-number projection (rounding of S: 2^-18 dB, of F: 2^-23 of the row's largest entry) is    */
+/* below the rounding error of an f32 sgemm over 2420 terms in any order; integer sums have no order.                 */
+/* ------------------------------------------------------------------------------------------ */
+void hpfw_oracle_quantise_filters(const float *f, int32_t *fq /* [64][2420], row-major */)
+{
+    const int kk = HPFW_O_BINS * HPFW_O_CTX;
+    for (int r = 0; r < HPFW_O_NFILT; ++r) {
+        float m = 0.0f;
+        for (int k = 0; k < kk; ++k) m = fmaxf(m, fabsf(f[(size_t)k * HPFW_O_NFILT + r]));
+        const int e = m > 0.0f ? 21 - ilogbf(m) : 0;
+        for (int k = 0; k < kk; ++k) fq[(size_t)r * kk + k] = (int32_t)rintf(ldexpf(f[(size_t)k * HPFW_O_NFILT + r], e));
+    }
+}
+
+void hpfw_oracle_project_q(const float *f, const float *s_db, int64_t c, int64_t *proj /* [64][c - 19] */)
+{
+    const int64_t nf = c - (HPFW_O_CTX - 1);
+    const int kk = HPFW_O_BINS * HPFW_O_CTX;
+    int32_t *fq = (int32_t *)malloc(sizeof(int32_t) * (size_t)HPFW_O_NFILT * kk);
+    int32_t *u = (int32_t *)malloc(sizeof(int32_t) * (size_t)(HPFW_O_BINS * c));
+    hpfw_oracle_quantise_filters(f, fq);
+    for (int64_t i = 0; i < HPFW_O_BINS * c; ++i) u[i] = (int32_t)rintf(s_db[i] * 131072.0f) + 40 * 131072;
+    for (int r = 0; r < HPFW_O_NFILT; ++r) {
+        int64_t *pr = proj + (int64_t)r * nf;
+        for (int64_t n = 0; n < nf; ++n) pr[n] = 0;
+        for (int b = 0; b < HPFW_O_BINS; ++b)
+            for (int t = 0; t < HPFW_O_CTX; ++t) {
+                const int64_t w = fq[(size_t)r * kk + b * HPFW_O_CTX + t];
+                const int32_t *ub = u + b * c + t;
+                for (int64_t n = 0; n < nf; ++n) pr[n] += w * (int64_t)ub[n];
+            }
+    }
+    free(u);
+    free(fq);
+}
+
+void hpfw_oracle_pack_q(const int64_t *proj, int64_t nf, uint64_t *hp)
+{
+    for (int64_t i = 0; i + HPFW_O_LAG < nf; ++i) {
+        uint64_t v = 0;
+        for (int r = 0; r < HPFW_O_NFILT; ++r)
+            if (proj[r * nf + i] - proj[r * nf + i + HPFW_O_LAG] >= 0) v |= 1ULL << (63 - r);
+        hp[i] = v;
+    }
+}
+
+/* 1 (default): the fixed-point projection S9q / S10q; 0: the f32 fma chain of S9 / S10.  What extraction uses. */
+static int g_projection_mode = 1;
+void hpfw_oracle_set_projection(int mode) { g_projection_mode = mode ? 1 : 0; }
+int hpfw_oracle_get_projection(void) { return g_projection_mode; }
+
 int64_t hpfw_oracle_extract(const hpfw_oracle_plan *p, const float *f, const int16_t *pcm, uint64_t *hp)
 {
     const int64_t c = p->info.c, nk = p->info.kmax - p->info.kmin;
@@ -1069,8 +1131,15 @@ int64_t hpfw_oracle_extract(const hpfw_oracle_plan *p, const float *f, const int
     hpfw_oracle_spectrum(p, pcm, x);
     hpfw_oracle_cqmag(p, x, mag);
     hpfw_oracle_db(mag, HPFW_O_BINS * c, mag);
-    hpfw_oracle_project(f, mag, c, proj);
-    hpfw_oracle_pack(proj, p->info.n_frames, hp);
+    if (g_projection_mode) {
+        int64_t *pq = (int64_t *)malloc(sizeof(int64_t) * (size_t)(HPFW_O_NFILT * p->info.n_frames));
+        hpfw_oracle_project_q(f, mag, c, pq);
+        hpfw_oracle_pack_q(pq, p->info.n_frames, hp);
+        free(pq);
+    } else {
+        hpfw_oracle_project(f, mag, c, proj);
+        hpfw_oracle_pack(proj, p->info.n_frames, hp);
+    }
     free(proj);
     free(mag);
     free(x);

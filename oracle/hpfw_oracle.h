@@ -81,6 +81,13 @@ void hpfw_oracle_db(const float *mag, int64_t n, float *s_db);
  *      f_colmajor: Filters = Matrix<float,64,Dynamic> column-major (hashprint_handle.h:68):
  *      element (r,k) at r + 64*k.  s_db bin-major [121][c].  out P row-major [64][c-19]. ---- */
 void hpfw_oracle_project(const float *f_colmajor, const float *s_db, int64_t c, float *proj);
+/* ---- a5..a8 in fixed point (S9q / S10q, see hpfw_oracle.c): exact integer sums of once-rounded factors ---- */
+void hpfw_oracle_quantise_filters(const float *f_colmajor, int32_t *fq /* [64][2420] row-major */);
+void hpfw_oracle_project_q(const float *f_colmajor, const float *s_db, int64_t c, int64_t *proj /* [64][c-19] */);
+void hpfw_oracle_pack_q(const int64_t *proj, int64_t n_frames, uint64_t *hp /* [n_frames-80] */);
+/* which projection hpfw_oracle_extract* use: 0 = the f32 fma chain (S9), 1 = fixed point (S9q) */
+void hpfw_oracle_set_projection(int mode);
+int hpfw_oracle_get_projection(void);
 /* ---- a7 + a8: calc_fingerprint + fingerprint_to_hashprint   hashprint_handle.h:115-142 ---- */
 void hpfw_oracle_pack(const float *proj, int64_t n_frames, uint64_t *hp /* [n_frames-80] */);
 /* ---- the same for any HashprintHandle<N, SH, FramesContext, T> (hashprint_handle.h:50-64), e.g. the

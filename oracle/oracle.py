@@ -60,6 +60,11 @@ def lib():
         L.hpfw_oracle_cqmag.argtypes = [vp, vp, vp]
         L.hpfw_oracle_db.argtypes = [vp, i64, vp]
         L.hpfw_oracle_project.argtypes = [vp, vp, i64, vp]
+        L.hpfw_oracle_project_q.argtypes = [vp, vp, i64, vp]
+        L.hpfw_oracle_pack_q.argtypes = [vp, i64, vp]
+        L.hpfw_oracle_quantise_filters.argtypes = [vp, vp]
+        L.hpfw_oracle_set_projection.argtypes = [i32]
+        L.hpfw_oracle_get_projection.restype = i32
         L.hpfw_oracle_pack.argtypes = [vp, i64, vp]
         L.hpfw_oracle_project_cfg.argtypes = [vp, vp, i32, i32, i32, i64, i64, vp]
         L.hpfw_oracle_pack_cfg.argtypes = [vp, i32, i32, i64, i64, vp]
@@ -177,6 +182,45 @@ def project(filters, s_db):
     out = np.zeros((NFILT, c - CTX + 1), np.float32)
     lib().hpfw_oracle_project(_p(f), _p(s), c, _p(out))
     return out
+
+
+def project_q(filters, s_db):
+    """S9q: the projection in fixed point (exact int64 sums of once-rounded 24-bit factors)"""
+    f = _c(filters, np.float32)
+    s = _c(s_db, np.float32)
+    c = s.shape[1]
+    out = np.zeros((NFILT, c - CTX + 1), np.int64)
+    lib().hpfw_oracle_project_q(_p(f), _p(s), c, _p(out))
+    return out
+
+
+def pack_q(proj):
+    pr = _c(proj, np.int64)
+    nf = pr.shape[1]
+    hp = np.zeros(max(nf - LAG, 0), np.uint64)
+    lib().hpfw_oracle_pack_q(_p(pr), nf, _p(hp))
+    return hp
+
+
+def quantise_filters(filters):
+    f = _c(filters, np.float32)
+    out = np.zeros((NFILT, BINS * CTX), np.int32)
+    lib().hpfw_oracle_quantise_filters(_p(f), _p(out))
+    return out
+
+
+def hashprints_from_db(filters, s_db):
+    """dB spectrogram [121][C] -> hashprints with the projection in force (set_projection)"""
+    return pack_q(project_q(filters, s_db)) if get_projection() else pack(project(filters, s_db))
+
+
+def set_projection(mode):
+    """what Plan.extract* use: 1 (default) = fixed point (S9q), 0 = the f32 fma chain (S9)"""
+    lib().hpfw_oracle_set_projection(int(mode))
+
+
+def get_projection():
+    return int(lib().hpfw_oracle_get_projection())
 
 
 def pack(proj):

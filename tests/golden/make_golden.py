@@ -62,9 +62,12 @@ def main():
         x = plan.spectrum(pcm)
         mag = plan.cqmag(x)
         sdb = oracle.db(mag)
-        proj = oracle.project(filt, sdb)
-        hp = oracle.pack(proj)
-        assert np.array_equal(hp, plan.extract(filt, pcm))
+        proj = oracle.project(filt, sdb)                               # the f32 chain (S9): kept as a second statement
+        hp_f32 = oracle.pack(proj)
+        hp = oracle.pack_q(oracle.project_q(filt, sdb))                # fixed point (S9q): what extraction uses
+        assert oracle.get_projection() == 1 and np.array_equal(hp, plan.extract(filt, pcm))
+        flips = sum(bin(int(v)).count("1") for v in hp ^ hp_f32)
+        assert flips <= 1e-4 * hp.size * 64, flips
         # pin the oracle to the float64 definition before trusting it
         xref = np.fft.fft(pcm / 32768.0)[plan.kmin:plan.kmax]
         assert np.abs((x[:, 0] + 1j * x[:, 1]) - xref).max() / np.abs(xref).max() < 1e-6
@@ -78,6 +81,8 @@ def main():
         ext[f"{tag}_geometry"] = np.array([plan.n1, plan.n2, plan.kmin, plan.kmax, plan.m, plan.c,
                                            plan.n_frames, plan.n_hp], np.int64)
         ext[f"{tag}_hp"] = hp
+        ext[f"{tag}_hp_f32chain"] = hp_f32
+        ext[f"{tag}_projq_every8"] = oracle.project_q(filt, sdb)[::8, ::8].copy()
         ext[f"{tag}_mag_f32_every8"] = mag[::4, ::8].copy()        # float32, exact oracle bits
         ext[f"{tag}_mag_f64_every8"] = m64[::4, ::8].copy()        # float64 definition
         ext[f"{tag}_db_every8"] = sdb[::4, ::8].copy()

@@ -212,7 +212,7 @@ def test_index_readback_and_cached_spectrogram(torch_cuda, oracle, filters):
     for c in (100, 137, 404):
         s = rng.uniform(-80, 0, (121, c)).astype(np.float32)
         got = g.extract_db(np.ascontiguousarray(s.T))
-        assert np.array_equal(got, oracle.pack(oracle.project(filters, s)))
+        assert np.array_equal(got, oracle.hashprints_from_db(filters, s))
     assert g.extract_db(np.zeros((99, 121), np.float32)).size == 0          # too short: no hashprints
     with pytest.raises(hpfw_amd.HpfwError):
         g.extract_db(np.zeros((200, 120), np.float32))                         # not a 121-bin spectrogram

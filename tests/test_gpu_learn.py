@@ -177,7 +177,7 @@ def test_spectrogram_cache_and_incremental_indexing(torch_cuda, oracle, tmp_path
     for i, c in enumerate(clips):                            # == extracting all five with those filters
         assert np.array_equal(by_name[f"trk{i}"], oracle.Plan(c.size).extract(filt, c)), i
     assert np.array_equal(by_name["foreign"], g.extract_db(foreign))
-    assert np.array_equal(by_name["foreign"], oracle.pack(oracle.project(filt, np.ascontiguousarray(foreign.T))))
+    assert np.array_equal(by_name["foreign"], oracle.hashprints_from_db(filt, np.ascontiguousarray(foreign.T)))
     # the covariance kept accumulating across the two runs (parallel_collector.h:93-97 + load())
     rawc = np.frombuffer(open(os.path.join(cache, "accum_cov.cereal"), "rb").read()[8:], np.float32).reshape(2420, 2420)
     for c in clips:

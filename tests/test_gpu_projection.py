@@ -1,0 +1,62 @@
+"""The projection in fixed point (k_project_q.hip, exact integer sums on the int8 matrix pipe) against
+the oracle's integer restatement, and beside the f32 fma chain (S9) it replaces as the default."""
+import numpy as np
+import pytest
+
+import hpfw_amd
+from hpfw_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+def test_fixed_point_projection_is_exact(oracle):
+    """hashprints in both projection modes against the oracle in the same mode, ragged clip lengths (tiles of 256
+    frames with tails, widths below one tile), from PCM and from given dB spectrograms; the int64 projection itself"""
+    import torch
+    filt = synth.make_filters()
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filt)
+    assert g.get_projection() in (0, 1)
+    before = oracle.get_projection()
+    try:
+        for sec, nclips in ((30.0, 3), (5.0, 4), (2.3, 2), (7.77, 1)):
+            clips = np.stack([synth.gen_clip(900 + i, sec) for i in range(nclips)])
+            plan = oracle.Plan(clips.shape[1])
+            db = np.stack([oracle.db(plan.cqmag(plan.spectrum(c))) for c in clips])
+            d_db = torch.from_numpy(db).cuda()
+            for mode in (1, 0):
+                g.set_projection(mode)
+                oracle.set_projection(mode)
+                want = np.stack([plan.extract(filt, c) for c in clips])
+                assert np.array_equal(g.extract(clips), want), (sec, mode)
+                hp = torch.zeros((nclips, plan.n_hp), dtype=torch.int64, device="cuda")
+                g.hashprints_from_db_dev(d_db.data_ptr(), nclips, plan.c, hp.data_ptr())
+                torch.cuda.synchronize()
+                assert np.array_equal(hp.cpu().numpy().view(np.uint64), want), (sec, mode)
+    finally:
+        oracle.set_projection(before)
+        g.close()
+
+
+def test_the_two_projections_agree_within_rounding(oracle):
+    """the fixed-point projection, scaled back, lies within 10^-3 of the f32 chain (|P| up to ~140: that is the f32
+    chain's own rounding error); the hashprints of the two differ in at most 10^-4 of their bits"""
+    filt = synth.make_filters()
+    clip = synth.gen_clip(31, 20.0)
+    plan = oracle.Plan(clip.size)
+    db = oracle.db(plan.cqmag(plan.spectrum(clip)))
+    pf, pq = oracle.project(filt, db), oracle.project_q(filt, db)
+    fq = oracle.quantise_filters(filt)
+    m = np.abs(filt.reshape(2420, 64)).max(axis=0)
+    e = 21 - np.floor(np.log2(m)).astype(int)
+    back = (pq - (fq.astype(np.int64).sum(axis=1) * 40 * 131072)[:, None]) / (2.0 ** e)[:, None] / 131072.0
+    assert np.abs(back - pf).max() < 1e-3
+    x = oracle.pack(pf) ^ oracle.pack_q(pq)
+    assert sum(bin(int(v)).count("1") for v in x) <= 1e-4 * x.size * 64

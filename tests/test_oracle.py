@@ -151,8 +151,11 @@ def test_golden_extract(oracle):
         assert np.array_equal(s[::4, ::8], g[f"{tag}_db_every8"])
         pr = oracle.project(filt, s)
         assert np.array_equal(pr[::8, ::8], g[f"{tag}_proj_every8"])
-        assert np.array_equal(oracle.pack(pr), g[f"{tag}_hp"])
-        assert np.array_equal(plan.extract(filt, pcm), g[f"{tag}_hp"])
+        assert np.array_equal(oracle.pack(pr), g[f"{tag}_hp_f32chain"])
+        pq = oracle.project_q(filt, s)
+        assert np.array_equal(pq[::8, ::8], g[f"{tag}_projq_every8"])
+        assert np.array_equal(oracle.pack_q(pq), g[f"{tag}_hp"])
+        assert oracle.get_projection() == 1 and np.array_equal(plan.extract(filt, pcm), g[f"{tag}_hp"])
     two = np.stack([gen.golden_pcm(110250, 1), gen.golden_pcm(110250, 2)])
     hp = oracle.Plan(110250).extract_batch(filt, two, n_threads=2)
     assert np.array_equal(hp[0], g["a_hp"]) and np.array_equal(hp[1], g["b_hp"])
