@@ -27,6 +27,11 @@ if ROOT not in sys.path:
 
 PROJECT_FLOP_PER_CLIP = 2.0 * 64 * 2420 * 2400       # filters [64x2420] . frames [2420x2400]
 MFMA_F32_PEAK_TFLOPS = 157.3                         # MI355X_MICROARCH.md: dense f32 MFMA peak
+# the projection runs as nine digit products on v_mfma_i32_32x32x32_i8: 16x the multiply-adds per instruction of the f32
+# form (K = 32 against 2) at the same 16 passes -- measured: 7.08e15 digit multiply-adds' worth of instructions in
+# 2.82 ms whether or not the operand reads are quartered -- so 16 x 157.3 dense int8 TOP/s
+MFMA_I8_PEAK_TOPS = 16 * 157.3
+HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md
 VALU_PAIR_PEAK = 256 * 4 * 32 * 2.4e9 / 4            # xor/popcount kernel: 4 VALU lane-ops per 64-bit pair
 MFMA_FP4_PEAK_PFLOPS = 10.07                         # MI355X_MICROARCH.md: dense FP4 MFMA (32x32x64 in 32 cycles/SIMD)
 FP4_PAIR_PEAK = MFMA_FP4_PEAK_PFLOPS * 1e15 / 2 / 64 # one pair = 64 multiply-adds of +-1
@@ -145,8 +150,8 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    # dominant kernel (f32 MFMA projection): one HIP event pair per launch, on the launch stream
-    gpu.set_kernel_timing(1 << hpfw_amd.KERNEL_KINDS.index("project_mfma"))
+    # the two largest kernels (the row transforms and the projection): one HIP event pair per launch, on the launch stream
+    gpu.set_kernel_timing((1 << hpfw_amd.KERNEL_KINDS.index("project_mfma")) | (1 << hpfw_amd.KERNEL_KINDS.index("fwd_rows")))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -166,22 +171,56 @@ def main():
 
     pj_ms, pj_launches = kt["project_mfma"]
     clips_per_launch = n_clips * args.steps / max(pj_launches, 1)
-    achieved = PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0) * clips_per_launch / (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12 \
-        if pj_launches else 0.0
-    traffic = None
+    fixed_point = gpu.get_projection() == 1
+    traffic_json = {}
     tr_path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr_path):
         try:
-            per_clip = json.load(open(tr_path)).get("project_mfma_hbm_bytes_per_clip")
-            traffic = per_clip * clips_per_launch if per_clip is not None else None   # PMC bytes, per launch
+            traffic_json = json.load(open(tr_path))
         except Exception:
-            traffic = None
-    roofline = {"kernel": "project_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                "avg_launch_ms": round(pj_ms / max(pj_launches, 1), 4), "launches": pj_launches,
-                "flop_per_clip": PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0),
-                "clips_per_launch": clips_per_launch}
+            traffic_json = {}
+
+    def pmc_traffic(key):                              # PMC bytes per clip (profiles/), per launch here
+        per_clip = traffic_json.get(key)
+        return per_clip * clips_per_launch if per_clip is not None else None
+
+    if fixed_point:
+        # algorithmic work: the reference's 2*64*2420*n_frames multiply-adds, each as nine digit products (S9q)
+        ops_per_clip = 9 * PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0)
+        achieved = ops_per_clip * clips_per_launch / (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12 if pj_launches else 0.0
+        roof_pj = {"kernel": "project_q_kernel (v_mfma_i32_32x32x32_i8, nine digit products of 24-bit fixed-point factors)",
+                   "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                   "frac": round(achieved / MFMA_I8_PEAK_TOPS, 4), "traffic": pmc_traffic("project_q_hbm_bytes_per_clip"),
+                   "avg_launch_ms": round(pj_ms / max(pj_launches, 1), 4), "launches": pj_launches,
+                   "ops_per_clip": ops_per_clip, "clips_per_launch": clips_per_launch,
+                   "f32_equivalent_tflops": round(PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0) * clips_per_launch /
+                                                  (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12, 1) if pj_launches else 0.0}
+    else:
+        achieved = PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0) * clips_per_launch / (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12 \
+            if pj_launches else 0.0
+        roof_pj = {"kernel": "project_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                   "achieved": round(achieved, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("project_mfma_hbm_bytes_per_clip"),
+                   "avg_launch_ms": round(pj_ms / max(pj_launches, 1), 4), "launches": pj_launches,
+                   "flop_per_clip": PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0),
+                   "clips_per_launch": clips_per_launch}
+    # the row transforms: one complex FFT of n2 points per residue pair in LDS; algorithmic bytes = the residue streams
+    # in (4 bytes per pair and time step) + the planar half spectra out
+    rw_ms, rw_launches = kt["fwd_rows"]
+    rows_bytes = ((geo.n1 + 1) // 2) * geo.n2 * 4 + 2 * geo.n1 * ((geo.n2 // 2 + 1 + 31) // 32 * 32) * 4
+    rows_clips = n_clips * args.steps / max(rw_launches, 1)
+    rows_gbs = rows_bytes * rows_clips / (rw_ms / max(rw_launches, 1) * 1e-3) / 1e9 if rw_launches else 0.0
+    roof_rows = {"kernel": "fwd_rows_kernel (residue pairs: FFT_n2 in LDS, Hermitian split, twiddle)", "bound": "hbm",
+                 "achieved": round(rows_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rows_gbs / HBM_PEAK_GBS, 4),
+                 "traffic": (traffic_json.get("fwd_rows_hbm_bytes_per_clip") * rows_clips
+                             if traffic_json.get("fwd_rows_hbm_bytes_per_clip") is not None else None),
+                 "avg_launch_ms": round(rw_ms / max(rw_launches, 1), 4), "launches": rw_launches,
+                 "bytes_per_clip": rows_bytes, "clips_per_launch": rows_clips,
+                 "note": "latency- and issue-bound (profiles/*_sq.json: 22 % VALU issue, 60 % of wave-cycles parked on "
+                         "barriers and waits), not HBM-bound"}
+    dominant_is_rows = roof_rows["avg_launch_ms"] > roof_pj["avg_launch_ms"]
+    roofline = roof_rows if dominant_is_rows else roof_pj
+    roofline_second = roof_pj if dominant_is_rows else roof_rows
 
     # per-kernel split of one extra (untimed) pass, for the record
     gpu.set_kernel_timing(-1)
@@ -214,8 +253,8 @@ def main():
                 ta = time.perf_counter(); x = plan.spectrum(c)
                 tb = time.perf_counter(); m = plan.cqmag(x)
                 tc = time.perf_counter(); d = oracle.db(m)
-                td = time.perf_counter(); pr = oracle.project(filt, d)
-                te = time.perf_counter(); oracle.pack(pr)
+                td = time.perf_counter(); pr = oracle.project_q(filt, d) if oracle.get_projection() else oracle.project(filt, d)
+                te = time.perf_counter(); oracle.pack_q(pr) if oracle.get_projection() else oracle.pack(pr)
                 tf = time.perf_counter()
                 for key, dtk in zip(st, (tb - ta, tc - tb, td - tc, te - td, tf - te)):
                     st[key] += dtk
@@ -261,7 +300,8 @@ def main():
             "metric": "hashprints/sec (index) + Hamming matches/sec (search), 30 s@44.1 kHz clips",
             "value": round(value, 1), "unit": "hashprints/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (transforms, dB) + int8 digits / int64 sums (projection)" if fixed_point else "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {n_clips} x {args.seconds:g} s synthetic 44.1 kHz PCM16 clips per GPU, "
                                    "hashprint extraction only (CQT + dB + projection + bit pack), inputs resident in HBM",
                        "clips_per_gpu": n_clips, "clip_seconds": args.seconds, "hashprints_per_clip": geo.n_hp,
@@ -272,7 +312,7 @@ def main():
             "clips_per_s": round(value / geo.n_hp, 1),
             "event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
             "kernel_ms_one_pass": split,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+            "roofline": roofline, "roofline_second_kernel": roofline_second, "cpu_baseline": cpu_baseline, "parity": parity,
             "pcie_inclusive": pcie, "any_length": any_len, "search": search,
             "stream": stream_res, "filter_learning": learn,
         }

@@ -267,7 +267,7 @@ int hpfw_gpu_timer_start(hpfw_gpu *h, void *stream);
 int hpfw_gpu_timer_stop(hpfw_gpu *h, void *stream, float *ms); /* synchronises on the stop event */
 /* per-kernel device time, measured with one HIP event pair per launch on the launch stream.
  * mask bit i enables kernel kind i in the order reported by hpfw_gpu_get_kernel_timing
- * (fwd_rows, fwd_cols, cq_chirpz, db, project_mfma, delta_pack, hamming_scan, topk); -1 = all,
+ * (fwd_rows, fwd_cols, cq_chirpz, db, project_mfma, delta_pack, hamming_scan, topk, pcm_pairs); -1 = all,
  * 0 = off.  Setting the mask resets the accumulated times. */
 int hpfw_gpu_set_kernel_timing(hpfw_gpu *h, int mask);
 /* names[i] (static strings) and ms[i], launches[i] for i < *n; pass capacity in *n */

@@ -73,12 +73,16 @@ def main():
             d["hbm_bytes_per_launch"] = (2.0 * f_ + w_) * 1024.0
     if pmc:
         json.dump(pmc, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
-        pk = next((v for k, v in sorted(pmc.items()) if k.startswith("project_kernel<true") or k == "project_kernel"), {})
-        if "hbm_bytes_per_launch" in pk:
-            json.dump({"project_mfma_hbm_bytes_per_clip": pk["hbm_bytes_per_launch"] / clips,
-                       "clips_per_launch_profiled": clips, "source": f"{tag}_pmc.json",
-                       "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / clips, launches of the largest grid"},
-                      open(os.path.join(here, "traffic.json"), "w"), indent=1)
+        traffic = {"clips_per_launch_profiled": clips, "source": f"{tag}_pmc.json",
+                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / clips, launches of the largest grid"}
+        for key, prefixes in (("project_mfma_hbm_bytes_per_clip", ("project_kernel<true", "project_kernel")),
+                              ("project_q_hbm_bytes_per_clip", ("project_q_kernel<true", "project_q_kernel")),
+                              ("fwd_rows_hbm_bytes_per_clip", ("fwd_rows_kernel",))):
+            pk = next((v for k, v in sorted(pmc.items()) if any(k.startswith(px) for px in prefixes)), {})
+            if "hbm_bytes_per_launch" in pk:
+                traffic[key] = pk["hbm_bytes_per_launch"] / clips
+        if len(traffic) > 3:
+            json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)
     # ---- calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (tools/fetch_calib.bin streams 1 GiB per kernel)
     calib = {}
     for which, counter, kern in (("calib_fetch", "FETCH_SIZE", "calib_read"), ("calib_write", "WRITE_SIZE", "calib_write")):
