@@ -129,12 +129,13 @@ __global__ __launch_bounds__(kQThreads, 2) void project_q_kernel(const v4i *__re
         for (int j = 0; j < 3; ++j) b[set][j] = bu[j];
     };
     auto mult = [&](int set) {
+        // the two filter tiles in turn: instructions on the same accumulator (digit products of equal weight) stay four apart
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                for (int t2 = 0; t2 < 2; ++t2)
                     acc[t2][i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[set][t2][i], b[set][j], acc[t2][i + j], 0, 0, 0);
     };
     for (int t = 0; t < kCtx; ++t) {
