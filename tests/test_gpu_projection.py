@@ -60,3 +60,44 @@ def test_the_two_projections_agree_within_rounding(oracle):
     assert np.abs(back - pf).max() < 1e-3
     x = oracle.pack(pf) ^ oracle.pack_q(pq)
     assert sum(bin(int(v)).count("1") for v in x) <= 1e-4 * x.size * 64
+
+
+def test_fixed_point_projection_edge_values(oracle):
+    """the digit splits at their limits: spectrogram values at the clamp (-80), at the reference level (0) and in
+    between to the last bit; filter rows that are all zero, a single one, +/- powers of two (the row scale's
+    boundary), denormal-small and alternating extremes; ragged widths down to one hashprint"""
+    import torch
+    rng = np.random.default_rng(77)
+    f = rng.standard_normal((2420, 64)).astype(np.float32) * 0.03          # [k][r] = column-major [64][2420]
+    f[:, 0] = 0.0                                                            # an all-zero row: every delta is 0 -> bit set
+    f[:, 1] = 0.0; f[17, 1] = 1.0                                            # a single tap
+    f[:, 2] = np.where(rng.random(2420) < 0.5, 0.25, -0.25)                  # +/- a power of two: fq = +/- 2^21 exactly
+    f[:, 3] = np.float32(2.0) ** rng.integers(-20, 2, 2420) * rng.choice([-1, 1], 2420)
+    f[:, 4] = np.nextafter(np.float32(0.5), np.float32(1.0))                 # just above a power of two
+    f[:, 5] = np.nextafter(np.float32(0.5), np.float32(0.0))                 # just below: the row scale changes
+    f[:, 6] = 1e-30
+    filt = np.ascontiguousarray(f).ravel()
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filt)
+    g.set_projection(1)
+    before = oracle.get_projection()
+    oracle.set_projection(1)
+    try:
+        for c in (100, 101, 355, 356, 1000):
+            s = rng.uniform(-80, 0, (3, 121, c)).astype(np.float32)
+            s[0, :, ::2] = -80.0
+            s[0, :, 1::2] = 0.0
+            s[1] = np.round(s[1] * 131072.0) / 131072.0                     # exactly representable steps
+            s[1, 5] = np.nextafter(np.float32(-80.0), np.float32(0.0))
+            s[2, :, : c // 2] = -80.0
+            d_s = torch.from_numpy(s).cuda()
+            hp = torch.zeros((3, c - 99), dtype=torch.int64, device="cuda")
+            g.hashprints_from_db_dev(d_s.data_ptr(), 3, c, hp.data_ptr())
+            torch.cuda.synchronize()
+            got = hp.cpu().numpy().view(np.uint64)
+            for i in range(3):
+                assert np.array_equal(got[i], oracle.hashprints_from_db(filt, s[i])), (c, i)
+            assert ((got >> np.uint64(63)) == 1).all()                       # row 0: zero filters, delta 0 >= 0
+    finally:
+        oracle.set_projection(before)
+        g.close()
