@@ -288,3 +288,30 @@ def test_any_length_extraction_against_float64(oracle):
     m64 = nsgt_f64.cq_magnitudes(pcm)
     assert mag.shape == m64.shape
     assert (np.abs(mag - m64).max(axis=1) / m64.max(axis=1)).max() < 1e-4
+
+
+def test_fixed_point_projection_against_numpy(oracle):
+    """S9q: quantised factors and exact int64 sums, restated in numpy; the scaled-back values lie within f32 rounding
+    of the f32 chain (S9) and of the float64 product"""
+    rng = np.random.default_rng(5)
+    filt = rng.standard_normal(64 * 2420).astype(np.float32) * 0.02          # column-major [64][2420]
+    s = rng.uniform(-80, 0, (121, 140)).astype(np.float32)
+    f = filt.reshape(2420, 64).T                                             # [r][k]
+    m = np.abs(f).max(axis=1)
+    e = 21 - np.floor(np.log2(m)).astype(np.int64)
+    fq = np.rint(f.astype(np.float64) * 2.0 ** e[:, None]).astype(np.int64)
+    assert np.array_equal(oracle.quantise_filters(filt), fq) and np.abs(fq).max() <= 2 ** 22
+    u = np.rint(s.astype(np.float64) * 131072.0).astype(np.int64) + 40 * 131072
+    nf = s.shape[1] - 19
+    frames = np.stack([u[b, t:t + nf] for b in range(121) for t in range(20)])   # [k][n], k = 20 b + t
+    want = fq @ frames
+    got = oracle.project_q(filt, s)
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    hp = oracle.pack_q(got)
+    bits = (want[:, :-80] - want[:, 80:]) >= 0
+    assert np.array_equal(hp, (bits.astype(np.uint64) << (np.uint64(63) - np.arange(64, dtype=np.uint64))[:, None]).sum(axis=0, dtype=np.uint64))
+    back = (want - (fq.sum(axis=1) * 40 * 131072)[:, None]) / 2.0 ** e[:, None] / 131072.0
+    exact = f.astype(np.float64) @ np.stack([s[b, t:t + nf] for b in range(121) for t in range(20)]).astype(np.float64)
+    chain = oracle.project(filt, s)
+    assert np.abs(back - exact).max() < 2e-4 and np.abs(chain - exact).max() < 2e-3
+    assert np.sqrt(np.mean((back - exact) ** 2)) < np.sqrt(np.mean((chain - exact) ** 2))   # closer than the f32 chain
