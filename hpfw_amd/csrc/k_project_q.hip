@@ -37,7 +37,7 @@ constexpr int kQChunks = 8;                    // bin chunks of 16 (121 bins pad
 constexpr int kQUnit = 48;                     // bytes per (chunk, column): three digits x 16 bins
 constexpr int kQSlabBytes = kQChunks * kQCols * kQUnit;       // 105 600
 constexpr int kQStepBytes = 2 * 3 * 4 * 64 * 16;              // filter digits of one t: [tile][digit][c][lane][16] = 24 576
-constexpr int kQLdsBytes = kQSlabBytes + 2 * kQStepBytes;     // 154 752
+constexpr int kQLdsBytes = kQSlabBytes + 2 * kQStepBytes;     // 154 752 (the epilogue's [64][256] int64 tile, 131 072, lies over it)
 
 __device__ __forceinline__ void q_digits(int u, int &d0, int &d1, int &d2)
 {
@@ -52,7 +52,7 @@ __device__ __forceinline__ void q_digits(int u, int &d0, int &d1, int &d2)
 template <bool FROM_T>
 __global__ __launch_bounds__(kQThreads, 2) void project_q_kernel(const v4i *__restrict__ fq_image, const float *__restrict__ sdb,
                                                                  const float *__restrict__ tmax, int c, int nf,
-                                                                 long long *__restrict__ proj)
+                                                                 long long *__restrict__ proj, uint64_t *__restrict__ hp)
 {
     unsigned char *slab = smem_raw;                                   // [chunk][column][digit][16]
     v4i *abuf = reinterpret_cast<v4i *>(smem_raw + kQSlabBytes);      // [2][tile][digit][c][lane]
@@ -161,29 +161,46 @@ __global__ __launch_bounds__(kQThreads, 2) void project_q_kernel(const v4i *__re
         }
         __syncthreads();
     }
-    if (!active) return;
-    // D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    // S10q here for the frames whose partner 80 frames on lies in this tile (176 of 256): the tile's Pq goes through
+    // the LDS (the slab is no longer read) instead of through HBM; only the columns a neighbouring tile needs -- the
+    // first 80 -- and those that need a neighbour -- the last 80 -- are written out for pack_q_edge_kernel.
+    long long *pl = reinterpret_cast<long long *>(smem_raw); // [64][256]
     long long *P = proj + (int64_t)clip * kFilters * nf;
     const int n = n0 + colw;
-    if (n >= nf) return;
+    if (active) {
+        // D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        const bool edge = (colw < kLag || colw >= kQTileN - kLag) && n < nf;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+        for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = 32 * t2 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            long long v = acc[t2][4][reg];
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = 32 * t2 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                long long v = acc[t2][4][reg];
 #pragma unroll
-            for (int cl = 3; cl >= 0; --cl) v = v * 256 + acc[t2][cl][reg];
-            P[(int64_t)row * nf + n] = v;
+                for (int cl = 3; cl >= 0; --cl) v = v * 256 + acc[t2][cl][reg];
+                pl[row * kQTileN + colw] = v;
+                if (edge) P[(int64_t)row * nf + n] = v;
+            }
+    }
+    __syncthreads();
+    const int nhp = nf - kLag;
+    if (tid < kQTileN - kLag && n0 + tid < nhp) { // (columns of waves past the clip are never read: their frames are >= nhp)
+        uint64_t v = 0;
+#pragma unroll 16
+        for (int r = 0; r < kFilters; ++r) {
+            const long long d = pl[r * kQTileN + tid] - pl[r * kQTileN + tid + kLag];
+            v |= (uint64_t)(d >= 0) << (63 - r);
         }
+        hp[(int64_t)clip * nhp + n0 + tid] = v;
+    }
 }
 
-// bit (63 - r) of hp[i] = (Pq[r,i] - Pq[r,i+80] >= 0)
-__global__ __launch_bounds__(256) void pack_q_kernel(const long long *__restrict__ proj, int nf, int nhp, uint64_t *__restrict__ hp)
+// the frames whose partner lies in the next tile: the last 80 of every tile of 256, from the edge columns in HBM
+__global__ __launch_bounds__(128) void pack_q_edge_kernel(const long long *__restrict__ proj, int nf, int nhp, uint64_t *__restrict__ hp)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * kQTileN + (kQTileN - kLag) + threadIdx.x;
     const int clip = blockIdx.y;
-    if (i >= nhp) return;
+    if (threadIdx.x >= kLag || i >= nhp) return;
     const long long *P = proj + (int64_t)clip * kFilters * nf + i;
     uint64_t v = 0;
 #pragma unroll 16
@@ -223,8 +240,9 @@ void pack_filters_q(const float *f, std::vector<int8_t> &image)
 
 size_t project_q_image_bytes() { return (size_t)kCtx * kQStepBytes; }
 
-void launch_project_q(const void *d_fq_image, const float *d_db, const float *d_tmax, int n_clips, int c, long long *d_proj,
-                      hipStream_t s)
+// dB spectrograms -> hashprints [n_clips][c - 99]; d_proj: scratch of n_clips * 64 * (c - 19) int64 (edge columns only are used)
+void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float *d_tmax, int n_clips, int c, long long *d_proj,
+                         uint64_t *d_hp, hipStream_t s)
 {
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
@@ -234,21 +252,16 @@ void launch_project_q(const void *d_fq_image, const float *d_db, const float *d_
                                   160 * 1024);
         attr_set.mark();
     }
-    const int nf = c - (kCtx - 1);
+    const int nf = c - (kCtx - 1), nhp = nf - kLag;
+    if (nhp <= 0) return;
     dim3 grid((nf + kQTileN - 1) / kQTileN, n_clips);
     if (d_tmax)
         hipLaunchKernelGGL(project_q_kernel<true>, grid, dim3(kQThreads), kQLdsBytes, s, static_cast<const v4i *>(d_fq_image), d_db, d_tmax, c,
-                           nf, d_proj);
+                           nf, d_proj, d_hp);
     else
         hipLaunchKernelGGL(project_q_kernel<false>, grid, dim3(kQThreads), kQLdsBytes, s, static_cast<const v4i *>(d_fq_image), d_db, d_tmax, c,
-                           nf, d_proj);
-}
-
-void launch_pack_q(const long long *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s)
-{
-    const int nhp = nf - kLag;
-    if (nhp <= 0) return;
-    hipLaunchKernelGGL(pack_q_kernel, dim3((nhp + 255) / 256, n_clips), dim3(256), 0, s, d_proj, nf, nhp, d_hp);
+                           nf, d_proj, d_hp);
+    hipLaunchKernelGGL(pack_q_edge_kernel, grid, dim3(128), 0, s, d_proj, nf, nhp, d_hp);
 }
 
 } // namespace hpfw
