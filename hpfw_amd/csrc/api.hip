@@ -558,9 +558,16 @@ int run_back(hpfw_gpu *h, DevPlan *dp, int ns, uint64_t *d_hp, hipStream_t s)
     float *proj = (float *)h->ws[3];
     int rc;
     if (h->projection) { // S9q: exact integer sums on the int8 matrix pipe, delta + pack in the same kernel
-        Timed t(h, K_PROJECT, s);
-        hpfw::launch_hashprints_q(h->d_fq_image, sdb, h->d_clipmax, ns, p.c, (long long *)h->ws[3], d_hp, s);
-        return check_launch("project");
+        {
+            Timed t(h, K_PROJECT, s);
+            hpfw::launch_hashprints_q(h->d_fq_image, sdb, h->d_clipmax, ns, p.c, (long long *)h->ws[3], d_hp, s);
+        }
+        if ((rc = check_launch("project"))) return rc;
+        {
+            Timed t(h, K_PACK, s);
+            hpfw::launch_pack_q_edge((const long long *)h->ws[3], ns, p.c, d_hp, s);
+        }
+        return check_launch("delta_pack");
     }
     {
         Timed t(h, K_PROJECT, s);
@@ -703,6 +710,7 @@ int hpfw_gpu_hashprints_from_db(hpfw_gpu *h, const float *d_db, int64_t n_clips,
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
         if (h->projection) {
             hpfw::launch_hashprints_q(h->d_fq_image, d_db + c0 * 121 * c, nullptr, nb, (int)c, (long long *)h->ws[3], d_hp + c0 * nhp, s);
+            hpfw::launch_pack_q_edge((const long long *)h->ws[3], nb, (int)c, d_hp + c0 * nhp, s);
         } else {
             hpfw::launch_project(h->d_fpack, d_db + c0 * 121 * c, nullptr, nb, (int)c, (float *)h->ws[3], s);
             hpfw::launch_pack((const float *)h->ws[3], nb, (int)nf, d_hp + c0 * nhp, s);

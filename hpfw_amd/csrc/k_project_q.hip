@@ -240,7 +240,8 @@ void pack_filters_q(const float *f, std::vector<int8_t> &image)
 
 size_t project_q_image_bytes() { return (size_t)kCtx * kQStepBytes; }
 
-// dB spectrograms -> hashprints [n_clips][c - 99]; d_proj: scratch of n_clips * 64 * (c - 19) int64 (edge columns only are used)
+// dB spectrograms -> hashprints [n_clips][c - 99] except the last 80 frames of every tile of 256 (launch_pack_q_edge);
+// d_proj: scratch of n_clips * 64 * (c - 19) int64 (edge columns only are written)
 void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float *d_tmax, int n_clips, int c, long long *d_proj,
                          uint64_t *d_hp, hipStream_t s)
 {
@@ -261,7 +262,14 @@ void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float 
     else
         hipLaunchKernelGGL(project_q_kernel<false>, grid, dim3(kQThreads), kQLdsBytes, s, static_cast<const v4i *>(d_fq_image), d_db, d_tmax, c,
                            nf, d_proj, d_hp);
-    hipLaunchKernelGGL(pack_q_edge_kernel, grid, dim3(128), 0, s, d_proj, nf, nhp, d_hp);
+}
+
+// the hashprints of the last 80 frames of every tile (their partners lie in the next tile), after launch_hashprints_q
+void launch_pack_q_edge(const long long *d_proj, int n_clips, int c, uint64_t *d_hp, hipStream_t s)
+{
+    const int nf = c - (kCtx - 1), nhp = nf - kLag;
+    if (nhp <= kQTileN - kLag) return; // a single tile whose every frame has its partner inside
+    hipLaunchKernelGGL(pack_q_edge_kernel, dim3((nf + kQTileN - 1) / kQTileN, n_clips), dim3(128), 0, s, d_proj, nf, nhp, d_hp);
 }
 
 } // namespace hpfw

@@ -133,6 +133,7 @@ size_t project_q_image_bytes();
 void pack_filters_q(const float *f_colmajor, std::vector<int8_t> &image);
 void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float *d_tmax, int n_clips, int c, long long *d_proj,
                          uint64_t *d_hp, hipStream_t s);
+void launch_pack_q_edge(const long long *d_proj, int n_clips, int c, uint64_t *d_hp, hipStream_t s);
 
 // ---- HashprintHandle with other template arguments (k_hashprint_cfg.hip) ----------------------------
 struct CfgArgs {
