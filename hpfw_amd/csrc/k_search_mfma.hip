@@ -288,8 +288,12 @@ struct SearchShiftArgs {
     int w32;           // row stride of the transposed window (odd)
 };
 
-__global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
+// TILES tiles of 1024 offsets per workgroup share the query operand of every step (one LDS read for TILES matrix
+// instructions); WAVES waves split the steps.
+template <int TILES, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void hamming_shift_kernel(SearchShiftArgs a)
 {
+    constexpr int kThr = 64 * WAVES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m_lane = lane & 31, h = lane >> 5;
     const int clip = blockIdx.x / a.chunks;
@@ -297,10 +301,10 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
     const int n = (int)(a.db_off[clip + 1] - r0);
     if (n <= 0 || a.k <= 0) return;
     const int keff = a.k < n ? a.k : n; // storage.h:37-39
-    const int t0 = (blockIdx.x - clip * a.chunks) * 1024;
+    const int t0 = (blockIdx.x - clip * a.chunks) * 1024 * TILES;
     if (t0 > n - keff) return;
     const int steps = a.k + 31;
-    const int win = 1024 + steps;                  // window slots used: 32 n + j < 992 + steps
+    const int win = 1024 * TILES + steps;          // window slots used: 32 n + j + 1024 tile < 1024 TILES - 32 + steps
     const int plane = 32 * a.w32;                  // v4i per half-plane of the transposed window
     v4i *wB = reinterpret_cast<v4i *>(smem_raw);   // [2][32][w32]
     v4i *wA = wB + 2 * plane;                      // [2][steps + 31]: slot i = Q[i - 31]
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
     // byte -> eight E2M1 nibbles by table: the expansion is this kernel's largest VALU item otherwise
     // (every workgroup expands its own window for a single query)
     uint32_t *lut = reinterpret_cast<uint32_t *>(wA + 2 * qlen);
-    lut[tid] = expand8((uint32_t)tid);
+    if (tid < 256) lut[tid] = expand8((uint32_t)tid);
     __syncthreads();
     auto expand32_lut = [&](uint32_t w) {
         v4i r;
@@ -320,23 +324,23 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
     };
     // every load of the staging (query first, then up to 8 window slots per thread and round) is issued
     // before the first value is expanded, so their latencies overlap instead of adding up
-    constexpr int kLq = 2, kLd = 8;
+    constexpr int kLq = 512 / kThr, kLd = 8;
     uint64_t wq[kLq];
 #pragma unroll
     for (int e = 0; e < kLq; ++e) {
-        const int j = tid + e * 256 - 31;
+        const int j = tid + e * kThr - 31;
         wq[e] = (j >= 0 && j < a.k) ? a.q[j] : 0ull;
     }
-    for (int i0 = tid; i0 < win; i0 += kLd * 256) {
+    for (int i0 = tid; i0 < win; i0 += kLd * kThr) {
         uint64_t w[kLd];
 #pragma unroll
         for (int e = 0; e < kLd; ++e) {
-            const int gi = t0 + i0 + e * 256;
-            w[e] = (i0 + e * 256 < win && gi < n) ? a.db[r0 + gi] : 0ull;
+            const int gi = t0 + i0 + e * kThr;
+            w[e] = (i0 + e * kThr < win && gi < n) ? a.db[r0 + gi] : 0ull;
         }
 #pragma unroll
         for (int e = 0; e < kLd; ++e) {
-            const int i = i0 + e * 256;
+            const int i = i0 + e * kThr;
             if (i < win) {
                 const bool in = t0 + i < n; // past the end of the clip: fp4 zeros, not expand(0) = all +1
                 const int slot = (i & 31) * a.w32 + (i >> 5);
@@ -347,14 +351,14 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
     }
 #pragma unroll
     for (int e = 0; e < kLq; ++e) {
-        const int i = tid + e * 256, j = i - 31;
+        const int i = tid + e * kThr, j = i - 31;
         if (i < qlen) {
             const bool in = j >= 0 && j < a.k;
             wA[i] = in ? expand32_lut((uint32_t)wq[e]) : v4i{0, 0, 0, 0};
             wA[qlen + i] = in ? expand32_lut((uint32_t)(wq[e] >> 32)) : v4i{0, 0, 0, 0};
         }
     }
-    for (int i = tid + kLq * 256; i < qlen; i += 256) { // queries longer than 450 hashprints: the rest, plainly
+    for (int i = tid + kLq * kThr; i < qlen; i += kThr) { // queries longer than 450 hashprints: the rest, plainly
         const int j = i - 31;
         const bool in = j >= 0 && j < a.k;
         const uint64_t w = in ? a.q[j] : 0ull;
@@ -362,29 +366,35 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
         wA[qlen + i] = in ? expand32_lut((uint32_t)(w >> 32)) : v4i{0, 0, 0, 0};
     }
     __syncthreads();
-    f32x16 acc = {0};
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int tl = 0; tl < TILES; ++tl) acc[tl] = f32x16{0};
     const int one = 0x7f7f7f7f;
-    const int per = (steps + 3) / 4, j0 = wave * per, j1 = min(steps, j0 + per);
+    const int per = (steps + WAVES - 1) / WAVES, j0 = wave * per, j1 = min(steps, j0 + per);
     const v4i *ap = wA + h * qlen + 31 - m_lane;   // + j
     const v4i *bp = wB + h * plane + m_lane;       // lane index = column n here
     // four steps per round: the eight operand reads of the next round are in flight behind the MFMAs of this one
     constexpr int kSt = 4;
-    v4i ca[kSt], cb[kSt], na[kSt], nb[kSt];
-    auto fetch = [&](int j, v4i (&fa)[kSt], v4i (&fb)[kSt]) {
+    v4i ca[kSt], cb[TILES][kSt], na[kSt], nb[TILES][kSt];
+    auto fetch = [&](int j, v4i (&fa)[kSt], v4i (&fb)[TILES][kSt]) {
 #pragma unroll
         for (int e = 0; e < kSt; ++e) {
             const int jj = j + e < j1 ? j + e : j1 - 1; // the tail re-reads the last step (its product is not used)
             fa[e] = ap[jj];
-            fb[e] = bp[(jj & 31) * a.w32 + (jj >> 5)];
+#pragma unroll
+            for (int tl = 0; tl < TILES; ++tl) fb[tl][e] = bp[(jj & 31) * a.w32 + (jj >> 5) + 32 * tl];
         }
     };
-    auto mult = [&](int j, const v4i (&fa)[kSt], const v4i (&fb)[kSt]) {
+    auto mult = [&](int j, const v4i (&fa)[kSt], const v4i (&fb)[TILES][kSt]) {
 #pragma unroll
         for (int e = 0; e < kSt; ++e) {
             if (j + e < j1) {
                 const v8i av = {fa[e].x, fa[e].y, fa[e].z, fa[e].w, 0, 0, 0, 0};
-                const v8i bv = {fb[e].x, fb[e].y, fb[e].z, fb[e].w, 0, 0, 0, 0};
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 4, 4, 0, one, 0, one);
+#pragma unroll
+                for (int tl = 0; tl < TILES; ++tl) {
+                    const v8i bv = {fb[tl][e].x, fb[tl][e].y, fb[tl][e].z, fb[tl][e].w, 0, 0, 0, 0};
+                    acc[tl] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[tl], 4, 4, 0, one, 0, one);
+                }
             }
         }
     };
@@ -400,19 +410,22 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads(); // the windows are no longer read: their memory takes the partial sums
-    float *red = reinterpret_cast<float *>(smem_raw); // [4 waves][16 regs][64 lanes]
+    float *red = reinterpret_cast<float *>(smem_raw); // [WAVES][TILES][16 regs][64 lanes]
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) red[(wave * 16 + reg) * 64 + lane] = acc[reg];
+    for (int tl = 0; tl < TILES; ++tl)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) red[((wave * TILES + tl) * 16 + reg) * 64 + lane] = acc[tl][reg];
     __syncthreads();
     // thread (reg = tid / 64 .. , lane): 16 regs x 64 lanes = 1024 sums, four per thread
     unsigned key = 0xffffffffu;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int reg = wave * 4 + e;
-        const float dot = red[reg * 64 + lane] + red[(16 + reg) * 64 + lane] + red[(32 + reg) * 64 + lane] +
-                          red[(48 + reg) * 64 + lane];
+    for (int e = 0; e < 16 * TILES / WAVES; ++e) {
+        const int idx = wave * (16 * TILES / WAVES) + e, tl = idx >> 4, reg = idx & 15;
+        float dot = 0.0f; // (integers below 2^24: any order of the partial sums gives the same value)
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) dot += red[((w * TILES + tl) * 16 + reg) * 64 + lane];
         const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h; // shift = offset inside the group of 32
-        const int lo = 32 * m_lane + m;                    // column m_lane: base offset 32 n
+        const int lo = 1024 * tl + 32 * m_lane + m;        // column m_lane: base offset 32 n
         const int dist = (64 * keff - (int)dot) >> 1;
         const unsigned cand = ((unsigned)dist << 12) | (unsigned)lo;
         if (t0 + lo <= n - keff && cand < key) key = cand;
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
     if (lane == 0) kr[wave] = key;
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w) key = kr[w] < key ? kr[w] : key;
+        for (int w = 1; w < WAVES; ++w) key = kr[w] < key ? kr[w] : key;
         if (key != 0xffffffffu) {
             const unsigned long long full = ((unsigned long long)(key >> 12) << 32) | (unsigned)(t0 + (int)(key & 0xfff));
             atomicMin(reinterpret_cast<unsigned long long *>(a.best) + clip, full);
@@ -435,17 +448,25 @@ __global__ __launch_bounds__(256) void hamming_shift_kernel(SearchShiftArgs a)
     }
 }
 
-static int shift_w32(int k)
+static int shift_w32(int k, int tiles)
 {
-    int w = (1024 + k + 31 + 31) / 32 + 1;
+    int w = (1024 * tiles + k + 31 + 31) / 32 + 1;
     return w | 1;
 }
 
-size_t hamming_shift_lds_bytes(int k)
+static bool shift_two_tiles()
 {
-    const size_t win = (size_t)2 * 32 * shift_w32(k) * 16, qa = (size_t)2 * (k + 62) * 16, lut = 1024;
-    return std::max(win + qa + lut, (size_t)16 * 1024);
+    static const bool on = std::getenv("HPFW_SHIFT_ONE_TILE") == nullptr;
+    return on;
 }
+
+static size_t shift_lds_bytes(int k, int tiles)
+{
+    const size_t win = (size_t)2 * 32 * shift_w32(k, tiles) * 16, qa = (size_t)2 * (k + 62) * 16, lut = 1024;
+    return std::max(win + qa + lut, (size_t)(tiles == 1 ? 16 : 64) * 1024); // (the partial sums overlay the windows)
+}
+
+size_t hamming_shift_lds_bytes(int k) { return shift_lds_bytes(k, 1); }
 
 // one query of k hashprints at d_q against the whole index: best[clip] (preset to ~0) gets (dist << 32) | offset
 void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_clips, int n_off_max, const uint64_t *d_q,
@@ -453,7 +474,9 @@ void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_c
 {
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel<1, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel<2, 8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set.mark();
     }
@@ -464,10 +487,19 @@ void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_c
     a.q = d_q;
     a.k = k;
     a.best = d_best;
-    a.chunks = (n_off_max + 1023) / 1024;
-    a.w32 = shift_w32(k);
-    hipLaunchKernelGGL(hamming_shift_kernel, dim3((unsigned)a.chunks * (unsigned)n_clips), dim3(256),
-                       hamming_shift_lds_bytes(k), s, a);
+    const int tiles1 = (n_off_max + 1023) / 1024;
+    // two tiles per workgroup share every step's query operand; one tile when the clips have a single one, or when
+    // the doubled window does not fit the LDS
+    const bool two = shift_two_tiles() && tiles1 > 1 && shift_lds_bytes(k, 2) <= 160 * 1024;
+    if (two) {
+        a.chunks = (tiles1 + 1) / 2;
+        a.w32 = shift_w32(k, 2);
+        hipLaunchKernelGGL((hamming_shift_kernel<2, 8>), dim3((unsigned)a.chunks * (unsigned)n_clips), dim3(512), shift_lds_bytes(k, 2), s, a);
+    } else {
+        a.chunks = tiles1;
+        a.w32 = shift_w32(k, 1);
+        hipLaunchKernelGGL((hamming_shift_kernel<1, 4>), dim3((unsigned)a.chunks * (unsigned)n_clips), dim3(256), shift_lds_bytes(k, 1), s, a);
+    }
 }
 
 size_t hamming_mfma_lds_bytes(int kt)
