@@ -602,6 +602,8 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     HIP_TRY(hipSetDevice(device));
     auto *h = new hpfw_gpu();
     h->device = device;
+    if (const char *e = std::getenv("HPFW_PROJECTION")) // "f32": handles start with the f32 fma chain (hpfw_gpu_set_projection(h, 0))
+        h->projection = std::strcmp(e, "f32") == 0 ? 0 : 1;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) != hipSuccess) {
         delete h;
