@@ -314,7 +314,11 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         bz.n_tiles1 = (bz.a + 15) / 16;
         bz.k1lo = p.kmin / p.n2;
         bz.k1n = (p.kmax - 1) / p.n2 - bz.k1lo + 1;
-        bz.n_tiles2 = ((2 * bz.k1n + 31) / 32 + 2) / 3 * 3;
+        {
+            const int need = (2 * bz.k1n + 31) / 32; // row tiles of 32 that hold the consumed rows
+            bz.nt2 = need < 3 ? need : 3;
+            bz.n_tiles2 = (need + bz.nt2 - 1) / bz.nt2 * bz.nt2;
+        }
         // coefficient images of the column transforms (the first one's two stages; the second one's rows that hold
         // consumed bins), packed on the device
         const cf *d_tw_n1 = nullptr;

@@ -51,7 +51,8 @@ struct BzArgs {
     int a;              // n1 = 16 a: the first transform's column stage splits into length-a and length-16 transforms
     int n_tiles1;       // row tiles of 32 (16 outputs k_a each) of the length-a stage
     int k1lo, k1n;      // rows k1lo .. k1lo + k1n - 1 of the second transform hold the consumed bins
-    int n_tiles2;       // row tiles of their coefficient image apack2 (a multiple of 3)
+    int n_tiles2;       // row tiles of their coefficient image apack2 (a multiple of nt2)
+    int nt2;            // row tiles per wave of that stage: what the consumed rows need, at most 3
     const float *wp;    // chirp w[j], planar [2][L] (Re plane, Im plane), 0 from sample N on
     const cf *tl;       // T_L[q1 k2] at [q1 n2 + k2]
     const cf *bhat;     // DFT_L(conj chirp)[q1 + n1 q2] at [q1 n2 + q2]
