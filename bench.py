@@ -189,7 +189,8 @@ def main():
         ops_per_clip = 9 * PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0)
         achieved = ops_per_clip * clips_per_launch / (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12 if pj_launches else 0.0
         roof_pj = {"kernel": "project_q_kernel (v_mfma_i32_32x32x32_i8, nine digit products of 24-bit fixed-point factors)",
-                   "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                   "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
+                   "unit_note": "integer work: tera int8 multiply-add operations (2 per multiply-add) per second, TOP/s",
                    "frac": round(achieved / MFMA_I8_PEAK_TOPS, 4), "traffic": pmc_traffic("project_q_hbm_bytes_per_clip"),
                    "avg_launch_ms": round(pj_ms / max(pj_launches, 1), 4), "launches": pj_launches,
                    "ops_per_clip": ops_per_clip, "clips_per_launch": clips_per_launch,
