@@ -181,9 +181,18 @@ class Gpu:
         self._h = ctypes.c_void_p()
         check(lib().hpfw_gpu_create(int(device), ctypes.byref(self._h)))
 
+    @classmethod
+    def from_handle(cls, handle):
+        """a view of a handle somebody else owns (a shard of hpfw_amd.multi.GpuGroup): close() does not destroy it"""
+        g = cls.__new__(cls)
+        g._h = ctypes.c_void_p(handle) if not isinstance(handle, ctypes.c_void_p) else handle
+        g._borrowed = True
+        return g
+
     def close(self):
         if getattr(self, "_h", None):
-            lib().hpfw_gpu_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                lib().hpfw_gpu_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -20,11 +20,13 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
 
 #include "../../include/hpfw_gpu.h"
+#include "legacy_internal.h" // the extern "C" signatures multi.cpp sees, checked against the definitions below
 
 extern "C" void hpfw_internal_set_error(const char *msg); // api.hip: feeds hpfw_gpu_last_error()
 
@@ -559,10 +561,14 @@ static void collect_cached(hpfw_legacy_collector *c, const std::vector<std::stri
 {
     std::error_code ec;
     std::vector<std::string> paths;
+    const std::unordered_set<std::string> done(done_stems.begin(), done_stems.end()); // a 100 k-track cache: no quadratic scan
     for (const auto &e : std::filesystem::directory_iterator(c->cache_dir + "spectros/", ec)) {
         if (!e.is_regular_file(ec)) continue;
-        const std::string stem = e.path().filename().string(); // the cache names its files by stem, without extension
-        if (std::find(done_stems.begin(), done_stems.end(), stem) == done_stems.end()) paths.push_back(e.path().string());
+        // the cache names its files by the track's stem (cache.h:30-33); the name returned is that file name as it is.
+        // (The reference returns path(cache file).stem() -- parallel_collector.h:123 -- i.e. a second stem: "a.b.wav" is
+        // cached as "a.b" and comes back as "a" there, as "a.b" here; INTEGRATION.md notes the deviation.)
+        const std::string stem = e.path().filename().string();
+        if (!done.count(stem)) paths.push_back(e.path().string());
     }
     std::sort(paths.begin(), paths.end()); // the reference's order is the directory's (and racy, :129): sorted here
     for (size_t at = 0; at < paths.size();) {

@@ -425,6 +425,10 @@ int hpfw_gpu_group_learn_filters(hpfw_gpu_group *g, float *filters_out)
     if ((rc = hpfw_gpu_learn_filters(g->shards[0].h, f.data()))) return rc;
     for (size_t i = 1; i < g->shards.size(); ++i)
         if ((rc = hpfw_gpu_set_filters(g->shards[i].h, f.data()))) return rc;
+    // the reference keeps accumulating across calls (parallel_collector.h:93-97): the total stays on shard 0 only, so
+    // that an accumulate + learn that follows adds every earlier file once and not once per shard
+    for (size_t i = 1; i < g->shards.size(); ++i)
+        if ((rc = hpfw_gpu_cov_reset(g->shards[i].h))) return rc;
     if (filters_out) std::memcpy(filters_out, f.data(), f.size() * 4);
     return 0;
 }

@@ -94,6 +94,13 @@ class GpuGroup:
     def shards(self):
         return int(lib().hpfw_gpu_group_size(self._g))
 
+    def handle(self, shard):
+        """the hpfw_gpu handle of a shard (owned by the group): wrap it with hpfw_amd.Gpu.from_handle"""
+        h = lib().hpfw_gpu_group_handle(self._g, int(shard))
+        if not h:
+            raise _lib.HpfwError(f"no shard {shard}")
+        return h
+
     @property
     def exchange(self):
         return lib().hpfw_gpu_group_exchange(self._g).decode()

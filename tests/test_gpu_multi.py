@@ -17,12 +17,37 @@ from hpfw_amd import _lib, multi, synth  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _n_devices():
+    """visible GPUs, counted without initialising the runtime (torch.cuda.device_count() does not, on this image)"""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def _device_sets():
+    """shard placements: one GPU carries every shard (what the one-GPU box can run); with more than one GPU visible
+    the real cross-device path -- ncclCommInitAll over several devices, a grouped ncclAllGather across their streams,
+    an in-place ncclAllReduce on each device's own covariance -- on two devices and on all of them.  On a one-GPU box
+    those cases are listed as skipped, not silently absent."""
+    sets = [[0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]]
+    n = _n_devices()
+    multi_sets = [[0, 1]] + ([list(range(n))] if n > 2 else [])
+    for d in multi_sets:
+        marks = [] if n >= len(set(d)) else [pytest.mark.skip(reason=f"needs {len(set(d))} GPUs, {n} visible")]
+        sets.append(pytest.param(d, marks=marks, id="devices-" + "-".join(map(str, d))))
+    if n > 2:                                                   # two shards per device over all devices
+        sets.append(pytest.param(list(range(n)) * 2, id=f"two-shards-on-each-of-{n}"))
+    return sets
+
+
 def _ragged(rng, lens):
     hp = [rng.integers(0, 2 ** 64, size=n, dtype=np.uint64) for n in lens]
     return np.concatenate(hp), np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]])
+@pytest.mark.parametrize("devices", _device_sets())
 def test_group_search_equals_unsharded_and_oracle(torch_cuda, gpu, oracle, devices):
     rng = np.random.default_rng(31)
     lens = [int(x) for x in rng.integers(1, 900, 203)] + [2320, 0, 5]
@@ -47,7 +72,8 @@ def test_group_search_equals_unsharded_and_oracle(torch_cuda, gpu, oracle, devic
     gpu.index_add(db, db_off)
     assert np.array_equal(gpu.search_topk(q, q_off, 10), want)
     g = multi.GpuGroup(devices)
-    assert g.shards == len(devices) and g.exchange == ("rccl" if len(devices) == 1 else "rccl+local")
+    assert g.shards == len(devices)
+    assert g.exchange == ("rccl" if len(set(devices)) == len(devices) else "rccl+local")
     g.index_build(db, db_off)
     for k in (1, 10):
         assert np.array_equal(g.search_topk(q, q_off, k), want[:, :k])
@@ -67,7 +93,9 @@ def test_group_extraction_and_learning(torch_cuda, oracle, filters):
     one.cov_accumulate(clips)
     f_one = one.learn_filters()
     cov_one, n_one = one.cov_get()
-    for devices in ([0], [0, 0, 0]):
+    n_dev = _n_devices()
+    placements = [[0], [0, 0, 0]] + ([[0, 1], list(range(n_dev))] if n_dev > 1 else [])
+    for devices in placements:
         g = multi.GpuGroup(devices)
         g.set_filters(filters)
         assert np.array_equal(g.extract(clips, plan.n_hp), want)          # clips sharded, order kept
@@ -76,6 +104,8 @@ def test_group_extraction_and_learning(torch_cuda, oracle, filters):
         f = g.learn_filters()                                             # all-reduce (or host sum), solve, install
         if len(devices) == 1:
             assert np.array_equal(f, f_one)                               # a sum of one: the same bits
+        cov_g, n_g = hpfw_amd.Gpu.from_handle(g.handle(0)).cov_get()      # the summed covariance, on shard 0
+        assert n_g == n_one and np.abs(cov_g - cov_one).max() <= 2e-5 * np.abs(cov_one).max()
         rows = f.reshape(2420, 64).T.astype(np.float64)
         w = np.linalg.eigvalsh(cov_one.astype(np.float64))[::-1]
         ray = np.einsum("rk,kl,rl->r", rows, cov_one.astype(np.float64), rows)
@@ -83,6 +113,40 @@ def test_group_extraction_and_learning(torch_cuda, oracle, filters):
         assert np.abs(rows @ rows.T - np.eye(64)).max() < 1e-4
         got = g.extract(clips, plan.n_hp)                                 # the learned filters are installed everywhere
         assert np.array_equal(got, plan.extract_batch(f, clips, n_threads=7))
+        g.close()
+    one.close()
+
+
+def test_group_learning_keeps_accumulating(torch_cuda):
+    """accumulate A, learn, accumulate B, learn (the reference's accum_cov grows across prepare() calls,
+    parallel_collector.h:93-97): the second result is the single handle's on A + B, i.e. the first sum entered the
+    second one once and not once per shard"""
+    a = np.stack([synth.gen_clip(870 + i, 3.0) for i in range(5)])
+    b = np.stack([synth.gen_clip(880 + i, 3.0) for i in range(4)])
+    one = hpfw_amd.Gpu(0)
+    one.cov_accumulate(a)
+    one.learn_filters()
+    one.cov_accumulate(b)
+    f_one = one.learn_filters()
+    cov_one, n_one = one.cov_get()
+    assert n_one == 9
+    n_dev = _n_devices()
+    for devices in [[0], [0, 0, 0]] + ([[0, 1], list(range(n_dev))] if n_dev > 1 else []):
+        g = multi.GpuGroup(devices)
+        g.cov_reset()
+        g.cov_accumulate(a)
+        g.learn_filters()
+        g.cov_accumulate(b)
+        f = g.learn_filters()
+        cov_g, n_g = hpfw_amd.Gpu.from_handle(g.handle(0)).cov_get()
+        assert n_g == 9
+        assert np.abs(cov_g - cov_one).max() <= 2e-5 * np.abs(cov_one).max(), devices
+        if len(devices) == 1:
+            assert np.array_equal(f, f_one)
+        rows = f.reshape(2420, 64).T.astype(np.float64)
+        w = np.linalg.eigvalsh(cov_one.astype(np.float64))[::-1]
+        ray = np.einsum("rk,kl,rl->r", rows, cov_one.astype(np.float64), rows)
+        assert np.abs(ray - w[:64]).max() / w[0] < 1e-4, devices
         g.close()
     one.close()
 
@@ -124,7 +188,7 @@ def test_cpp_sharded_live_song_identification(torch_cuda, filters, tmp_path):
     assert outs["live_id"] == outs["live_id_multi"] == outs["live_id_multi--one-collector"] and outs["live_id"][-1] == "=> 0 1"
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]] + [d for d in _device_sets()[3:]])
 def test_group_prepare_learns_over_shards(torch_cuda, oracle, tmp_path, devices):
     """ParallelCollector::prepare over the shards (hpfw_gpu_group_prepare): files sharded per device, covariance summed
     (ncclAllReduce, or on the host when shards share a device), filters solved once, every shard hashes its own files;
@@ -153,6 +217,7 @@ def test_group_prepare_learns_over_shards(torch_cuda, oracle, tmp_path, devices)
     cov, _ = one.cov_get()
     rawc = np.frombuffer(open(os.path.join(cache, "accum_cov.cereal"), "rb").read()[8:], np.float32).reshape(2420, 2420)
     assert np.abs(cov - rawc).max() <= 2e-5 * np.abs(cov).max()
+    devices = list(devices)
     if len(devices) == 1:                                     # one shard: the single collector's bits
         pc = hpfw_amd.ParallelCollector()
         cache1 = str(tmp_path / "cache1") + "/"
