@@ -25,12 +25,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PROJECT_FLOP_PER_CLIP = 2.0 * 64 * 2420 * 2400       # filters [64x2420] . frames [2420x2400]
+PROJECT_FLOP_PER_CLIP = 2.0 * 64 * 2420 * 2400       # filters [64x2420] . frames [2420x2400] (the f32 chain forms all 2400 frames)
+PROJECT_Q_MACS_PER_CLIP = 64 * 2420 * 2320           # fixed point: the lag-80 difference is taken first, 2320 columns remain
 MFMA_F32_PEAK_TFLOPS = 157.3                         # MI355X_MICROARCH.md: dense f32 MFMA peak
-# the projection runs as nine digit products on v_mfma_i32_32x32x32_i8: 16x the multiply-adds per instruction of the f32
-# form (K = 32 against 2) at the same 16 passes -- measured: 7.08e15 digit multiply-adds' worth of instructions in
-# 2.82 ms whether or not the operand reads are quartered -- so 16 x 157.3 dense int8 TOP/s
-MFMA_I8_PEAK_TOPS = 16 * 157.3
+# v_mfma_i32_32x32x32_i8 takes 32 cycles per instruction and SIMD (MI355X_MICROARCH.md "I8: 2x BF16 per clock"; measured
+# by tools/mfma_i8_probe.hip, profiles/r03_mfma_i8_probe.jsonl: 32.1 cycles on 1, 2 or 4 accumulators): 65536 operations
+# x 1024 SIMDs x 2.4 GHz / 32 = 5033 dense int8 TOP/s at the nominal clock.  The same probe, back to back on random
+# operands with nothing else in the loop, holds 1.63-1.79 GHz: 2.9-3.5 POP/s is what the chip sustains on this instruction.
+MFMA_I8_PEAK_TOPS = 65536 * 1024 * 2.4e9 / 32 / 1e12
+MFMA_I8_PROBE_TOPS = 3535.0                          # best case of the probe on random operands (4 accumulators, 2 waves per SIMD)
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md
 VALU_PAIR_PEAK = 256 * 4 * 32 * 2.4e9 / 4            # xor/popcount kernel: 4 VALU lane-ops per 64-bit pair
 MFMA_FP4_PEAK_PFLOPS = 10.07                         # MI355X_MICROARCH.md: dense FP4 MFMA (32x32x64 in 32 cycles/SIMD)
@@ -83,10 +86,12 @@ def main():
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the oracle altogether (profiling runs: nothing but the product in the process)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) section")
+    ap.add_argument("--no-f32-chain", action="store_true",
+                    help="skip the pass with the f32-chain projection and its bit comparison with the fixed-point default")
     ap.add_argument("--no-any-length", action="store_true",
                     help="skip the section on clips whose length is not 7-smooth (chirp-z forward transform)")
-    ap.add_argument("--cpu-clips-per-core", type=int, default=4,
-                    help="CPU baseline sample: clips per host thread (about 10 s of CPU work)")
+    ap.add_argument("--cpu-clips-per-core", type=int, default=64,
+                    help="CPU baseline sample: clips per usable host CPU (about 10 s of CPU work on the 16 CPUs of a GPU box: all 1000 clips)")
     args = ap.parse_args()
 
     import torch
@@ -113,6 +118,14 @@ def main():
     def barrier():
         if world > 1:
             tdist.barrier()
+
+    ranks_seen, devices_seen = [rank], [dev_index]
+    if world > 1:                                            # who is here: one all-gather of (rank, local device)
+        me = torch.tensor([rank, dev_index], dtype=torch.int64, device="cpu" if rehearse else device)
+        got = [torch.empty_like(me) for _ in range(world)]
+        tdist.all_gather(got, me)
+        ranks_seen = sorted(int(g[0].item()) for g in got)
+        devices_seen = [int(g[1].item()) for g in got]
 
     def max_over_ranks(x):
         if world == 1:
@@ -185,17 +198,28 @@ def main():
         return per_clip * clips_per_launch if per_clip is not None else None
 
     if fixed_point:
-        # algorithmic work: the reference's 2*64*2420*n_frames multiply-adds, each as nine digit products (S9q)
-        ops_per_clip = 9 * PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0)
-        achieved = ops_per_clip * clips_per_launch / (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12 if pj_launches else 0.0
-        roof_pj = {"kernel": "project_q_kernel (v_mfma_i32_32x32x32_i8, nine digit products of 24-bit fixed-point factors)",
-                   "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
-                   "unit_note": "integer work: tera int8 multiply-add operations (2 per multiply-add) per second, TOP/s",
-                   "frac": round(achieved / MFMA_I8_PEAK_TOPS, 4), "traffic": pmc_traffic("project_q_hbm_bytes_per_clip"),
+        # work the kernel's instructions perform: 64 x 2420 x n_hp multiply-adds (the reference forms n_frames columns and
+        # subtracts afterwards; here the difference comes first), each as nine int8 digit products (S9q), 2 operations each
+        pj_s = pj_ms / max(pj_launches, 1) * 1e-3
+        macs_per_clip = PROJECT_Q_MACS_PER_CLIP * (geo.n_hp / 2320.0)
+        ops_per_clip = 2.0 * 9 * macs_per_clip
+        achieved = ops_per_clip * clips_per_launch / pj_s / 1e12 if pj_launches else 0.0
+        algorithmic = 2.0 * macs_per_clip * clips_per_launch / pj_s / 1e12 if pj_launches else 0.0
+        roof_pj = {"kernel": "hashprint_q_kernel (v_mfma_i32_32x32x32_i8, nine digit products of 24-bit fixed-point factors)",
+                   "bound": "mfma", "achieved": round(achieved, 1), "peak": round(MFMA_I8_PEAK_TOPS, 1), "unit": "TFLOP/s",
+                   "unit_note": "integer work: tera int8 operations (2 per multiply-add) per second, TOP/s; 'achieved' counts the "
+                                "nine digit products the fixed-point decomposition performs per reference multiply-add",
+                   "frac": round(achieved / MFMA_I8_PEAK_TOPS, 4),
+                   "frac_of_probe_ceiling": round(achieved / MFMA_I8_PROBE_TOPS, 4),
+                   "probe_ceiling_tops": MFMA_I8_PROBE_TOPS,
+                   "frac_algorithmic": round(algorithmic / MFMA_I8_PEAK_TOPS, 4),
+                   "algorithmic_tops": round(algorithmic, 1),
+                   "traffic": pmc_traffic("project_q_hbm_bytes_per_clip"),
                    "avg_launch_ms": round(pj_ms / max(pj_launches, 1), 4), "launches": pj_launches,
                    "ops_per_clip": ops_per_clip, "clips_per_launch": clips_per_launch,
-                   "f32_equivalent_tflops": round(PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0) * clips_per_launch /
-                                                  (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12, 1) if pj_launches else 0.0}
+                   "note": "frac_algorithmic counts one multiply-add per reference multiply-add (2 x 64 x 2420 x n_hp operations per "
+                           "clip); probe_ceiling = tools/mfma_i8_probe.hip back to back on random operands (the clock the chip holds "
+                           "under this instruction, profiles/r03_mfma_i8_probe.jsonl)"}
     else:
         achieved = PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0) * clips_per_launch / (pj_ms / max(pj_launches, 1) * 1e-3) / 1e12 \
             if pj_launches else 0.0
@@ -239,7 +263,10 @@ def main():
         plan = oracle.Plan(n_samples)
         got_all = hp.cpu().numpy().view(np.uint64)
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            from hpfw_amd import hostinfo
+            budget = hostinfo.cpu_budget()                   # affinity and cgroup quota, not the machine's core count
+            ref_libs = hostinfo.reference_cpu_libraries()    # FFTW3 / Eigen3 / TBB / essentia / MKL: looked for, not assumed
+            cores = budget["usable"]
             n_cpu = min(n_clips, max(1, args.cpu_clips_per_core * cores))
             sample = pcm[:n_cpu].cpu().numpy()
             t1 = time.perf_counter()
@@ -260,12 +287,18 @@ def main():
                 for key, dtk in zip(st, (tb - ta, tc - tb, td - tc, te - td, tf - te)):
                     st[key] += dtk
             one_dt = time.perf_counter() - t_one
+            scaling = (n_cpu / cdt) / (n_one / one_dt)
             cpu_baseline = {"value": round(n_cpu * geo.n_hp / cdt, 1), "unit": "hashprints/s", "cores": cores,
                             "kind": "port",
                             "sample": f"{n_cpu} of the same {args.seconds:g} s clips, oracle/hpfw_oracle.c "
-                                      f"(own C restatement, -O3 -mfma, no FFTW/Eigen/TBB on this box), "
-                                      f"{cores} threads in static chunks as flow_builder.hpp:321-325, {cdt:.1f} s",
+                                      f"(own C restatement, -O3 -mfma), {cores} threads = the CPUs this process may use "
+                                      f"(machine: {budget['os_cpu_count']}, cgroup quota: {budget['cgroup_cpus']}) in static "
+                                      f"chunks as flow_builder.hpp:321-325, {cdt:.1f} s",
                             "clips_per_s": round(n_cpu / cdt, 2),
+                            "host": budget,
+                            "reference_cpu_libraries": ref_libs,
+
+                            "threads_over_one_thread": round(scaling, 2),
                             "one_thread": {"clips_per_s": round(n_one / one_dt, 2), "clips": n_one,
                                            "ms_per_clip_by_stage": {k: round(v * 1e3 / n_one, 1) for k, v in st.items()}}}
         else:
@@ -273,6 +306,42 @@ def main():
             want = np.stack([plan.extract(filt, c) for c in pcm[idx].cpu().numpy()])
         parity = {"clips_checked": int(len(idx)), "bit_identical": bool(np.array_equal(got_all[idx], want)),
                   "hashprints_differing": int((got_all[idx] != want).sum())}
+
+    # the reference's arithmetic type for filters * frames is f32 (parallel_collector.h:57,127): the same pass with the f32
+    # fma chain (S9) instead of the fixed-point default (S9q), and every hashprint of the batch compared between the two
+    f32_chain = None
+    if fixed_point and not args.no_f32_chain:
+        hp32 = torch.empty_like(hp)
+        gpu.set_projection(0)
+        try:
+            def step32():
+                gpu.extract_dev(pcm.data_ptr(), n_samples, n_clips, hp32.data_ptr(), stream)
+            step32()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                step32()
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t1) / 2
+        finally:
+            gpu.set_projection(1)
+        x = torch.bitwise_xor(hp, hp32)
+        words = int((x != 0).sum().item())
+        bits = 0
+        for sh in range(0, 64, 16):                          # popcount by 16-bit table-free folding on the device
+            v = (x >> sh) & 0xFFFF
+            v = (v & 0x5555) + ((v >> 1) & 0x5555)
+            v = (v & 0x3333) + ((v >> 2) & 0x3333)
+            v = (v & 0x0F0F) + ((v >> 4) & 0x0F0F)
+            v = (v & 0x00FF) + ((v >> 8) & 0x00FF)
+            bits += int(v.sum().item())
+        f32_chain = {"ms_per_step": round(dt32 * 1e3, 3), "clips_per_s": round(n_clips / dt32, 1),
+                     "hashprints_per_s": round(n_clips * geo.n_hp / dt32, 1),
+                     "hashprints_differing_vs_fixed_point": words, "bits_differing_vs_fixed_point": bits,
+                     "hashprints_compared": int(hp.numel()), "bits_compared": int(hp.numel()) * 64,
+                     "note": "hpfw_gpu_set_projection(h, 0): filters * frames as the f32 fma chain on v_mfma_f32_32x32x2_f32, "
+                             "rank 0's batch, outside the timed region"}
+        del hp32, x
 
     pcie = None
     if rank == 0 and world == 1 and not args.no_pcie:
@@ -297,6 +366,12 @@ def main():
                                   stream, barrier, rehearse)
 
     if rank == 0:
+        comm = None
+        if world > 1:
+            comm = {"backend": tdist.get_backend(), "world_size": tdist.get_world_size(), "ranks_seen": ranks_seen,
+                    "devices_seen": devices_seen,
+                    "note": "backend 'nccl' is RCCL on ROCm; one process and one GPU per rank; ranks_seen / devices_seen come from "
+                            "an all-gather of every rank's (rank, local device) at start-up"}
         line = {
             "metric": "hashprints/sec (index) + Hamming matches/sec (search), 30 s@44.1 kHz clips",
             "value": round(value, 1), "unit": "hashprints/s", "n_gpus": world, "steps": args.steps,
@@ -314,8 +389,9 @@ def main():
             "event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
             "kernel_ms_one_pass": split,
             "roofline": roofline, "roofline_second_kernel": roofline_second, "cpu_baseline": cpu_baseline, "parity": parity,
+            "projection_f32_chain": f32_chain,
             "pcie_inclusive": pcie, "any_length": any_len, "search": search,
-            "stream": stream_res, "filter_learning": learn,
+            "stream": stream_res, "filter_learning": learn, "rccl": comm,
         }
         print(json.dumps(line), flush=True)
     gpu.close()
@@ -328,7 +404,8 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
     """configs[2] per GPU (configs[3] layout when world > 1): index shard resident in HBM, replicated
     queries, scan + per-shard top-k on every rank, one all-gather of Q x k x 16 B, identical merge."""
     import hpfw_amd
-    n_hp, kq = 2320, 305
+    n_hp = 2320
+    kq = int(gpu.geometry(5 * 44100).n_hp)            # what extraction yields for a 5 s query: 304 (C = ceil(M / 3), DESIGN.md section 7)
     n_local = args.index_clips
     g = torch.Generator(device=device)
     g.manual_seed(0x1D8 + rank)

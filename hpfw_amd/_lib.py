@@ -37,7 +37,7 @@ EXPORTS = (
     "hpfw_gpu_cfg_cov_reset", "hpfw_gpu_cfg_cov_accumulate", "hpfw_gpu_cfg_cov_get", "hpfw_gpu_cfg_learn_filters",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
     "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions", "hpfw_gpu_chirpz_table", "hpfw_gpu_prepare_length", "hpfw_gpu_set_projection", "hpfw_gpu_get_projection",
-    "hpfw_gpu_hashprints_from_db",
+    "hpfw_gpu_hashprints_from_db", "hpfw_gpu_stage_delta_q",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_calc_hashprints", "par_collector_save", "par_collector_load",
     "prepare_result_free", "calc_hashprint_result_free",
@@ -142,6 +142,7 @@ def lib():
     L.hpfw_gpu_set_projection.argtypes = [vp, i32]
     L.hpfw_gpu_get_projection.argtypes = [vp]
     L.hpfw_gpu_hashprints_from_db.argtypes = [vp, vp, i64, i64, vp, vp]
+    L.hpfw_gpu_stage_delta_q.argtypes = [vp, vp, i64, i64, vp, vp, vp]
     L.hpfw_gpu_set_conventions.argtypes = [vp, u32]
     L.par_collector_new.restype = vp
     L.par_collector_del.argtypes = [vp]
@@ -243,6 +244,10 @@ class Gpu:
 
     def hashprints_from_db_dev(self, d_db, n_clips, c, d_hp, stream=0):
         check(lib().hpfw_gpu_hashprints_from_db(self._h, d_db, n_clips, c, d_hp, stream))
+
+    def stage_delta_q_dev(self, d_db, n_clips, c, d_delta, d_hp=0, stream=0):
+        """the exact integer sums of the fixed-point projection, int64 [n_clips][64][c - 99] (parity checkpoint)"""
+        check(lib().hpfw_gpu_stage_delta_q(self._h, d_db, n_clips, c, d_delta, d_hp, stream))
 
     def prepare_length(self, n_samples):
         """build the host half of the tables of a clip length on the calling thread (thread-safe; see hpfw_gpu.h)"""

@@ -452,7 +452,7 @@ int pass_clips(hpfw_gpu *h, const DevPlan *dp, int64_t n_clips)
 {
     const hpfw::HostPlan &p = dp->hp;
     size_t per_clip = (size_t)2 * p.n1 * ((p.h + 31) / 32 * 32) * 4 + (size_t)(p.kmax - p.kmin) * 8 + (size_t)121 * p.c * 4 +
-                      (size_t)64 * std::max(p.n_frames, 1) * 8 + (size_t)((p.n1 + 1) / 2) * p.n2 * 4;
+                      (size_t)64 * std::max(p.n_frames, 1) * 4 + (size_t)((p.n1 + 1) / 2) * p.n2 * 4;
     if (p.bluestein) per_clip += 2 * hpfw::bz_plane_bytes(dp->bz, 1);
     size_t work = 0;
     for (const hpfw::CqClassDev &cd : dp->cls) work = std::max(work, hpfw::cq_big_work_bytes(cd, 1));
@@ -473,7 +473,7 @@ int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
     const size_t planar = p.bluestein ? hpfw::bz_plane_bytes(dp->bz, nb) : 0;
     const size_t need[7] = {p.bluestein ? planar : (size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4,
                             (size_t)nb * (p.kmax - p.kmin) * 8,
-                            (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 8, // (P as int64 for the fixed-point projection)
+                            (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4, // (P: the f32-chain projection only)
                             (size_t)ns * 121 * hpfw::kCqMaxWaves * 4,
                             p.bluestein ? 0 : (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4, planar}; // (the chirp-z path reads the PCM as it lies)
     for (int i = 0; i < 7; ++i) {
@@ -561,17 +561,12 @@ int run_back(hpfw_gpu *h, DevPlan *dp, int ns, uint64_t *d_hp, hipStream_t s)
     float *sdb = (float *)h->ws[2];
     float *proj = (float *)h->ws[3];
     int rc;
-    if (h->projection) { // S9q: exact integer sums on the int8 matrix pipe, delta + pack in the same kernel
+    if (h->projection) { // S9q: reference level, clip, exact integer sums on the int8 matrix pipe, sign and pack in ONE kernel
         {
             Timed t(h, K_PROJECT, s);
-            hpfw::launch_hashprints_q(h->d_fq_image, sdb, h->d_clipmax, ns, p.c, (long long *)h->ws[3], d_hp, s);
+            hpfw::launch_hashprints_q(h->d_fq_image, sdb, h->d_clipmax, ns, p.c, d_hp, nullptr, s);
         }
-        if ((rc = check_launch("project"))) return rc;
-        {
-            Timed t(h, K_PACK, s);
-            hpfw::launch_pack_q_edge((const long long *)h->ws[3], ns, p.c, d_hp, s);
-        }
-        return check_launch("delta_pack");
+        return check_launch("project");
     }
     {
         Timed t(h, K_PROJECT, s);
@@ -711,12 +706,11 @@ int hpfw_gpu_hashprints_from_db(hpfw_gpu *h, const float *d_db, int64_t n_clips,
     Ordered ordered(h, s);
     int rc;
     const int nbmax = 256;
-    if ((rc = ensure(&h->ws[3], &h->ws_bytes[3], (size_t)nbmax * 64 * (size_t)nf * 8))) return rc;
+    if (!h->projection && (rc = ensure(&h->ws[3], &h->ws_bytes[3], (size_t)nbmax * 64 * (size_t)nf * 4))) return rc;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
         if (h->projection) {
-            hpfw::launch_hashprints_q(h->d_fq_image, d_db + c0 * 121 * c, nullptr, nb, (int)c, (long long *)h->ws[3], d_hp + c0 * nhp, s);
-            hpfw::launch_pack_q_edge((const long long *)h->ws[3], nb, (int)c, d_hp + c0 * nhp, s);
+            hpfw::launch_hashprints_q(h->d_fq_image, d_db + c0 * 121 * c, nullptr, nb, (int)c, d_hp + c0 * nhp, nullptr, s);
         } else {
             hpfw::launch_project(h->d_fpack, d_db + c0 * 121 * c, nullptr, nb, (int)c, (float *)h->ws[3], s);
             hpfw::launch_pack((const float *)h->ws[3], nb, (int)nf, d_hp + c0 * nhp, s);
@@ -724,6 +718,26 @@ int hpfw_gpu_hashprints_from_db(hpfw_gpu *h, const float *d_db, int64_t n_clips,
         if ((rc = check_launch("project"))) return rc;
     }
     return 0;
+}
+
+int hpfw_gpu_stage_delta_q(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c, int64_t *d_delta, uint64_t *d_hp, void *stream)
+{
+    if (!h || !d_db || !d_delta) return fail(HPFW_E_INVALID, "null argument");
+    if (!h->has_filters) return fail(HPFW_E_NOFILTERS, "no filters: call hpfw_gpu_set_filters or hpfw_gpu_learn_filters first");
+    const int64_t nhp = c - (hpfw::kCtx - 1) - hpfw::kLag;
+    if (nhp <= 0 || n_clips <= 0) return 0;
+    if (n_clips > 65535) return fail(HPFW_E_INVALID, "at most 65535 clips per call");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    Ordered ordered(h, s);
+    int rc;
+    uint64_t *hp = d_hp;
+    if (!hp) { // the kernel always writes its hashprints
+        if ((rc = ensure(&h->ws[3], &h->ws_bytes[3], (size_t)n_clips * (size_t)nhp * 8))) return rc;
+        hp = (uint64_t *)h->ws[3];
+    }
+    hpfw::launch_hashprints_q(h->d_fq_image, d_db, nullptr, (int)n_clips, (int)c, hp, (long long *)d_delta, s);
+    return check_launch("project");
 }
 
 int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out)

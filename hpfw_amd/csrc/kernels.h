@@ -128,13 +128,13 @@ void launch_project(const float *d_fpack, const float *d_db, const float *d_tmax
                     float *d_proj, hipStream_t s);
 // delta over 80 frames, sign, bit pack: proj [n_clips][64][nf] -> hp [n_clips][nf-80]
 void launch_pack(const float *d_proj, int n_clips, int nf, uint64_t *d_hp, hipStream_t s);
-// the same in fixed point (k_project_q.hip): filter digits image; exact int64 projection with delta + pack
-// in its epilogue (and a small kernel for the frames whose partner lies in the next tile)
+// a4's reference level + a5..a8 in fixed point (k_project_q.hip): filter digits image; dB terms (d_tmax != NULL)
+// or dB spectrograms -> hashprints in one kernel, the lag-80 difference taken on the quantised spectrogram (exact integers).
+// d_dbg: NULL, or (tests) the integer sums D [n_clips][64][c - 99]
 size_t project_q_image_bytes();
 void pack_filters_q(const float *f_colmajor, std::vector<int8_t> &image);
-void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float *d_tmax, int n_clips, int c, long long *d_proj,
-                         uint64_t *d_hp, hipStream_t s);
-void launch_pack_q_edge(const long long *d_proj, int n_clips, int c, uint64_t *d_hp, hipStream_t s);
+void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float *d_tmax, int n_clips, int c, uint64_t *d_hp,
+                         long long *d_dbg, hipStream_t s);
 
 // ---- HashprintHandle with other template arguments (k_hashprint_cfg.hip) ----------------------------
 struct CfgArgs {

@@ -281,16 +281,21 @@ int hpfw_gpu_plan_checksum(int64_t n_samples, uint64_t *out8);
 int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein, unsigned conventions, uint64_t *out8);
 
 /* ---- the projection's arithmetic.  The reference multiplies filters and frames in f32 (an Eigen/MKL sgemm,
- * parallel_collector.h:57,127) and keeps only the sign of P[r,i] - P[r,i+80].  mode 1 (default): both factors rounded
- * once to 24-bit fixed point, the 2420-term sums exact integers on the int8 matrix pipe (closer to the
- * real-number product than an f32 sgemm in any order, and 3x faster than mode 0).  mode 0: the f32 fma chain in
- * ascending k on the f32 matrix pipe.  The two differ in a hashprint bit only where the difference of
- * the two projections is within rounding of zero. */
+ * parallel_collector.h:57,127) and keeps only the sign of P[r,i] - P[r,i+80] (hashprint_handle.h:119-122).  mode 1
+ * (default): both factors rounded once to fixed point (S to 1/98304 dB, F to 2^-22 of its row's largest entry), the
+ * lag-80 difference taken on the quantised spectrogram and its 2420-term sums with the filters exact integers on the
+ * int8 matrix pipe (closer to the real-number product than an f32 sgemm in any order; no projection is
+ * ever stored).  mode 0: the f32 fma chain in ascending k on the f32 matrix pipe.  The two differ in a
+ * hashprint bit only where the difference of the two projections is within rounding of zero. */
 int hpfw_gpu_set_projection(hpfw_gpu *h, int mode);
 int hpfw_gpu_get_projection(hpfw_gpu *h);
 /* dB spectrograms [n_clips][121][c] (device, as hpfw_gpu_stage_spectrogram writes them) -> hashprints
  * [n_clips][c - 99] with the handle's filters and projection mode */
 int hpfw_gpu_hashprints_from_db(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c, uint64_t *d_hp, void *stream);
+/* parity checkpoint of mode 1: the exact integer sums D[r][i] = sum_k fq[r][k] (u[k][i] - u[k][i + 80]) whose signs are
+ * the hashprint bits, d_delta [n_clips][64][c - 99] int64 (device); d_hp may be NULL.  Same kernel as extraction. */
+int hpfw_gpu_stage_delta_q(hpfw_gpu *h, const float *d_db, int64_t n_clips, int64_t c, int64_t *d_delta, uint64_t *d_hp,
+                           void *stream);
 
 /* ---- table preparation ahead of time.  A corpus of real recordings brings a new clip length with almost every file,
  * and the host half of a length's tables (constant-Q windows and chirp spectra, twiddles) costs more than the

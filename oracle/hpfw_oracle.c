@@ -1062,17 +1062,26 @@ void hpfw_oracle_pack_cfg(const float *proj, int bits, int lag, int64_t n_frames
 /* ------------------------------------------------------------------------------------------ */
 /* S9q / S10q: the projection in fixed point, exactly.                                           */
 /* The reference multiplies filters and frames in f32 (an Eigen/MKL sgemm, parallel_collector.h:57,127) and keeps    */
-/* only the SIGN of P[r,i] - P[r,i+80] (hashprint_handle.h:119-122).  Here both factors are rounded once to 24-bit   */
-/* fixed point and the 2420-term sums are exact integers:                                                             */
-/*   u[b][c]  = rint(S[b][c] * 2^17) + 40 * 2^17          (S in [-80, 0] dB; the offset centres the range and cancels */
-/*                                                          in the difference of two columns of the same filter)     */
+/* only the SIGN of P[r,i] - P[r,i+80] (hashprint_handle.h:119-122).  Here both factors are rounded once to fixed     */
+/* point and the 2420-term sums are exact integers:                                                                   */
+/*   u[b][c]  = rint(clamp(S[b][c], -80, 0) * 98304)        (S in [-80, 0] dB already, convert.h:12-15; 98304 = 3 2^15 */
+/*                                                          keeps the difference of two columns inside 24 bits)       */
 /*   fq[r][k] = rint(F[r][k] * 2^(21 - ilogb(max_k |F[r][k]|)))   (a positive power of two per filter row: it cannot  */
 /*                                                          change a sign)                                            */
 /*   Pq[r][n] = sum_{b,t} fq[r][20 b + t] * u[b][n + t]    (int64, |Pq| < 2^57)                                       */
-/*   bit (63 - r) of hp[i] = (Pq[r][i] - Pq[r][i + 80] >= 0)                                                          */
-/* The distance to the real-number projection (rounding of S: 2^-18 dB, of F: 2^-23 of the row's largest entry) is    */
+/*   D[r][i]  = Pq[r][i] - Pq[r][i + 80] = sum_{b,t} fq[r][20 b + t] * (u[b][i + t] - u[b][i + 80 + t])              */
+/*   bit (63 - r) of hp[i] = (D[r][i] >= 0)                                                                           */
+/* The distance to the real-number projection (rounding of S: 5.1e-6 dB, of F: 2^-23 of the row's largest entry) is   */
 /* below the rounding error of an f32 sgemm over 2420 terms in any order; integer sums have no order.                 */
 /* ------------------------------------------------------------------------------------------ */
+#define HPFW_O_QSCALE 98304.0f
+
+static int32_t q_fixed(float s)
+{
+    s = s < -80.0f ? -80.0f : (s > 0.0f ? 0.0f : s);
+    return (int32_t)rintf(s * HPFW_O_QSCALE);
+}
+
 void hpfw_oracle_quantise_filters(const float *f, int32_t *fq /* [64][2420], row-major */)
 {
     const int kk = HPFW_O_BINS * HPFW_O_CTX;
@@ -1084,6 +1093,11 @@ void hpfw_oracle_quantise_filters(const float *f, int32_t *fq /* [64][2420], row
     }
 }
 
+void hpfw_oracle_quantise_db(const float *s_db, int64_t count, int32_t *u)
+{
+    for (int64_t i = 0; i < count; ++i) u[i] = q_fixed(s_db[i]);
+}
+
 void hpfw_oracle_project_q(const float *f, const float *s_db, int64_t c, int64_t *proj /* [64][c - 19] */)
 {
     const int64_t nf = c - (HPFW_O_CTX - 1);
@@ -1091,7 +1105,7 @@ void hpfw_oracle_project_q(const float *f, const float *s_db, int64_t c, int64_t
     int32_t *fq = (int32_t *)malloc(sizeof(int32_t) * (size_t)HPFW_O_NFILT * kk);
     int32_t *u = (int32_t *)malloc(sizeof(int32_t) * (size_t)(HPFW_O_BINS * c));
     hpfw_oracle_quantise_filters(f, fq);
-    for (int64_t i = 0; i < HPFW_O_BINS * c; ++i) u[i] = (int32_t)rintf(s_db[i] * 131072.0f) + 40 * 131072;
+    hpfw_oracle_quantise_db(s_db, HPFW_O_BINS * c, u);
     for (int r = 0; r < HPFW_O_NFILT; ++r) {
         int64_t *pr = proj + (int64_t)r * nf;
         for (int64_t n = 0; n < nf; ++n) pr[n] = 0;
@@ -1102,6 +1116,35 @@ void hpfw_oracle_project_q(const float *f, const float *s_db, int64_t c, int64_t
                 for (int64_t n = 0; n < nf; ++n) pr[n] += w * (int64_t)ub[n];
             }
     }
+    free(u);
+    free(fq);
+}
+
+/* the sums whose signs are the hashprint bits, with the difference taken first (what the GPU kernel forms): */
+/* D[r][i] = sum_{b,t} fq[r][20 b + t] * (u[b][i + t] - u[b][i + 80 + t]), i < c - 99                          */
+void hpfw_oracle_delta_q(const float *f, const float *s_db, int64_t c, int64_t *delta /* [64][c - 99] */)
+{
+    const int64_t nhp = c - (HPFW_O_CTX - 1) - HPFW_O_LAG;
+    const int kk = HPFW_O_BINS * HPFW_O_CTX;
+    if (nhp <= 0) return;
+    int32_t *fq = (int32_t *)malloc(sizeof(int32_t) * (size_t)HPFW_O_NFILT * kk);
+    int32_t *u = (int32_t *)malloc(sizeof(int32_t) * (size_t)(HPFW_O_BINS * c));
+    int32_t *du = (int32_t *)malloc(sizeof(int32_t) * (size_t)(HPFW_O_BINS * c));
+    hpfw_oracle_quantise_filters(f, fq);
+    hpfw_oracle_quantise_db(s_db, HPFW_O_BINS * c, u);
+    for (int b = 0; b < HPFW_O_BINS; ++b)
+        for (int64_t col = 0; col < c; ++col) du[b * c + col] = col + HPFW_O_LAG < c ? u[b * c + col] - u[b * c + col + HPFW_O_LAG] : 0;
+    for (int r = 0; r < HPFW_O_NFILT; ++r) {
+        int64_t *dr = delta + (int64_t)r * nhp;
+        for (int64_t n = 0; n < nhp; ++n) dr[n] = 0;
+        for (int b = 0; b < HPFW_O_BINS; ++b)
+            for (int t = 0; t < HPFW_O_CTX; ++t) {
+                const int64_t w = fq[(size_t)r * kk + b * HPFW_O_CTX + t];
+                const int32_t *db_ = du + b * c + t;
+                for (int64_t n = 0; n < nhp; ++n) dr[n] += w * (int64_t)db_[n];
+            }
+    }
+    free(du);
     free(u);
     free(fq);
 }

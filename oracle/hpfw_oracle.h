@@ -85,6 +85,9 @@ void hpfw_oracle_project(const float *f_colmajor, const float *s_db, int64_t c, 
 void hpfw_oracle_quantise_filters(const float *f_colmajor, int32_t *fq /* [64][2420] row-major */);
 void hpfw_oracle_project_q(const float *f_colmajor, const float *s_db, int64_t c, int64_t *proj /* [64][c-19] */);
 void hpfw_oracle_pack_q(const int64_t *proj, int64_t n_frames, uint64_t *hp /* [n_frames-80] */);
+/* the same sums with the lag-80 difference taken first: delta[r][i] = proj[r][i] - proj[r][i + 80], [64][c - 99] */
+void hpfw_oracle_delta_q(const float *f_colmajor, const float *s_db, int64_t c, int64_t *delta);
+void hpfw_oracle_quantise_db(const float *s_db, int64_t count, int32_t *u);
 /* which projection hpfw_oracle_extract* use: 0 = the f32 fma chain (S9), 1 = fixed point (S9q) */
 void hpfw_oracle_set_projection(int mode);
 int hpfw_oracle_get_projection(void);

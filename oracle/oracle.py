@@ -62,6 +62,8 @@ def lib():
         L.hpfw_oracle_project.argtypes = [vp, vp, i64, vp]
         L.hpfw_oracle_project_q.argtypes = [vp, vp, i64, vp]
         L.hpfw_oracle_pack_q.argtypes = [vp, i64, vp]
+        L.hpfw_oracle_delta_q.argtypes = [vp, vp, i64, vp]
+        L.hpfw_oracle_quantise_db.argtypes = [vp, i64, vp]
         L.hpfw_oracle_quantise_filters.argtypes = [vp, vp]
         L.hpfw_oracle_set_projection.argtypes = [i32]
         L.hpfw_oracle_get_projection.restype = i32
@@ -200,6 +202,23 @@ def pack_q(proj):
     hp = np.zeros(max(nf - LAG, 0), np.uint64)
     lib().hpfw_oracle_pack_q(_p(pr), nf, _p(hp))
     return hp
+
+
+def delta_q(filters, s_db):
+    """S9q with the lag-80 difference taken first: D[r][i] = Pq[r][i] - Pq[r][i + 80], int64 [64][c - 99]"""
+    f = _c(filters, np.float32)
+    s = _c(s_db, np.float32)
+    c = s.shape[1]
+    out = np.zeros((NFILT, max(c - CTX + 1 - LAG, 0)), np.int64)
+    lib().hpfw_oracle_delta_q(_p(f), _p(s), c, _p(out))
+    return out
+
+
+def quantise_db(s_db):
+    s = _c(s_db, np.float32)
+    out = np.zeros(s.shape, np.int32)
+    lib().hpfw_oracle_quantise_db(_p(s), s.size, _p(out))
+    return out
 
 
 def quantise_filters(filters):

@@ -76,7 +76,7 @@ def main():
         traffic = {"clips_per_launch_profiled": clips, "source": f"{tag}_pmc.json",
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / clips, launches of the largest grid"}
         for key, prefixes in (("project_mfma_hbm_bytes_per_clip", ("project_kernel<true", "project_kernel")),
-                              ("project_q_hbm_bytes_per_clip", ("project_q_kernel<true", "project_q_kernel")),
+                              ("project_q_hbm_bytes_per_clip", ("hashprint_q_kernel<true", "hashprint_q_kernel", "project_q_kernel")),
                               ("fwd_rows_hbm_bytes_per_clip", ("fwd_rows_kernel",))):
             pk = next((v for k, v in sorted(pmc.items()) if any(k.startswith(px) for px in prefixes)), {})
             if "hbm_bytes_per_launch" in pk:

@@ -83,6 +83,7 @@ def main():
         ext[f"{tag}_hp"] = hp
         ext[f"{tag}_hp_f32chain"] = hp_f32
         ext[f"{tag}_projq_every8"] = oracle.project_q(filt, sdb)[::8, ::8].copy()
+        ext[f"{tag}_deltaq_every8"] = oracle.delta_q(filt, sdb)[::8, ::8].copy()
         ext[f"{tag}_mag_f32_every8"] = mag[::4, ::8].copy()        # float32, exact oracle bits
         ext[f"{tag}_mag_f64_every8"] = m64[::4, ::8].copy()        # float64 definition
         ext[f"{tag}_db_every8"] = sdb[::4, ::8].copy()

@@ -18,7 +18,7 @@ def oracle():
 
 def test_fixed_point_projection_is_exact(oracle):
     """hashprints in both projection modes against the oracle in the same mode, ragged clip lengths (tiles of 256
-    frames with tails, widths below one tile), from PCM and from given dB spectrograms; the int64 projection itself"""
+    hashprints with tails, widths below one tile), from PCM and from given dB spectrograms; the int64 sums themselves"""
     import torch
     filt = synth.make_filters()
     g = hpfw_amd.Gpu(0)
@@ -40,6 +40,12 @@ def test_fixed_point_projection_is_exact(oracle):
                 g.hashprints_from_db_dev(d_db.data_ptr(), nclips, plan.c, hp.data_ptr())
                 torch.cuda.synchronize()
                 assert np.array_equal(hp.cpu().numpy().view(np.uint64), want), (sec, mode)
+                if mode == 1:                                         # the exact integer sums behind the bits
+                    dq = torch.zeros((nclips, 64, plan.n_hp), dtype=torch.int64, device="cuda")
+                    g.stage_delta_q_dev(d_db.data_ptr(), nclips, plan.c, dq.data_ptr())
+                    torch.cuda.synchronize()
+                    for i in range(nclips):
+                        assert np.array_equal(dq[i].cpu().numpy(), oracle.delta_q(filt, db[i])), (sec, i)
     finally:
         oracle.set_projection(before)
         g.close()
@@ -56,7 +62,7 @@ def test_the_two_projections_agree_within_rounding(oracle):
     fq = oracle.quantise_filters(filt)
     m = np.abs(filt.reshape(2420, 64)).max(axis=0)
     e = 21 - np.floor(np.log2(m)).astype(int)
-    back = (pq - (fq.astype(np.int64).sum(axis=1) * 40 * 131072)[:, None]) / (2.0 ** e)[:, None] / 131072.0
+    back = pq / (2.0 ** e)[:, None] / 98304.0
     assert np.abs(back - pf).max() < 1e-3
     x = oracle.pack(pf) ^ oracle.pack_q(pq)
     assert sum(bin(int(v)).count("1") for v in x) <= 1e-4 * x.size * 64
@@ -87,16 +93,21 @@ def test_fixed_point_projection_edge_values(oracle):
             s = rng.uniform(-80, 0, (3, 121, c)).astype(np.float32)
             s[0, :, ::2] = -80.0
             s[0, :, 1::2] = 0.0
-            s[1] = np.round(s[1] * 131072.0) / 131072.0                     # exactly representable steps
+            s[1] = np.round(s[1] * 98304.0) / 98304.0                       # steps of the fixed-point grid
             s[1, 5] = np.nextafter(np.float32(-80.0), np.float32(0.0))
             s[2, :, : c // 2] = -80.0
+            s[2, 7, 1::3] = 0.0                                             # |Du| at its largest: -80 against 0, 80 columns apart
             d_s = torch.from_numpy(s).cuda()
             hp = torch.zeros((3, c - 99), dtype=torch.int64, device="cuda")
             g.hashprints_from_db_dev(d_s.data_ptr(), 3, c, hp.data_ptr())
             torch.cuda.synchronize()
             got = hp.cpu().numpy().view(np.uint64)
+            dq = torch.zeros((3, 64, c - 99), dtype=torch.int64, device="cuda")
+            g.stage_delta_q_dev(d_s.data_ptr(), 3, c, dq.data_ptr())
+            torch.cuda.synchronize()
             for i in range(3):
                 assert np.array_equal(got[i], oracle.hashprints_from_db(filt, s[i])), (c, i)
+                assert np.array_equal(dq[i].cpu().numpy(), oracle.delta_q(filt, s[i])), (c, i)
             assert ((got >> np.uint64(63)) == 1).all()                       # row 0: zero filters, delta 0 >= 0
     finally:
         oracle.set_projection(before)

@@ -155,6 +155,8 @@ def test_golden_extract(oracle):
         pq = oracle.project_q(filt, s)
         assert np.array_equal(pq[::8, ::8], g[f"{tag}_projq_every8"])
         assert np.array_equal(oracle.pack_q(pq), g[f"{tag}_hp"])
+        dq = oracle.delta_q(filt, s)
+        assert np.array_equal(dq, pq[:, :-80] - pq[:, 80:]) and np.array_equal(dq[::8, ::8], g[f"{tag}_deltaq_every8"])
         assert oracle.get_projection() == 1 and np.array_equal(plan.extract(filt, pcm), g[f"{tag}_hp"])
     two = np.stack([gen.golden_pcm(110250, 1), gen.golden_pcm(110250, 2)])
     hp = oracle.Plan(110250).extract_batch(filt, two, n_threads=2)
@@ -301,7 +303,11 @@ def test_fixed_point_projection_against_numpy(oracle):
     e = 21 - np.floor(np.log2(m)).astype(np.int64)
     fq = np.rint(f.astype(np.float64) * 2.0 ** e[:, None]).astype(np.int64)
     assert np.array_equal(oracle.quantise_filters(filt), fq) and np.abs(fq).max() <= 2 ** 22
-    u = np.rint(s.astype(np.float64) * 131072.0).astype(np.int64) + 40 * 131072
+    s[3, :7] = [-80.0, 0.0, -79.99999, -1e-6, -40.000004, -80.0, 0.0]          # the ends of the range
+    prod = s * np.float32(98304.0)                                           # one f32 rounding, then round-half-even
+    assert prod.dtype == np.float32
+    u = np.rint(prod.astype(np.float64)).astype(np.int64)
+    assert np.array_equal(oracle.quantise_db(s), u) and u.min() >= -80 * 98304 and u.max() <= 0
     nf = s.shape[1] - 19
     frames = np.stack([u[b, t:t + nf] for b in range(121) for t in range(20)])   # [k][n], k = 20 b + t
     want = fq @ frames
@@ -310,7 +316,14 @@ def test_fixed_point_projection_against_numpy(oracle):
     hp = oracle.pack_q(got)
     bits = (want[:, :-80] - want[:, 80:]) >= 0
     assert np.array_equal(hp, (bits.astype(np.uint64) << (np.uint64(63) - np.arange(64, dtype=np.uint64))[:, None]).sum(axis=0, dtype=np.uint64))
-    back = (want - (fq.sum(axis=1) * 40 * 131072)[:, None]) / 2.0 ** e[:, None] / 131072.0
+    # the difference taken first (what the GPU kernel forms): the same integers, and three balanced base-256 digits hold it
+    du = u[:, :-80] - u[:, 80:]
+    assert np.abs(du).max() <= 80 * 98304 < 127 * 65536 + 127 * 256 + 127
+    nhp = nf - 80
+    dframes = np.stack([du[b, t:t + nhp] for b in range(121) for t in range(20)])
+    dq = oracle.delta_q(filt, s)
+    assert np.array_equal(dq, fq @ dframes) and np.array_equal(dq, want[:, :-80] - want[:, 80:])
+    back = want / 2.0 ** e[:, None] / 98304.0
     exact = f.astype(np.float64) @ np.stack([s[b, t:t + nf] for b in range(121) for t in range(20)]).astype(np.float64)
     chain = oracle.project(filt, s)
     assert np.abs(back - exact).max() < 2e-4 and np.abs(chain - exact).max() < 2e-3

@@ -17,7 +17,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kIters = 4096;
 
-// ACC independent accumulators, LDSOPS: 0 = operands in registers, 1 = both operands re-read from LDS every instruction
+// ACC independent accumulators, LDSOPS: 0 = operands in registers, 1 = both operands of every instruction re-read from LDS
+// (ds_read_b128), the reads of the next group of ACC instructions issued before this group's instructions
 template <int ACC, int LDSOPS>
 __global__ __launch_bounds__(512) void probe(const v4i *__restrict__ src, int *out, long long *stamps)
 {
@@ -29,16 +30,29 @@ __global__ __launch_bounds__(512) void probe(const v4i *__restrict__ src, int *o
 #pragma unroll
     for (int a = 0; a < ACC; ++a) acc[a] = v16i{0};
     v4i a0 = src[lane], b0 = src[64 + lane];
+    v4i an[ACC], bn[ACC], ac[ACC], bc[ACC];
+#pragma unroll
+    for (int a = 0; a < ACC; ++a) {
+        an[a] = lds[(a * 128 + lane) & 4095];
+        bn[a] = lds[(a * 128 + 64 + lane) & 4095];
+    }
     const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < kIters / ACC; ++it) {
+        if (LDSOPS) {
 #pragma unroll
-        for (int a = 0; a < ACC; ++a) {
-            if (LDSOPS) {
-                a0 = lds[((it * ACC + a) * 128 + lane) & 4095];
-                b0 = lds[((it * ACC + a) * 128 + 64 + lane) & 4095];
+            for (int a = 0; a < ACC; ++a) {
+                ac[a] = an[a];
+                bc[a] = bn[a];
             }
-            acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[a], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < ACC; ++a) {
+                an[a] = lds[(((it + 1) * ACC + a) * 128 + lane) & 4095];
+                bn[a] = lds[(((it + 1) * ACC + a) * 128 + 64 + lane) & 4095];
+            }
         }
+#pragma unroll
+        for (int a = 0; a < ACC; ++a)
+            acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(LDSOPS ? ac[a] : a0, LDSOPS ? bc[a] : b0, acc[a], 0, 0, 0);
     }
     const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     int s = 0;
