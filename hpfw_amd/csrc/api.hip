@@ -67,7 +67,8 @@ hpfw::RadixList to_radix(const std::vector<int> &r)
 
 struct DevPlan {
     hpfw::HostPlan hp;
-    hpfw::ColsArgs cols;
+    hpfw::ColsQArgs cols;
+    hpfw::Rows2Out rows_out;
     hpfw::RowsArgs rows;
     hpfw::BzArgs bz; // clip lengths with a prime factor above 7 (hp.bluestein)
     hpfw::CqPlanDev cq;
@@ -288,9 +289,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     ra.n2 = p.n2;
     ra.h = p.h;
     ra.hpad = (p.h + 31) / 32 * 32;
-    // The pcm_pairs pre-pass (coalesced stream) measured faster than reading the aligned 4-byte pair
-    // words in place (6.4 vs 7.1 ms per 1000 clips); HPFW_ROWS_INPLACE=1 selects the latter (n1 even).
-    ra.pair_stride = (p.n1 % 2 == 0 && !p.bluestein && std::getenv("HPFW_ROWS_INPLACE")) ? p.n1 / 2 : 1;
+    ra.pair_stride = 1;
     ra.groups.n = (int)p.groups.size();
     for (size_t g = 0; g < p.groups.size(); ++g) {
         ra.groups.r1[g] = p.groups[g].first;
@@ -298,7 +297,6 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         ra.groups.tw_off[g] = p.rows_gtw_off[g];
     }
     if ((rc = upload(p.rows_gtw, reinterpret_cast<const hpfw::HostCf **>(&ra.gtw), dp->owned))) return rc;
-    if ((rc = upload(p.tw_big, reinterpret_cast<const hpfw::HostCf **>(&ra.tw_big), dp->owned))) return rc;
     if ((rc = upload(p.pos_n2, &ra.pos_n2, dp->owned))) return rc;
     if ((rc = upload(p.kb_last, &ra.kb_last, dp->owned))) return rc;
     if (hpfw::fwd_rows_lds_bytes(ra) > 160 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
@@ -366,28 +364,40 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         if (launched != hipSuccess || done != hipSuccess)
             return fail(HPFW_E_HIP, std::string("chirp-z tables: ") + hipGetErrorString(launched != hipSuccess ? launched : done));
     }
-    // column DFT: coefficient image for the MFMA A operand
-    hpfw::ColsArgs &ca = dp->cols;
+    // S6 (7-smooth lengths): the column stage's twiddle digits, digit-offset correction and inter-stage twiddles
+    hpfw::ColsQArgs &ca = dp->cols;
     std::memset(&ca, 0, sizeof(ca));
-    ca.n1 = p.n1;
-    ca.n2 = p.n2;
-    ca.h = p.h;
-    ca.hpad = ra.hpad;
-    ca.kmin = p.kmin;
-    ca.kmax = p.kmax;
-    ca.k1lo = p.k1lo;
-    ca.k1n = p.k1hi - p.k1lo + 1;
-    ca.n_tiles = (2 * ca.k1n + 15) / 16;
+    dp->rows_out = hpfw::Rows2Out{p.n1, p.hq, p.q2lo, p.q2w, nullptr, nullptr, (p.n2 + 3) / 4};
     if (!p.bluestein) {
-        std::vector<float> apack((size_t)p.n1 * ca.n_tiles * 64);
-        hpfw::pack_cols_coefficients(p.n1, ca.k1lo, ca.k1n, reinterpret_cast<const float *>(p.tw_n1.data()),
-                                     ca.n_tiles, apack.data());
-        if ((rc = upload(apack, &ca.apack, dp->owned))) return rc;
+        ca.n1 = p.n1;
+        ca.n2 = p.n2;
+        ca.hq = p.hq;
+        ca.mt = p.cols_mt;
+        ca.ks = p.cols_ks;
+        const int8_t *img = nullptr;
+        if ((rc = upload(p.cols_image, &img, dp->owned))) return rc;
+        ca.image = img;
+        if ((rc = upload(p.cols_corr, &ca.corr, dp->owned))) return rc;
+        if ((rc = upload(p.ts_seed, reinterpret_cast<const hpfw::HostCf **>(&dp->rows_out.seed), dp->owned))) return rc;
+        if ((rc = upload(p.ts_step, reinterpret_cast<const hpfw::HostCf **>(&dp->rows_out.step), dp->owned))) return rc;
     }
     hpfw::CqPlanDev &c = dp->cq;
     c.kmin = p.kmin;
     c.nk = p.kmax - p.kmin;
     c.c = p.c;
+    if (p.bluestein) { // natural order from kmin on
+        c.xn1 = 1;
+        c.xw = 0;
+        c.xq0 = p.kmin;
+        c.xclip = c.nk;
+        c.xmagic = 0;
+    } else {           // x[k mod n1][k / n1 - q2lo], rows of q2w
+        c.xn1 = p.n1;
+        c.xw = p.q2w;
+        c.xq0 = p.q2lo;
+        c.xclip = (int64_t)p.n1 * p.q2w;
+        c.xmagic = ((1ull << 40) + (unsigned long long)p.n1 - 1) / (unsigned long long)p.n1;
+    }
     std::vector<int> start(p.start, p.start + 121), lg(p.lg, p.lg + 121);
     if ((rc = upload(start, &c.start, dp->owned))) return rc;
     if ((rc = upload(lg, &c.lg, dp->owned))) return rc;
@@ -415,7 +425,8 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         std::vector<hpfw::HostCf>().swap(hp.rows_gtw);
         std::vector<hpfw::HostCf>().swap(hp.tw_n2);
         std::vector<hpfw::HostCf>().swap(hp.tw_n1);
-        std::vector<hpfw::HostCf>().swap(hp.tw_big);
+        std::vector<hpfw::HostCf>().swap(hp.ts_seed);
+        std::vector<int8_t>().swap(hp.cols_image);
         std::vector<hpfw::HostCf>().swap(hp.g);
         for (hpfw::BluesteinClass &bc : hp.classes) {
             std::vector<hpfw::HostCf>().swap(bc.tw);
@@ -451,9 +462,11 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
 int pass_clips(hpfw_gpu *h, const DevPlan *dp, int64_t n_clips)
 {
     const hpfw::HostPlan &p = dp->hp;
-    size_t per_clip = (size_t)2 * p.n1 * ((p.h + 31) / 32 * 32) * 4 + (size_t)(p.kmax - p.kmin) * 8 + (size_t)121 * p.c * 4 +
-                      (size_t)64 * std::max(p.n_frames, 1) * 4 + (size_t)((p.n1 + 1) / 2) * p.n2 * 4;
-    if (p.bluestein) per_clip += 2 * hpfw::bz_plane_bytes(dp->bz, 1);
+    size_t per_clip = (size_t)121 * p.c * 4 + (size_t)64 * std::max(p.n_frames, 1) * 4;
+    if (p.bluestein)
+        per_clip += 2 * hpfw::bz_plane_bytes(dp->bz, 1) + (size_t)(p.kmax - p.kmin) * 8;
+    else
+        per_clip += (size_t)p.hq * p.n2 * 8 + (size_t)p.n1 * p.q2w * 8;
     size_t work = 0;
     for (const hpfw::CqClassDev &cd : dp->cls) work = std::max(work, hpfw::cq_big_work_bytes(cd, 1));
     per_clip += work;
@@ -471,11 +484,12 @@ int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
         if (rc) return rc;
     }
     const size_t planar = p.bluestein ? hpfw::bz_plane_bytes(dp->bz, nb) : 0;
-    const size_t need[7] = {p.bluestein ? planar : (size_t)nb * 2 * p.n1 * ((p.h + 31) / 32 * 32) * 4,
-                            (size_t)nb * (p.kmax - p.kmin) * 8,
+    // ws[0]: the column stage's output z [hq][n2] (chirp-z path: a planar buffer); ws[1]: the forward bins (XsView layout)
+    const size_t need[7] = {p.bluestein ? planar : (size_t)nb * p.hq * p.n2 * 8,
+                            p.bluestein ? (size_t)nb * (p.kmax - p.kmin) * 8 : (size_t)nb * p.n1 * p.q2w * 8,
                             (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4, // (P: the f32-chain projection only)
                             (size_t)ns * 121 * hpfw::kCqMaxWaves * 4,
-                            p.bluestein ? 0 : (size_t)nb * ((p.n1 + 1) / 2) * p.n2 * 4, planar}; // (the chirp-z path reads the PCM as it lies)
+                            0, planar};
     for (int i = 0; i < 7; ++i) {
         int rc = ensure(&h->ws[i], &h->ws_bytes[i], need[i]);
         if (rc) return rc;
@@ -507,23 +521,16 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
         }
         return check_launch("bz_cols");
     }
-    if (dp->rows.pair_stride == 1) {
-        Timed t(h, K_PAIRS, s);
-        hpfw::launch_pcm_pairs(p.n, p.n1, p.n2, d_pcm, nb, (hpfw::i16x2 *)h->ws[5], s);
-    }
-    {
-        Timed t(h, K_ROWS, s);
-        if (dp->rows.pair_stride == 1)
-            hpfw::launch_fwd_rows(dp->rows, (const hpfw::i16x2 *)h->ws[5], nb, yp, s);
-        else
-            hpfw::launch_fwd_rows(dp->rows, reinterpret_cast<const hpfw::i16x2 *>(d_pcm), nb, yp, s);
-    }
-    if ((rc = check_launch("fwd_rows"))) return rc;
     {
         Timed t(h, K_COLS, s);
-        hpfw::launch_fwd_cols(dp->cols, yp, nb, x, s);
+        hpfw::launch_fwd_cols_q(dp->cols, d_pcm, p.n, nb, (float *)h->ws[0], s); // pcm as it lies -> z [hq][Re, Im][n2]
     }
-    return check_launch("fwd_cols");
+    if ((rc = check_launch("fwd_cols"))) return rc;
+    {
+        Timed t(h, K_ROWS, s);
+        hpfw::launch_fwd_rows2(dp->rows, dp->rows_out, (const float *)h->ws[0], nb, x, s); // -> x [n1][q2w]
+    }
+    return check_launch("fwd_rows");
 }
 
 // front end for nb clips: PCM -> dB terms t (and their per-clip maximum in d_clipmax) at clip slot
@@ -931,7 +938,9 @@ int hpfw_gpu_stage_spectrum(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
-        if ((rc = run_forward(h, dp, d_pcm + c0 * n_samples, nb, (hpfw::cf *)d_x + c0 * nk, s))) return rc;
+        if ((rc = run_forward(h, dp, d_pcm + c0 * n_samples, nb, (hpfw::cf *)h->ws[1], s))) return rc;
+        hpfw::launch_gather_bins(dp->cq, (const hpfw::cf *)h->ws[1], nb, (hpfw::cf *)d_x + c0 * nk, s); // natural order [kmin, kmax)
+        if ((rc = check_launch("gather_bins"))) return rc;
     }
     return 0;
 }
@@ -949,14 +958,19 @@ int hpfw_gpu_stage_cqmag(hpfw_gpu *h, const float *d_x, int64_t n_samples, int64
     const int nbmax = pass_clips(h, dp, n_clips);
     if ((rc = ensure_ws(h, dp, nbmax, nbmax))) return rc;
     const int64_t nk = dp->hp.kmax - dp->hp.kmin;
+    hpfw::CqPlanDev cq = dp->cq; // the caller's bins lie in natural order
+    cq.xn1 = 1;
+    cq.xw = 0;
+    cq.xq0 = dp->hp.kmin;
+    cq.xclip = nk;
     for (int64_t c0 = 0; c0 < n_clips; c0 += nbmax) {
         const int nb = (int)std::min<int64_t>(nbmax, n_clips - c0);
         for (const hpfw::CqClassDev &cd : dp->cls) {
             if (cd.outer)
-                hpfw::launch_cq_big_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb, (hpfw::cf *)h->d_cqwork,
+                hpfw::launch_cq_big_class(cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb, (hpfw::cf *)h->d_cqwork,
                                           d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s);
             else
-                hpfw::launch_cq_class(dp->cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb,
+                hpfw::launch_cq_class(cq, cd, (const hpfw::cf *)d_x + c0 * nk, nb,
                                       d_mag + c0 * 121 * dp->hp.c, (float *)h->ws[4], false, s);
         }
         if ((rc = check_launch("cq_chirpz"))) return rc;

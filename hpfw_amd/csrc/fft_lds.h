@@ -243,10 +243,17 @@ HPFW_DEVICE void cq_transform(Lds &lds, const CqTwiddles &tw, int nthreads, int 
 
 // ---- the whole band: window*chirp, forward FFT, times V, inverse FFT, magnitudes ----
 // lds: Size<NP>::DATA complex slots; red: one float per thread (the largest value it stored).
+// xs(i): forward bin start_j + i of the clip (a plain pointer's [] in the emulation, kernels.h XsBand in the kernels:
+// the forward transform leaves the bins in rows k mod n1).
 // fin(m): what is stored for magnitude m -- m itself, or its dB term (monotone in m, so the
 // largest stored value belongs to the largest magnitude either way).
-template <int NP, class Lds, class Red, class Fin>
-HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const cf *__restrict__ xs, const cf *__restrict__ g,
+struct XsPtr {
+    const cf *p;
+    HPFW_DEVICE_MEMBER cf operator()(int i) const { return p[i]; }
+};
+
+template <int NP, class Lds, class Red, class Xs, class Fin>
+HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const Xs &xs, const cf *__restrict__ g,
                               int lg, const CqTwiddles &tw, const cf *__restrict__ vrev, int c,
                               float *__restrict__ out_mag, Fin fin)
 {
@@ -255,7 +262,7 @@ HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const cf *__rest
     const bool prune = lg <= P::N / 4; // the first pass is radix 4 for every admitted length
     HPFW_FOR_THREADS(tid, nthreads)
     {
-        for (int i = tid; i < lg; i += nthreads) lds[pad16(i)] = c_mul(xs[i], g[i]);
+        for (int i = tid; i < lg; i += nthreads) lds[pad16(i)] = c_mul(xs(i), g[i]);
         if (!prune)
             for (int i = lg + tid; i < P::N; i += nthreads) lds[pad16(i)] = {0.0f, 0.0f};
     }

@@ -409,4 +409,84 @@ HPFW_DEVICE void rows_body(Lds &lds, const RowsArgs &a, int nthreads, const i16x
     rows_body_from<Groups>(lds, a, nthreads, PairLoad{pairs, a.pair_stride}, a0, ya, yb);
 }
 
+// ---- S6, the row stage of the forward transform (7-smooth lengths) ------------------------------------------------
+// The column stage (k_forward.hip, fwd_cols_q_kernel) leaves z[q1][k2] = G[q1][k2] T_N[q1 k2], q1 <= n1 / 2.  Row q1:
+// Z = FFT_n2(z[q1]) (S4), X[q1 + n1 q2] = Z[q2], and the bins of row n1 - q1 by X[k] = conj(X[N - k]):
+// X[(n1 - q1) + n1 q2] = conj(Z[n2 - 1 - q2]).  Only q2lo <= q2 < q2lo + q2w holds consumed bins; they are stored as
+// x[row][q2 - q2lo], rows of q2w elements (the constant-Q stage gathers its slices from that layout: kernels.h XsView).
+struct Rows2Out {
+    int n1, hq;      // rows of the column stage: hq = n1 / 2 + 1 computed, n1 in the output
+    int q2lo, q2w;
+    // the twiddles between the stages, T_N[q1 k2] 2^-37, from every fourth one: [hq][nq] seeds T_N[4 q1 m] 2^-37 and
+    // [hq][4] steps T_N[q1 e]; element 4 m + e is seed (e = 0) or seed * step[e] (S1)
+    const cf *seed, *step;
+    int nq;
+};
+
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+
+// zrow: the row's Re values, then its Im values (n2 floats each), the column stage's integers rounded to f32
+template <class Groups, class Lds>
+HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const float *__restrict__ zrow, int q1, const Rows2Out &o,
+                            cf *__restrict__ xclip)
+{
+    const int n2 = Groups::kProduct ? Groups::kProduct : a.n2;
+    HPFW_FOR_THREADS(tid, nthreads)
+    {
+        constexpr int kLd = 4; // loads in batches so that their latencies overlap
+        if ((n2 & 3) == 0) {   // both planes start 16-byte aligned: four elements per pair of loads
+            const f4 *__restrict__ sr = reinterpret_cast<const f4 *>(zrow), *__restrict__ si = reinterpret_cast<const f4 *>(zrow + n2);
+            const cf *__restrict__ seeds = o.seed + (int64_t)q1 * o.nq;
+            const cf s1 = o.step[q1 * 4 + 1], s2 = o.step[q1 * 4 + 2], s3 = o.step[q1 * 4 + 3];
+            const int nq = n2 / 4;
+            for (int t0 = tid; t0 < nq; t0 += kLd * nthreads) {
+                f4 vr[kLd], vi[kLd];
+                cf w0[kLd];
+#pragma unroll
+                for (int e = 0; e < kLd; ++e) {
+                    const int t = t0 + e * nthreads;
+                    vr[e] = sr[t < nq ? t : 0];
+                    vi[e] = si[t < nq ? t : 0];
+                    w0[e] = seeds[t < nq ? t : 0];
+                }
+#pragma unroll
+                for (int e = 0; e < kLd; ++e) {
+                    const int t = t0 + e * nthreads;
+                    if (t < nq) {
+                        lds[4 * t] = c_mul(cf{vr[e].x, vi[e].x}, w0[e]);
+                        lds[4 * t + 1] = c_mul(cf{vr[e].y, vi[e].y}, c_mul(w0[e], s1));
+                        lds[4 * t + 2] = c_mul(cf{vr[e].z, vi[e].z}, c_mul(w0[e], s2));
+                        lds[4 * t + 3] = c_mul(cf{vr[e].w, vi[e].w}, c_mul(w0[e], s3));
+                    }
+                }
+            }
+        } else {
+            for (int t = tid; t < n2; t += nthreads) {
+                const cf w0 = o.seed[(int64_t)q1 * o.nq + (t >> 2)];
+                lds[t] = c_mul(cf{zrow[t], zrow[n2 + t]}, (t & 3) ? c_mul(w0, o.step[q1 * 4 + (t & 3)]) : w0);
+            }
+        }
+    }
+    HPFW_BARRIER();
+    Groups::run(lds, a, nthreads);
+    const int *__restrict__ pos = a.pos_n2;
+    constexpr bool kNat = Groups::kNatural;
+    const bool mirror_row = q1 >= 1 && o.n1 - q1 >= o.hq; // row n1 - q1 is not computed itself
+    HPFW_FOR_THREADS(tid, nthreads)
+    {
+        for (int i = tid; i < 2 * o.q2w; i += nthreads) {
+            const bool mir = i >= o.q2w;
+            if (mir && !mirror_row) break;
+            const int j = mir ? i - o.q2w : i;
+            const int q2 = o.q2lo + j;
+            const int src = mir ? n2 - 1 - q2 : q2;
+            cf v = lds[kNat ? src : pos[src]];
+            if (mir) v.i = -v.i;
+            xclip[(int64_t)(mir ? o.n1 - q1 : q1) * o.q2w + j] = v;
+        }
+    }
+}
+
 } // namespace hpfw

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(cq_threads(NP), cq_waves(NP)) void cq_kernel(CqPlan
     float *red = reinterpret_cast<float *>(lds + P::DATA); // one float per thread behind the data
     const int j = cc.band[blockIdx.x];
     const int clip = blockIdx.y;
-    const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[j] - cp.kmin);
+    const XsBand xs{cp.view(x, clip), cp.start[j]};
     float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
     cq_band_body<NP>(lds, red, cq_threads(NP), xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
                        [](float m) { return DBT ? db_term(m * m) : m; });

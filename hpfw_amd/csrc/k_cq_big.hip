@@ -47,12 +47,12 @@ __global__ __launch_bounds__(256) void cq_big_dif_kernel(CqBigArgs a, CqPlanDev 
     cf u[4];
     if (FIRST) {
         const int jb = a.band[bi], lg = cp.lg[jb];
-        const cf *xs = x + (int64_t)clip * cp.nk + (cp.start[jb] - cp.kmin);
+        const XsBand xs{cp.view(x, clip), cp.start[jb]};
         const cf *g = cp.g + cp.g_off[jb];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = i0 + q * quarter;
-            u[q] = i < lg ? c_mul(xs[i], g[i]) : cf{0.0f, 0.0f};
+            u[q] = i < lg ? c_mul(xs(i), g[i]) : cf{0.0f, 0.0f};
         }
     } else {
 #pragma unroll

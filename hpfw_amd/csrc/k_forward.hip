@@ -1,294 +1,392 @@
-// k_forward.hip -- a1 + the forward half of a2: int16 PCM -> forward DFT bins [kmin, kmax).
+// k_forward.hip -- a1 + the forward half of a2: int16 PCM -> forward DFT bins [kmin, kmax), for 7-smooth clip lengths.
 //
 // Replaces essentia MonoLoader (PCM16 mono 44.1 kHz case) and the length-N FFT inside essentia
 // NSGConstantQ::compute, called from CQT<>::spectrogram (reference include/hpfw/spectrum/cqt.h:45-52,
-// 66-71).  N = n1 * n2 (n2 = 6300, n1 = 210 for a 30 s clip):
-//   pcm_pairs: coalescing pre-pass.  The clip is an [n2][n1] row-major matrix of samples; residue pair
-//              (2p, 2p+1) is a 4-byte column of it.  A workgroup transposes a tile of 64 time steps
-//              through LDS so that fwd_rows reads its pair stream contiguously.
-//   fwd_rows : one workgroup per pair of residues (a, a+1) mod n1: the two real sequences
-//              x[a + n1 t], x[a+1 + n1 t] ride one complex length-n2 FFT held in LDS (fft_rows.h), are
-//              split by Hermitian symmetry, multiplied by T_N[a k2] and written as planar half spectra.
-//   fwd_cols : the remaining length-n1 DFT, only for the rows k1 that hold consumed bins (about 10 % of
-//              the N/2 bins feed the 121 bands): a dense [4 K1 x 2 n1] . [2 n1 x h] real contraction on
-//              v_mfma_f32_32x32x2_f32.  The MFMA chains its k index in ascending order, which is the
-//              specification's fma chain over residues (Re then Im part of each), bit for bit.
+// 66-71).  N = n1 * n2 (n2 = 6300, n1 = 210 for a 30 s clip); the clip AS IT LIES is an [n1][n2]
+// row-major matrix of samples x[n2 k1 + k2], and the transform runs its column stage first:
+//   fwd_cols_q : G[q1][k2] = sum_k1 wq[(q1 k1) mod n1] pcm[n2 k1 + k2] for the rows q1 <= n1 / 2 (the rest are their
+//                conjugates).  int16 samples times 23-bit fixed-point twiddles: an exact integer sum, so it runs on
+//                v_mfma_i32_32x32x32_i8 as six digit products (samples: two bytes; twiddles: three balanced base-256
+//                digits) -- a dense [2 hq x n1] . [n1 x n2] contraction per clip that needs no summation order.  The
+//                epilogue rounds the integers ONCE to f32.
+//   fwd_rows2  : one workgroup per row q1: times the twiddles between the stages on the way in (formed from every fourth
+//                one, 13 KB per row instead of 50), FFT_n2 in LDS (fft_rows.h), of which only the outputs q2 that hold consumed
+//                bins (a tenth) are stored, for the row itself and, conjugated, for its mirror n1 - q1.
+// Nothing is re-laid-out on the way: the first kernel reads the PCM where the caller put it, the second writes the
+// consumed bins.  (Clip lengths with a prime factor above 7: k_bluestein.hip.)
 #include "kernels.h"
 
 namespace hpfw {
 
 extern __shared__ __align__(16) unsigned char smem_raw[];
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kPairsTileMax = 128; // time steps per tile; fewer when n1 is large (the tile lives in LDS)
+// ---- column stage ---------------------------------------------------------------------------------------------
+// One workgroup = 4 waves = 128 columns k2 of one clip x up to 7 row tiles (224 rows (Re, Im interleaved) = 112 q1);
+// a wave owns 32 columns.  K = k1 in chunks of 224 samples (7 matrix-instruction steps): the samples of the chunk sit
+// in LDS as two byte planes [16 k1][column][16 bytes] -- the transposition the matrix instruction's operand layout asks for (a lane
+// holds 16 consecutive k1 of one column) happens on the way in, with byte permutes -- the twiddle digits of one row
+// tile and chunk (21 KB) next to them.  79 KB of LDS: two workgroups per CU, one's staging and epilogue under the
+// other's matrix instructions.
+//
+// Sample digits: x = 256 hi + lo + 128 with hi = x >> 8 (the high byte as it is) and lo = (x & 255) - 128 (the low
+// byte with its top bit flipped), both in [-128, 127]; the constant 128 adds 128 sum_k1 wq[(q1 k1) mod n1] to every
+// element of row q1, an exact integer the epilogue adds back (ColsQArgs::corr).
+// Digit products of equal weight share an accumulator: c = i + j for sample digit i (0 lo, 1 hi) and twiddle digit j;
+// |acc| <= 2 n1 2^14 < 2^31 for every admitted n1; G = sum_c acc_c 2^(8c) + corr, formed in double (exact), rounded
+// once to f32.
+constexpr int kCqThreads = 256;
+constexpr int kCqCols = 128;                      // columns per workgroup
+constexpr int kCqKSteps = 7;                      // matrix-instruction steps (of 32 samples) per chunk
+constexpr int kCqKChunk = 32 * kCqKSteps;         // 224 samples k1 per chunk
+constexpr int kCqTilesPerGroup = 7;               // row tiles per workgroup
+constexpr int kCqPlaneBytes = kCqCols * kCqKChunk;            // 28 672
+constexpr int kCqABytes = kCqKSteps * 3 * 1024;               // 21 504
+constexpr int kCqLdsBytes = 2 * kCqPlaneBytes + kCqABytes;    // 78 848
 
-// VEC: the tile (nt * n1 samples) is copied in 16-byte pieces -- the launcher checks that every tile
-// starts 16-byte aligned and holds a multiple of 8 samples; otherwise sample by sample.
-// n: samples between consecutive clips; n_valid: samples of a clip that exist (the chirp-z transform pads the
-// [n2][n1] matrix with zeros beyond them: n_valid < n1 n2)
-template <bool VEC>
-__global__ __launch_bounds__(256) void pcm_pairs_kernel(int64_t n, int64_t n_valid, int n1, int n2, int kPairsTile,
-                                                        const int16_t *__restrict__ pcm, i16x2 *__restrict__ pairs)
+// Layout of a plane: [unit j of 16 samples k1][slot of a column][16 bytes], 2 KB per unit.  Inside every block of 32
+// columns the slot is a bit permutation of the column, pi(c) = (c2 ^ c0) | c3 << 1 | c4 << 2 | c1 << 3 | c0 << 4
+// (c_i the bits of c), chosen so that BOTH access patterns are free of bank conflicts: the operand reads (ds_read_b128:
+// the 16 lanes of a group hold columns of one parity class of (c4, c3, c2), which pi sends to 16 different slots mod 16)
+// and the staging writes below (ds_write_b32 from lanes = 8 groups of 4 columns x 4 consecutive sample quads: for a
+// fixed column inside its group pi mod 8 runs through 0..7).
+__device__ __forceinline__ int cq_slot(int c)
 {
-    int16_t *tile = reinterpret_cast<int16_t *>(smem_raw); // [kPairsTile][n1]
-    const int tid = threadIdx.x;
-    const int clip = blockIdx.y;
-    const int t0 = blockIdx.x * kPairsTile;
-    const int nt = min(kPairsTile, n2 - t0);
-    const int np = (n1 + 1) / 2;
-    const int16_t *src = pcm + (int64_t)clip * n + (int64_t)t0 * n1;
-    if (VEC) {
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-        uint4 *t4 = reinterpret_cast<uint4 *>(tile);
-        for (int i = tid; i < nt * n1 / 8; i += 256) t4[i] = s4[i];
-    } else {
-        const int64_t left = n_valid - (int64_t)t0 * n1; // samples of this tile that exist
-        for (int i = tid; i < nt * n1; i += 256) tile[i] = i < left ? src[i] : (int16_t)0;
+    const int l = c & 31;
+    return (c & ~31) | (((l >> 2) ^ l) & 1) | (((l >> 3) & 1) << 1) | (((l >> 4) & 1) << 2) | (((l >> 1) & 1) << 3) | ((l & 1) << 4);
+}
+// byte address of samples k1 = 4 rq .. 4 rq + 3 of column c inside a plane
+__device__ __forceinline__ int cq_b_addr(int c, int rq) { return (rq >> 2) * (kCqCols * 16) + cq_slot(c) * 16 + 4 * (rq & 3); }
+
+// four rows of two columns (one dword per row: [lo0 hi0 lo1 hi1] after the low bytes' top bits were flipped) ->
+// per column and plane one dword of four consecutive k1
+__device__ __forceinline__ void cq_store_pair(unsigned char *planes, int c, int rq, unsigned r0, unsigned r1, unsigned r2, unsigned r3)
+{
+    const unsigned x01 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), x23 = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+    const unsigned y01 = __builtin_amdgcn_perm(r1, r0, 0x07030602u), y23 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+    const int a0 = cq_b_addr(c, rq), a1 = cq_b_addr(c + 1, rq);
+    *reinterpret_cast<unsigned *>(planes + a0) = __builtin_amdgcn_perm(x23, x01, 0x05040100u);                 // lo plane
+    *reinterpret_cast<unsigned *>(planes + kCqPlaneBytes + a0) = __builtin_amdgcn_perm(x23, x01, 0x07060302u); // hi plane
+    *reinterpret_cast<unsigned *>(planes + a1) = __builtin_amdgcn_perm(y23, y01, 0x05040100u);
+    *reinterpret_cast<unsigned *>(planes + kCqPlaneBytes + a1) = __builtin_amdgcn_perm(y23, y01, 0x07060302u);
+}
+
+// The samples of chunk kc (224 k1 x 128 columns) from the PCM as it lies into the two planes.  A lane takes 4 columns
+// x 4 consecutive k1; the 32 lanes of a half wave = 8 column groups (64 contiguous bytes of a row: one sector) x 4
+// sample quads (one unit of 16 k1).  LOADW: samples per global load (4: n2 a multiple of 4 and the PCM 8-byte aligned;
+// 2: n2 even, 4-byte aligned; 1 otherwise).
+template <int LOADW>
+__device__ __forceinline__ void cq_stage_samples(const ColsQArgs &a, const int16_t *__restrict__ clip_pcm, int col0, int kc,
+                                                 unsigned char *planes, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cg = lane & 7, sub = (lane >> 3) & 3, half = lane >> 5;
+    const int row_last = a.n1 - 1;
+    constexpr int kItems = (kCqKChunk / 16) * (kCqCols / 32); // (unit, block of 32 columns) per half wave: 56
+    constexpr int kPer = kItems / 8;                          // 7 per lane
+    // columns past the clip's: any valid address (their results are not stored); a group never straddles the end when
+    // LOADW divides n2
+    const int last = a.n2 - 1;
+    unsigned r[kPer][4][2];
+    // every load of the lane is issued before the first value is used: one memory latency instead of seven
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int it = 2 * wave + half + 8 * u;
+        const int j = it >> 2, blk = it & 3;
+        const int rq = 4 * j + sub;
+        const int gc = col0 + 32 * blk + 4 * cg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = kc * kCqKChunk + 4 * rq + i;
+            if (row > row_last) row = row_last;      // samples past n1 meet zero twiddle digits: any valid address
+            const int16_t *rowp = clip_pcm + (int64_t)row * a.n2;
+            if (LOADW == 4) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(rowp + (gc + 3 <= last ? gc : last - 3));
+                r[u][i][0] = v.x;
+                r[u][i][1] = v.y;
+            } else if (LOADW == 2) {
+                r[u][i][0] = *reinterpret_cast<const unsigned *>(rowp + (gc + 1 <= last ? gc : last - 1));
+                r[u][i][1] = *reinterpret_cast<const unsigned *>(rowp + (gc + 3 <= last ? gc + 2 : last - 1));
+            } else {
+                const int c0 = gc <= last ? gc : last, c1 = gc + 1 <= last ? gc + 1 : last, c2 = gc + 2 <= last ? gc + 2 : last,
+                          c3 = gc + 3 <= last ? gc + 3 : last;
+                r[u][i][0] = (unsigned)(unsigned short)rowp[c0] | ((unsigned)(unsigned short)rowp[c1] << 16);
+                r[u][i][1] = (unsigned)(unsigned short)rowp[c2] | ((unsigned)(unsigned short)rowp[c3] << 16);
+            }
+        }
     }
-    __syncthreads();
-    i16x2 *dst = pairs + (int64_t)clip * np * n2 + t0;
-    const bool even = (n1 & 1) == 0; // then a pair is one aligned 32-bit word of the tile
-    // the tile length is a power of two: a thread keeps its time step and walks the pairs (no division per word)
-    const int lg = 31 - __builtin_clz((unsigned)kPairsTile);
-    const int tt = tid & (kPairsTile - 1), pstep = 256 >> lg;
-    if (pstep >= 1) {
-        if (tt < nt) {
-            const int16_t *row = tile + tt * n1;
-            i16x2 *out = dst + tt;
-            for (int p = tid >> lg; p < np; p += pstep) {
-                i16x2 v;
-                if (even) {
-                    v = *reinterpret_cast<const i16x2 *>(row + 2 * p);
-                } else {
-                    v.x = row[2 * p];
-                    v.y = (2 * p + 1 < n1) ? row[2 * p + 1] : (short)0;
-                }
-                out[(int64_t)p * n2] = v;
-            }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int it = 2 * wave + half + 8 * u;
+        const int j = it >> 2, blk = it & 3;
+        const int rq = 4 * j + sub;
+        const int c = 32 * blk + 4 * cg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[u][i][0] ^= 0x00800080u;               // lo = (x & 255) - 128: the low bytes' top bits flipped
+            r[u][i][1] ^= 0x00800080u;
         }
-    } else { // a tile longer than the workgroup (not produced by the launcher): the general walk
-        for (int i = tid; i < np * kPairsTile; i += 256) {
-            const int p = i >> lg, t2 = i & (kPairsTile - 1);
-            if (t2 < nt) {
-                i16x2 v;
-                v.x = tile[t2 * n1 + 2 * p];
-                v.y = (2 * p + 1 < n1) ? tile[t2 * n1 + 2 * p + 1] : (short)0;
-                dst[(int64_t)p * n2 + t2] = v;
-            }
-        }
+        cq_store_pair(planes, c, rq, r[u][0][0], r[u][1][0], r[u][2][0], r[u][3][0]);
+        cq_store_pair(planes, c + 2, rq, r[u][0][1], r[u][1][1], r[u][2][1], r[u][3][1]);
     }
 }
 
-// one workgroup = one residue pair of one clip; the body (fft_rows.h) is shared with tests/emu.
+// the barriers of the column kernel order LDS traffic only: no wait for the global loads and stores in flight (the next
+// tile's twiddle digits, the epilogue's table values, the previous tile's results), which __syncthreads() would drain
+__device__ __forceinline__ void cq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// z: the stage's output, PLANAR: [clip][q1][Re row, Im row][n2] floats -- with the samples as the matrix instruction's A operand
+// (tile row = column k2) and the twiddle digits as B (tile column = output row), a lane ends up with ONE output row (Re or
+// Im of one q1) and four runs of four consecutive k2: every global access of the epilogue is 16 bytes wide.
+// SMALL: n1 <= 255, the digit-product sums stay below 2^23 and pair up in int32 (acc_0 + 2^8 acc_1, acc_2 + 2^8 acc_3)
+// before the conversion.  HPFW_COLS_STAMPS (diagnostic builds only): cycle stamps per phase, tools/cols_stamps.py.
+#ifdef HPFW_COLS_STAMPS
+#define CQ_STAMP(k) stamp(k)
+#else
+#define CQ_STAMP(k) ((void)0)
+#endif
+
+template <int LOADW, bool SMALL>
+__global__ __launch_bounds__(kCqThreads, 2) void fwd_cols_q_kernel(ColsQArgs a, const int16_t *__restrict__ pcm, int64_t clip_samples,
+                                                                   float *__restrict__ z)
+{
+    unsigned char *planes = smem_raw;                                       // [2 planes][14 units][128 column slots][16 bytes]
+    v4i *abuf = reinterpret_cast<v4i *>(smem_raw + 2 * kCqPlaneBytes);      // [7 steps][3 digits][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, nl = lane & 31;
+    const int clip = blockIdx.x;                 // the fast index: workgroups resident together share a column block, hence
+    const int col0 = blockIdx.y * kCqCols;       // the same slices of the twiddle tables in L2
+    const int mt0 = blockIdx.z * kCqTilesPerGroup;
+    const int mt1 = min(a.mt, mt0 + kCqTilesPerGroup);
+    const int n_chunks = (a.ks + kCqKSteps - 1) / kCqKSteps;
+    const int16_t *clip_pcm = pcm + (int64_t)clip * clip_samples;
+    const v4i *image = static_cast<const v4i *>(a.image);
+    constexpr int kAPer = (kCqABytes / 16 + kCqThreads - 1) / kCqThreads; // 6 pieces of 16 bytes per thread (the last partly)
+    v4i areg[kAPer];
+    auto load_a = [&](int mt, int kc) {          // the twiddle digits of (row tile, chunk): global -> registers
+        const int steps = min(kCqKSteps, a.ks - kc * kCqKSteps);
+        const v4i *src = image + ((int64_t)mt * a.ks + kc * kCqKSteps) * 3 * 64;
+#pragma unroll
+        for (int e = 0; e < kAPer; ++e) {
+            const int i = tid + e * kCqThreads;
+            areg[e] = i < steps * 3 * 64 ? src[i] : v4i{0, 0, 0, 0};
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int e = 0; e < kAPer; ++e) {
+            const int i = tid + e * kCqThreads;
+            if (i < kCqABytes / 16) abuf[i] = areg[e];
+        }
+    };
+#ifdef HPFW_COLS_STAMPS
+    long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int k) {
+        const long long t = __builtin_amdgcn_s_memtime();
+        st[k] += t - tprev;
+        tprev = t;
+    };
+#endif
+    load_a(mt0, 0);
+    if (n_chunks == 1) cq_stage_samples<LOADW>(a, clip_pcm, col0, 0, planes, tid); // the usual case: staged once per workgroup
+    CQ_STAMP(0);
+    const int s_base = cq_slot(wave * 32 + nl) * 16; // A operand: this lane's column (tile row) inside the block
+    const int cbase = col0 + wave * 32 + 4 * h;      // D: registers 4 g .. 4 g + 3 are columns cbase + 8 g + (0..3), tile column = lane & 31
+    const bool vec4 = (a.n2 & 3) == 0;               // then the rows of z and of the twiddle planes start 16-byte aligned
+    for (int mt = mt0; mt < mt1; ++mt) {
+        // this lane's output row, and what the epilogue adds
+        const int row = 32 * mt + nl, q1 = row >> 1;
+        const bool live = q1 < a.hq;
+        const double corr = a.corr[2 * (live ? q1 : a.hq - 1) + (row & 1)];
+        CQ_STAMP(1);
+        v16i acc[4];
+        for (int kc = 0; kc < n_chunks; ++kc) {
+            cq_lds_barrier();                    // everybody has read the previous twiddle digits (and sample planes)
+            CQ_STAMP(2);
+            if (n_chunks > 1) cq_stage_samples<LOADW>(a, clip_pcm, col0, kc, planes, tid);
+            store_a();
+            CQ_STAMP(3);
+            cq_lds_barrier();
+            CQ_STAMP(4);
+            {                                    // the next (tile, chunk)'s digits are on their way during the products
+                int nmt = mt, nkc = kc + 1;
+                if (nkc == n_chunks) {
+                    nkc = 0;
+                    ++nmt;
+                }
+                if (nmt < mt1) load_a(nmt, nkc);
+            }
+            const int steps = min(kCqKSteps, a.ks - kc * kCqKSteps);
+            // operands of step s + 1 are read while the products of step s run: two register sets in turn
+            v4i w[2][3], x[2][2];
+            auto fetch = [&](int set, int s) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) w[set][d] = abuf[(s * 3 + d) * 64 + lane];
+                const int off = s_base + (2 * s + h) * (kCqCols * 16);
+                x[set][0] = *reinterpret_cast<const v4i *>(planes + off);
+                x[set][1] = *reinterpret_cast<const v4i *>(planes + kCqPlaneBytes + off);
+            };
+            auto mult = [&](int set, bool first) {
+                // sample digit i (0 lo, 1 hi) times twiddle digit j goes to accumulator i + j; the very first products of a
+                // tile start from the instruction's zero operand instead of a cleared register
+                const v16i zero = v16i{0};
+                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[set][0], w[set][0], first ? zero : acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[set][0], w[set][1], first ? zero : acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[set][0], w[set][2], first ? zero : acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[set][1], w[set][2], first ? zero : acc[3], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[set][1], w[set][0], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[set][1], w[set][1], acc[2], 0, 0, 0);
+            };
+            fetch(0, 0);
+            if (steps > 1) fetch(1, 1);
+            if (kc == 0) mult(0, true); else mult(0, false);
+#pragma unroll 1
+            for (int s = 1; s + 1 < steps; s += 2) {
+                fetch(0, s + 1);
+                mult(1, false);
+                if (s + 2 < steps) fetch(1, s + 2);
+                mult(0, false);
+            }
+            if ((steps & 1) == 0) mult(1, false);
+            CQ_STAMP(5);
+        }
+        // D[tile row = column][tile column = output row]: this lane holds output row `row`, register r = column
+        // cbase + 8 (r >> 2) + (r & 3).  G = sum_c acc_c 2^(8c) + corr, every term and partial sum exact in double; rounded once.
+        float gm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double g;
+            if (SMALL) {
+                const int lo = acc[0][r] + (acc[1][r] << 8), hi = acc[2][r] + (acc[3][r] << 8); // |.| < 2^31: n1 <= 255
+                g = __builtin_fma((double)hi, 65536.0, (double)lo) + corr;
+            } else {
+                g = corr;
+#pragma unroll
+                for (int c = 3; c >= 0; --c) g = __builtin_fma((double)acc[c][r], (double)(1 << (8 * c)), g);
+            }
+            gm[r] = (float)g;
+        }
+        CQ_STAMP(6);
+        if (live) {
+            float *zrow = z + (((int64_t)clip * a.hq + q1) * 2 + (row & 1)) * a.n2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cbase + 8 * g;
+                if (vec4 && c + 3 < a.n2) {
+                    *reinterpret_cast<float4 *>(zrow + c) = float4{gm[4 * g], gm[4 * g + 1], gm[4 * g + 2], gm[4 * g + 3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < a.n2) zrow[c + e] = gm[4 * g + e];
+                }
+            }
+        }
+        CQ_STAMP(7);
+    }
+#ifdef HPFW_COLS_STAMPS
+    if (a.stamps && tid == 0) {
+        long long *o = a.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = st[k];
+    }
+#endif
+}
+
+#ifdef HPFW_COLS_STAMPS
+long long *g_cols_stamps = nullptr;
+extern "C" long long *hpfw_debug_cols_stamps() { return g_cols_stamps; }
+#endif
+
+// ---- row stage ------------------------------------------------------------------------------------------------
+// one workgroup = one row q1 of one clip; the body (fft_rows.h) is shared with tests/emu.
 // 512 threads x 128 VGPRs and 50 KB of LDS: two workgroups per CU, every pass one butterfly per thread.
 constexpr int kFwdThreads = 512;
 
-// WAVES: waves per SIMD the register allocation is held to (4: two workgroups per CU; 6: three)
 template <class Groups, int WAVES>
-__global__ __launch_bounds__(kFwdThreads, WAVES) void fwd_rows_kernel(RowsArgs a, const i16x2 *__restrict__ pairs,
-                                                                  int64_t clip_pitch, int pair_pitch,
-                                                                  float *__restrict__ yp)
+__global__ __launch_bounds__(kFwdThreads, WAVES) void fwd_rows2_kernel(RowsArgs a, Rows2Out o, const float *__restrict__ z,
+                                                                   cf *__restrict__ x)
 {
     cf *lds = reinterpret_cast<cf *>(smem_raw);
-    // clip is the fast grid index: workgroups resident at the same time then share one residue
-    // pair, so its two rows of the T_N[a k2] table (50 KB of the 5.3 MB) stay in L2 instead of the
-    // whole table cycling through it once per clip
-    const int p = blockIdx.y;
-    const int clip = blockIdx.x;
-    const int a0 = 2 * p;
-    float *ya = yp + ((int64_t)clip * 2 * a.n1 + 2 * a0) * a.hpad;
-    float *yb = (a0 + 1 < a.n1) ? ya + 2 * (int64_t)a.hpad : nullptr;
-    rows_body<Groups>(lds, a, kFwdThreads, pairs + clip * clip_pitch + (int64_t)p * pair_pitch, a0, ya, yb);
+    // clip is the fast grid index: workgroups resident at the same time run the same row, whose butterfly twiddles
+    // they share in L2
+    const int clip = blockIdx.x, q1 = blockIdx.y;
+    rows2_body<Groups>(lds, a, kFwdThreads, z + ((int64_t)clip * o.hq + q1) * 2 * a.n2, q1, o, x + (int64_t)clip * o.n1 * o.q2w);
 }
 
-// ---- column DFT on the matrix cores --------------------------------------------------------
-// D[row][k2] = sum_k A[row][k] B[k][k2], k = 2 a + part: B = planar Y' (row 2a = Re, 2a+1 = Im of
-// residue a); A rows come in (Re, Im) pairs per wanted k1, "complex row" cr:
-//   cr <  K1 : k1 = k1lo + cr           -> X[n2 k1 + k2]
-//   cr >= K1 : k1' = n1 - 1 - k1        -> X[n2 k1 + (n2 - k2)] = conj(.)      (X[k] = conj X[N - k])
-// One wave = one tile of 32 columns x NT row tiles of 32 (16 complex rows each); no LDS, no barriers.
-// kColsStep = MFMA k-steps (residues) per register block, a template argument: the loop runs an even number
-// of blocks, so the launcher picks the step that pads n1 least (n1 = 210: 14 blocks of 15, where 16 pads to 224)
-
-// Operands come through buffer loads: lane part of the address in one VGPR that never changes, the
-// residue step in an SGPR, the row-tile step in the instruction's immediate -- no vector address
-// arithmetic between the MFMAs -- and a residue past n1 (the padded tail of the last block) is
-// out of range of the descriptor and reads as 0.
-__device__ __forceinline__ float cols_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+__global__ __launch_bounds__(256) void gather_bins_kernel(CqPlanDev cp, const cf *__restrict__ x, cf *__restrict__ out)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-
-template <int NT, int kColsStep>
-__global__ __launch_bounds__(256, 2) void fwd_cols_kernel(ColsArgs ca, int tile0, const float *__restrict__ yp,
-                                                          cf *__restrict__ x)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ctile = blockIdx.x * 4 + wave;
     const int clip = blockIdx.y;
-    if (ctile * 32 >= ca.h) return;
-    const int hb = lane >> 5, j = lane & 31;
-    const int64_t clip_floats = (int64_t)2 * ca.n1 * ca.hpad;
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(yp + clip * clip_floats), (short)0, (int)(clip_floats * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(ca.apack), (short)0, ca.n1 * ca.n_tiles * 256, 0x00020000); // [a][tile][lane]
-    const int vb = (hb * ca.hpad + ctile * 32 + j) * 4;
-    const int va = (tile0 * 64 + lane) * 4;
-    const int sb = 2 * ca.hpad * 4;                          // bytes per residue in Y' (Re row, Im row)
-    const int sa = ca.n_tiles * 256;                         // bytes per residue in the coefficient image
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x16{0};
-    float a0[kColsStep][NT], b0[kColsStep], a1[kColsStep][NT], b1[kColsStep];
-    const int nblocks = (ca.n1 + kColsStep - 1) / kColsStep;
-#pragma unroll
-    for (int s = 0; s < kColsStep; ++s) {
-        b0[s] = cols_ld(rb, vb, s * sb);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) a0[s][t] = cols_ld(ra, va + t * 256, s * sa);
-    }
-    // two register sets in turn: the loads of the next block are issued between the MFMAs of this one
-#pragma unroll 1
-    for (int blk = 0; blk < nblocks; blk += 2) {
-        const int r1 = (blk + 1) * kColsStep, r2 = (blk + 2) * kColsStep;
-#pragma unroll
-        for (int s = 0; s < kColsStep; ++s) {
-            b1[s] = cols_ld(rb, vb, (r1 + s) * sb);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) a1[s][t] = cols_ld(ra, va + t * 256, (r1 + s) * sa);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s][t], b0[s], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0); // keep the loads up here: the scheduler would sink them to save registers
-        }
-#pragma unroll
-        for (int s = 0; s < kColsStep; ++s) {
-            b0[s] = cols_ld(rb, vb, (r2 + s) * sb);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) a0[s][t] = cols_ld(ra, va + t * 256, (r2 + s) * sa);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s][t], b1[s], acc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // D layout: column = lane & 31; registers (2q, 2q+1) of a tile are rows 2p, 2p+1 with
-    // p = (q & 1) + 4 (q >> 1) + 2 (lane >> 5): the Re / Im rows of complex row tile * 16 + p
-    const int k2 = ctile * 32 + j;
-    cf *xo = x + (int64_t)clip * (ca.kmax - ca.kmin);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int cr = (tile0 + t) * 16 + (q & 1) + 4 * (q >> 1) + 2 * hb;
-            const float re = acc[t][2 * q], im = acc[t][2 * q + 1];
-            if (cr < ca.k1n) {
-                const int64_t k = (int64_t)ca.n2 * (ca.k1lo + cr) + k2;
-                if (k2 < ca.h && k >= ca.kmin && k < ca.kmax) xo[k - ca.kmin] = {re, im};
-            } else if (cr < 2 * ca.k1n) {
-                const int64_t k = (int64_t)ca.n2 * (ca.k1lo + cr - ca.k1n) + (ca.n2 - k2);
-                if (k2 >= 1 && k2 <= ca.n2 - ca.h && k >= ca.kmin && k < ca.kmax) xo[k - ca.kmin] = {re, -im};
-            }
-        }
-    }
+    const XsView v = cp.view(x, clip);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cp.nk; i += gridDim.x * 256) out[(int64_t)clip * cp.nk + i] = v(cp.kmin + i);
 }
 
-void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s)
+template <int LOADW>
+static void launch_cols_q_t(const ColsQArgs &a, const int16_t *d_pcm, int64_t clip_samples, dim3 grid, float *d_z, hipStream_t s)
 {
-    int kPairsTile = kPairsTileMax;
-    while (kPairsTile > 1 && (size_t)kPairsTile * n1 * sizeof(int16_t) > 60 * 1024) kPairsTile /= 2;
-    dim3 grid((n2 + kPairsTile - 1) / kPairsTile, n_clips);
-    const int tail = n2 % kPairsTile;
-    const bool vec = (reinterpret_cast<uintptr_t>(d_pcm) % 16 == 0) && (n * 2 % 16 == 0) && (kPairsTile * n1 % 8 == 0) &&
-                     (tail * n1 % 8 == 0);
-    const size_t lds = ((size_t)kPairsTile * n1 * sizeof(int16_t) + 15) / 16 * 16;
-    if (vec)
-        hipLaunchKernelGGL(pcm_pairs_kernel<true>, grid, dim3(256), lds, s, n, n, n1, n2, kPairsTile, d_pcm, d_pairs);
+    static PerDeviceOnce attr_set;
+    if (attr_set.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_cols_q_kernel<LOADW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kCqLdsBytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_cols_q_kernel<LOADW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kCqLdsBytes);
+        attr_set.mark();
+    }
+    if (a.n1 <= 255)
+        hipLaunchKernelGGL((fwd_cols_q_kernel<LOADW, true>), grid, dim3(kCqThreads), kCqLdsBytes, s, a, d_pcm, clip_samples, d_z);
     else
-        hipLaunchKernelGGL(pcm_pairs_kernel<false>, grid, dim3(256), lds, s, n, n, n1, n2, kPairsTile, d_pcm, d_pairs);
+        hipLaunchKernelGGL((fwd_cols_q_kernel<LOADW, false>), grid, dim3(kCqThreads), kCqLdsBytes, s, a, d_pcm, clip_samples, d_z);
+}
+
+void launch_fwd_cols_q(const ColsQArgs &a_in, const int16_t *d_pcm, int64_t clip_samples, int n_clips, float *d_z, hipStream_t s)
+{
+    if (n_clips <= 0) return;
+    ColsQArgs a = a_in;
+#ifdef HPFW_COLS_STAMPS
+    static long long *d_stamps = nullptr;
+    if (!d_stamps) (void)hipMalloc(&d_stamps, (size_t)64 * 1024 * 1024);
+    a.stamps = d_stamps;
+    g_cols_stamps = d_stamps;
+#endif
+    dim3 grid(n_clips, (a.n2 + kCqCols - 1) / kCqCols, (a.mt + kCqTilesPerGroup - 1) / kCqTilesPerGroup);
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_pcm);
+    if (a.n2 % 4 == 0 && a.n2 >= 4 && addr % 8 == 0 && clip_samples % 4 == 0)
+        launch_cols_q_t<4>(a, d_pcm, clip_samples, grid, d_z, s);
+    else if (a.n2 % 2 == 0 && addr % 4 == 0 && clip_samples % 2 == 0)
+        launch_cols_q_t<2>(a, d_pcm, clip_samples, grid, d_z, s);
+    else
+        launch_cols_q_t<1>(a, d_pcm, clip_samples, grid, d_z, s);
 }
 
 size_t fwd_rows_lds_bytes(const RowsArgs &a) { return (size_t)a.n2 * sizeof(cf); }
 
 template <class Groups, int WAVES>
-static void launch_rows_t(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, float *d_yp, hipStream_t s)
+static void launch_rows2_t(const RowsArgs &a, const Rows2Out &o, const float *d_z, int n_clips, cf *d_x, hipStream_t s)
 {
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_rows_kernel<Groups, WAVES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_rows2_kernel<Groups, WAVES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set.mark();
     }
-    dim3 grid(n_clips, (a.n1 + 1) / 2);
-    // pre-passed stream: [clip][pair][n2]; in place: pair p of time step t at pcm word t n1/2 + p
-    const int64_t clip_pitch = a.pair_stride == 1 ? (int64_t)((a.n1 + 1) / 2) * a.n2 : (int64_t)a.n1 * a.n2 / 2;
-    const int pair_pitch = a.pair_stride == 1 ? a.n2 : 1;
-    hipLaunchKernelGGL((fwd_rows_kernel<Groups, WAVES>), grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, d_pairs,
-                       clip_pitch, pair_pitch, d_yp);
+    dim3 grid(n_clips, o.hq);
+    hipLaunchKernelGGL((fwd_rows2_kernel<Groups, WAVES>), grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, o, d_z, d_x);
 }
 
-// d_src: the pcm_pairs output when a.pair_stride == 1, otherwise the PCM itself (n1 even: every
-// residue pair is an aligned 4-byte word of the [n2][n1] sample matrix)
-void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_src, int n_clips, float *d_yp, hipStream_t s)
+void launch_fwd_rows2(const RowsArgs &a, const Rows2Out &o, const float *d_z, int n_clips, cf *d_x, hipStream_t s)
 {
+    if (n_clips <= 0) return;
     // the compile-time sequence runs its last two groups one butterfly per thread
-    // 4 waves per SIMD (two workgroups per CU): held to 6 (80 VGPRs, three workgroups) the static kernel measured
-    // slower, 4.42 against 4.17 ms for pairs + rows per 1000 clips
     if (Groups6300::matches_plan(a) && Groups6300::min_threads(a.n2) <= kFwdThreads)
-        launch_rows_t<Groups6300, 4>(a, d_src, n_clips, d_yp, s);
+        launch_rows2_t<Groups6300, 4>(a, o, d_z, n_clips, d_x, s);
     else
-        launch_rows_t<RuntimeGroups, 4>(a, d_src, n_clips, d_yp, s);
+        launch_rows2_t<RuntimeGroups, 4>(a, o, d_z, n_clips, d_x, s);
 }
 
-template <int STEP>
-static void launch_cols_step(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s)
+void launch_gather_bins(const CqPlanDev &cp, const cf *d_x, int n_clips, cf *d_out, hipStream_t s)
 {
-    dim3 grid(((ca.h + 31) / 32 + 3) / 4, n_clips);
-    for (int t0 = 0; t0 < ca.n_tiles; t0 += 3) {
-        const int nt = ca.n_tiles - t0 < 3 ? ca.n_tiles - t0 : 3;
-        if (nt == 3)
-            hipLaunchKernelGGL((fwd_cols_kernel<3, STEP>), grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
-        else if (nt == 2)
-            hipLaunchKernelGGL((fwd_cols_kernel<2, STEP>), grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
-        else
-            hipLaunchKernelGGL((fwd_cols_kernel<1, STEP>), grid, dim3(256), 0, s, ca, t0, d_yp, d_x);
-    }
-}
-
-void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s)
-{
-    auto padded = [&](int step) { return ((ca.n1 + step - 1) / step + 1) / 2 * 2 * step; }; // residues the loop walks
-    int best = 16;
-    for (int step : {15, 14})
-        if (padded(step) < padded(best)) best = step;
-    if (best == 16)
-        launch_cols_step<16>(ca, d_yp, n_clips, d_x, s);
-    else if (best == 15)
-        launch_cols_step<15>(ca, d_yp, n_clips, d_x, s);
-    else
-        launch_cols_step<14>(ca, d_yp, n_clips, d_x, s);
-}
-
-// host: coefficient image of the column DFT for the MFMA A operand, [a][tile][lane]:
-// lane l supplies A[row = 32 tile + (l & 31)][k = 2 a + (l >> 5)]; row 2 cr = Re row, 2 cr + 1 = Im row.
-void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, int n_tiles, float *apack)
-{
-    for (int a = 0; a < n1; ++a)
-        for (int t = 0; t < n_tiles; ++t)
-            for (int l = 0; l < 64; ++l) {
-                const int row = 32 * t + (l & 31), cr = row >> 1, part = l >> 5;
-                float v = 0.0f;
-                if (cr < 2 * k1n) {
-                    const int k1 = cr < k1n ? k1lo + cr : n1 - 1 - (k1lo + cr - k1n);
-                    const int64_t idx = ((int64_t)a * k1) % n1;
-                    const float dr = tw_n1_ri[2 * idx], di = tw_n1_ri[2 * idx + 1];
-                    if ((row & 1) == 0) v = part == 0 ? dr : -di; // Re: fma(dr, yr), fma(-di, yi)
-                    else v = part == 0 ? di : dr;                  // Im: fma(di, yr), fma(dr, yi)
-                }
-                apack[((size_t)a * n_tiles + t) * 64 + l] = v;
-            }
+    if (n_clips <= 0) return;
+    hipLaunchKernelGGL(gather_bins_kernel, dim3((cp.nk + 255) / 256 < 64 ? (cp.nk + 255) / 256 : 64, n_clips), dim3(256), 0, s, cp, d_x, d_out);
 }
 
 } // namespace hpfw

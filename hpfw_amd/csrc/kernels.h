@@ -34,13 +34,35 @@ constexpr int kLag = 80;
 constexpr int kFilters = 64;
 constexpr int kFrame = kBins * kCtx;
 
-// Column DFT (length n1 across residues) on the matrix cores: see k_forward.hip.
-struct ColsArgs {
-    int n1, n2, h, hpad;
-    int kmin, kmax;     // forward bins consumed
-    int k1lo, k1n;      // wanted rows k1lo .. k1lo + k1n - 1 (and their mirrors)
-    int n_tiles;        // row tiles of 32 (16 complex rows each) covering 2 k1n complex rows
-    const float *apack; // coefficient image [n1][n_tiles][64]
+// S6, the column stage of the forward transform on the int8 matrix cores (k_forward.hip): the clip as it lies is an
+// [n1][n2] sample matrix; rows q1 <= n1 / 2 of its length-n1 DFT down the columns, exact integers, rounded once to f32
+// (the row stage multiplies them by the twiddles between the stages on its way in).
+struct ColsQArgs {
+    int n1, n2, hq;      // hq = n1 / 2 + 1 rows
+    int mt, ks;          // 32-row tiles of the (Re, Im) interleaved rows; 32-sample steps of k1
+    const void *image;   // digits of the fixed-point twiddles as the A operand [mt][ks][3][64][16 bytes]
+    const double *corr;  // [2 hq]: what the samples' +128 digit offset adds to every element of a row
+    long long *stamps;   // diagnostic builds (-DHPFW_COLS_STAMPS) only: per workgroup 8 cycle sums
+};
+
+// Where the forward bins of one clip lie: in natural order from bin q0 on (n1 == 1: the chirp-z forward transform, the
+// stage entry points), or as the row stage of S6 leaves them, x[k mod n1][k / n1 - q0] in rows of w elements.
+struct XsView {
+    const cf *base;
+    int n1, w, q0;
+    unsigned long long magic; // ceil(2^40 / n1): k / n1 = (k magic) >> 40 for every k < 2^21, n1 <= 2^13
+    HPFW_DEVICE_MEMBER cf operator()(int k) const
+    {
+        if (n1 == 1) return base[k - q0];
+        const int q2 = (int)(((unsigned long long)(unsigned)k * magic) >> 40);
+        return base[(int64_t)(k - q2 * n1) * w + (q2 - q0)];
+    }
+};
+// the slice of one band: element i is bin start + i
+struct XsBand {
+    XsView v;
+    int start;
+    HPFW_DEVICE_MEMBER cf operator()(int i) const { return v(start + i); }
 };
 
 // Forward transform of a clip length with a prime factor above 7 (k_bluestein.hip): a chirp-z
@@ -76,6 +98,10 @@ struct CqClassDev {
 
 struct CqPlanDev {
     int kmin, nk;       // first forward bin, number of bins per clip
+    int xn1, xw, xq0;   // layout of the forward bins (XsView); set per call
+    int64_t xclip;      // elements per clip
+    unsigned long long xmagic;
+    HPFW_DEVICE_MEMBER XsView view(const cf *x, int clip) const { return XsView{x + (int64_t)clip * xclip, xn1, xw, xq0, xmagic}; }
     int c;              // spectrogram columns
     const int *start;   // slice start (absolute bin)   [121]
     const int *lg;      // window length                [121]
@@ -83,14 +109,13 @@ struct CqPlanDev {
     const cf *g;        // window * chirp / (M P)       [sum lg]
 };
 
-// coalescing pre-pass: pcm [n_clips][n2][n1] -> pairs [n_clips][(n1+1)/2][n2] (two residues per word)
-void launch_pcm_pairs(int64_t n, int n1, int n2, const int16_t *d_pcm, int n_clips, i16x2 *d_pairs, hipStream_t s);
-// a1 + forward FFT of residue pairs: pairs -> planar yp [n_clips][2 n1][hpad] (twiddled half spectra, Re and Im rows)
-void launch_fwd_rows(const RowsArgs &a, const i16x2 *d_pairs, int n_clips, float *d_yp, hipStream_t s);
+// S6 column stage: pcm [n_clips][n1][n2] (clips `clip_samples` apart) -> z [n_clips][hq][Re row, Im row][n2]
+void launch_fwd_cols_q(const ColsQArgs &a, const int16_t *d_pcm, int64_t clip_samples, int n_clips, float *d_z, hipStream_t s);
+// S6 row stage: z -> x [n_clips][n1][q2w] (XsView layout)
 size_t fwd_rows_lds_bytes(const RowsArgs &a);
-// length-n1 DFT across residues on f32 MFMA: planar yp [n_clips][2 n1][hpad] -> x [n_clips][kmax-kmin]
-void launch_fwd_cols(const ColsArgs &ca, const float *d_yp, int n_clips, cf *d_x, hipStream_t s);
-void pack_cols_coefficients(int n1, int k1lo, int k1n, const float *tw_n1_ri, int n_tiles, float *apack);
+void launch_fwd_rows2(const RowsArgs &a, const Rows2Out &o, const float *d_z, int n_clips, cf *d_x, hipStream_t s);
+// the bins [kmin, kmax) in natural order out of either layout (stage entry point)
+void launch_gather_bins(const CqPlanDev &cp, const cf *d_x, int n_clips, cf *d_out, hipStream_t s);
 // chirp-z forward transform (k_bluestein.hip): pcm -> G' -> H' -> x; the planar buffers hold bz_plane_bytes(bz, n_clips) each
 size_t bz_plane_bytes(const BzArgs &bz, int n_clips);
 // coefficient images of the first transform's two column stages (apack1, apack3), from T_n1 on the device

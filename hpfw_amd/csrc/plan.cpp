@@ -370,9 +370,57 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
         }
     }
     if (!p.bluestein) { // the chirp-z path's own tables (chirp, T_L, Bhat, w[k] / L) are generated on the device
-        p.tw_big.resize((size_t)n1 * p.h);
-        parallel_rows(n1, [&](int64_t a) {
-            for (int64_t k2 = 0; k2 < p.h; ++k2) p.tw_big[(size_t)(a * p.h + k2)] = twiddle_f(a * k2, n);
+        // S6: fixed-point twiddles of the column stage, their digits as the int8 matrix instruction's A operand, the
+        // correction for the samples' digit offset, and the twiddles between the stages
+        const int64_t hq = n1 / 2 + 1;
+        p.hq = (int)hq;
+        p.q2lo = (int)(kmin / n1);
+        p.q2w = (int)((kmax - 1) / n1) - p.q2lo + 1;
+        p.cols_mt = (int)((2 * hq + 31) / 32);
+        p.cols_ks = (int)((n1 + 31) / 32);
+        p.wq.resize((size_t)2 * n1);
+        for (int64_t m = 0; m < n1; ++m) {
+            double c, s;
+            twiddle_d(m, n1, c, s);
+            p.wq[(size_t)(2 * m)] = (int32_t)std::rint(c * 4194304.0);
+            p.wq[(size_t)(2 * m + 1)] = (int32_t)std::rint(s * 4194304.0);
+        }
+        p.cols_corr.assign((size_t)2 * hq, 0.0);
+        for (int64_t q1 = 0; q1 < hq; ++q1) {
+            int64_t sr = 0, si = 0;
+            for (int64_t k1 = 0; k1 < n1; ++k1) {
+                sr += p.wq[(size_t)(2 * ((q1 * k1) % n1))];
+                si += p.wq[(size_t)(2 * ((q1 * k1) % n1) + 1)];
+            }
+            p.cols_corr[(size_t)(2 * q1)] = (double)(128 * sr); // |.| < 2^43: exact
+            p.cols_corr[(size_t)(2 * q1 + 1)] = (double)(128 * si);
+        }
+        // image [tile][step][digit][lane][16]: byte e of lane l = digit of W[row = 32 tile + (l & 31)][k1 = 32 step + 16 (l >> 5) + e],
+        // W[2 q1] = Re wq[(q1 k1) mod n1], W[2 q1 + 1] = Im; zero beyond the hq rows and the n1 samples
+        p.cols_image.assign((size_t)p.cols_mt * p.cols_ks * 3 * 1024, 0);
+        parallel_rows(p.cols_mt, [&](int64_t mt) {
+            for (int64_t ks = 0; ks < p.cols_ks; ++ks)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 16; ++e) {
+                        const int64_t row = 32 * mt + (l & 31), k1 = 32 * ks + 16 * (l >> 5) + e, q1 = row >> 1;
+                        if (q1 >= hq || k1 >= n1) continue;
+                        const int w = p.wq[(size_t)(2 * ((q1 * k1) % n1) + (row & 1))];
+                        const int d0 = ((w + 128) & 255) - 128, w1 = (w - d0) >> 8, d1 = ((w1 + 128) & 255) - 128, d2 = (w1 - d1) >> 8;
+                        const int d[3] = {d0, d1, d2};
+                        for (int i = 0; i < 3; ++i)
+                            p.cols_image[((((size_t)mt * p.cols_ks + ks) * 3 + i) * 64 + l) * 16 + e] = (int8_t)d[i];
+                    }
+        });
+        const int64_t nq = (n2 + 3) / 4;
+        p.ts_seed.resize((size_t)(hq * nq));
+        p.ts_step.resize((size_t)(hq * 4));
+        parallel_rows(hq, [&](int64_t q1) {
+            for (int64_t m = 0; m < nq; ++m) {
+                const HostCf t = twiddle_f((q1 * 4 * m) % n, n);
+                p.ts_seed[(size_t)(q1 * nq + m)] = {std::ldexp(t.r, -37), std::ldexp(t.i, -37)};
+            }
+            p.ts_step[(size_t)(q1 * 4)] = {1.0f, 0.0f};
+            for (int e = 1; e < 4; ++e) p.ts_step[(size_t)(q1 * 4 + e)] = twiddle_f((q1 * e) % n, n);
         });
     }
     p.pos_n2.resize((size_t)n2);
@@ -633,9 +681,25 @@ extern "C" int hpfw_gpu_plan_checksum_ex(int64_t n_samples, int force_bluestein,
     if (!out8 || conventions > hpfw::kConvAll || !hpfw::build_plan(n_samples, p, why, false, force_bluestein != 0, conventions)) return -2;
     out8[0] = fnv1a(p.tw_n2.data(), p.tw_n2.size() * 8);
     out8[1] = fnv1a(p.tw_n1.data(), p.tw_n1.size() * 8);
-    out8[2] = fnv1a(p.tw_big.data(), p.tw_big.size() * 8);
-    // chirp-z lengths: no T_N (slot 2 = the hash of nothing); the tables that stand in its place are generated on the
-    // device and checked there (hpfw_gpu_chirpz_table_checksums)
+    {   // the full table as the row stage forms it (S1 product of seed and step), row by row: the oracle's table
+        uint64_t ht = 1469598103934665603ull;
+        const int64_t nq = (p.n2 + 3) / 4;
+        for (int64_t q1 = 0; q1 < p.hq; ++q1)
+            for (int64_t k2 = 0; k2 < p.n2; ++k2) {
+                const hpfw::HostCf a = p.ts_seed[(size_t)(q1 * nq + k2 / 4)], w = p.ts_step[(size_t)(q1 * 4 + (k2 & 3))];
+                float pair[2] = {a.r, a.i};
+                if (k2 & 3) {
+                    const float pp = a.i * w.i, qq = a.i * w.r;
+                    pair[0] = __builtin_fmaf(a.r, w.r, -pp);
+                    pair[1] = __builtin_fmaf(a.r, w.i, qq);
+                }
+                ht = fnv1a(pair, 8, ht);
+            }
+        out8[2] = fnv1a(p.wq.data(), p.wq.size() * 4, ht);
+    }
+    // (the twiddles between the two stages, then the column stage's fixed-point twiddles.)  chirp-z lengths: neither
+    // (slot 2 = the hash of nothing); the tables that stand in their place are generated on the device and checked there
+    // (hpfw_gpu_chirpz_table_checksums)
     out8[3] = fnv1a(p.pos_n2.data(), p.pos_n2.size() * 4);
     uint64_t h = fnv1a(p.start, sizeof(p.start));
     h = fnv1a(p.lg, sizeof(p.lg), h);

@@ -36,7 +36,19 @@ struct HostPlan {
     std::vector<std::pair<int, int>> groups; // the same passes, fused in pairs (second = 1: single pass)
     std::vector<HostCf> rows_gtw;           // per-butterfly twiddles of every group, [entry][butterfly]
     std::vector<int> rows_gtw_off;          // start of each group's table in rows_gtw
-    std::vector<HostCf> tw_n2, tw_n1, tw_big;
+    std::vector<HostCf> tw_n2, tw_n1;
+    std::vector<HostCf> tw_big;             // the STFT of the Mel front-end only (build_frame_transform): rows of ones
+    // S6, column stage first (7-smooth lengths): the clip as it lies is an [n1][n2] sample matrix
+    int hq = 0;                             // rows q1 = 0 .. n1 / 2 of the column stage (the rest follow by conjugation)
+    int q2lo = 0, q2w = 0;                  // outputs q2lo .. q2lo + q2w - 1 of every row transform hold consumed bins
+    int cols_mt = 0, cols_ks = 0;           // 32-row tiles of the (Re, Im) interleaved rows; 32-sample steps of k1
+    std::vector<int32_t> wq;                // [n1][2]: rint(2^22 T_n1[m])
+    std::vector<int8_t> cols_image;         // digits of wq as the matrix instruction's A operand (k_forward.hip)
+    std::vector<double> cols_corr;          // [2 hq]: 128 sum_k1 wq[(q1 k1) mod n1] (Re, Im): the samples' +128 digit offset
+    // the twiddles between the stages, T_N[q1 k2] 2^-37, are formed by the row stage from every fourth one:
+    // ts[q1][4 m + e] = ts_seed[q1][m] (e = 0), ts_seed[q1][m] * ts_step[q1][e] (S1; e = 1, 2, 3)
+    std::vector<HostCf> ts_seed;            // [hq][ceil(n2 / 4)]: T_N[4 q1 m] 2^-37
+    std::vector<HostCf> ts_step;            // [hq][4]: T_N[q1 e] (entry 0 unused)
     std::vector<int> pos_n2;
     std::vector<int> kb_last;               // last group's block b holds outputs kb_last[b] + (n2 / len) f
     int start[121], lg[121], psize[121];

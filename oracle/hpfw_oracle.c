@@ -318,7 +318,10 @@ struct hpfw_oracle_plan {
     int32_t start[HPFW_O_BINS], lg[HPFW_O_BINS], psize[HPFW_O_BINS], cls[HPFW_O_BINS];
     cf *tw_n2;       /* T_{n2}                                    */
     cf *tw_n1;       /* T_{n1}                                    */
-    cf *tw_big;      /* [n1][h] : T_N[n1 * k2]                    */
+    int32_t *wq;     /* [n1][2]: rint(2^22 T_{n1}[m]) -- the column stage's fixed-point twiddles (S6) */
+    cf *ts;          /* [n1 / 2 + 1][n2]: the twiddles between the stages, T_N[q1 k2] 2^-37 (the scale of wq and of pcm / 32768
+                      * folded in: a power of two, exact) FORMED AS THE ROW STAGE FORMS THEM, from every fourth one:
+                      * ts[q1][4 m] = T_N[4 q1 m] 2^-37, ts[q1][4 m + e] = ts[q1][4 m] * T_N[q1 e] (S1), e = 1, 2, 3     */
     int32_t *pos_n2; /* digit-reversed position of output k2       */
     cf *g[HPFW_O_BINS]; /* window * chirp / (M * P), length lg[j]  */
     int n_cls;
@@ -760,11 +763,25 @@ hpfw_oracle_plan *hpfw_oracle_plan_create3(int64_t n, int force_bluestein, unsig
     }
     p->tw_n2 = make_twiddle_table(n2);
     p->tw_n1 = make_twiddle_table(n1);
-    p->tw_big = (cf *)malloc(sizeof(cf) * (size_t)(n1 * p->info.h));
-    for (int64_t a = 0; a < n1; ++a)
-        for (int64_t k2 = 0; k2 < p->info.h; ++k2)
-            hpfw_oracle_twiddle(a * k2, n, &p->tw_big[a * p->info.h + k2].r,
-                                &p->tw_big[a * p->info.h + k2].i);
+    p->wq = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)n1);
+    for (int64_t m = 0; m < n1; ++m) {
+        double c, s;
+        twiddle_d(m, n1, &c, &s);
+        p->wq[2 * m] = (int32_t)rint(c * 4194304.0);
+        p->wq[2 * m + 1] = (int32_t)rint(s * 4194304.0);
+    }
+    const int64_t hq = n1 / 2 + 1;
+    p->ts = (cf *)malloc(sizeof(cf) * (size_t)(hq * n2));
+    for (int64_t q1 = 0; q1 < hq; ++q1) {
+        cf step[4];
+        for (int e = 1; e < 4; ++e) hpfw_oracle_twiddle((q1 * e) % n, n, &step[e].r, &step[e].i);
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            float re, im;
+            hpfw_oracle_twiddle((q1 * (k2 & ~(int64_t)3)) % n, n, &re, &im);
+            cf seed = {ldexpf(re, -37), ldexpf(im, -37)};
+            p->ts[q1 * n2 + k2] = (k2 & 3) ? c_mul(seed, step[k2 & 3]) : seed;
+        }
+    }
     p->pos_n2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)n2);
     for (int64_t k = 0; k < n2; ++k)
         p->pos_n2[k] = (int32_t)hpfw_oracle_digit_pos(k, n2, p->info.radix, p->info.n_radix);
@@ -782,7 +799,8 @@ void hpfw_oracle_plan_destroy(hpfw_oracle_plan *p)
     if (!p) return;
     free(p->tw_n2);
     free(p->tw_n1);
-    free(p->tw_big);
+    free(p->wq);
+    free(p->ts);
     free(p->pos_n2);
     free(p->bz_w);
     free(p->bz_tl);
@@ -868,47 +886,52 @@ void hpfw_oracle_spectrum(const hpfw_oracle_plan *p, const int16_t *pcm, float *
         spectrum_bluestein(p, pcm, x_ri);
         return;
     }
-    const int64_t n1 = p->info.n1, n2 = p->info.n2, h = p->info.h;
-    cf *yp = (cf *)malloc(sizeof(cf) * (size_t)(n1 * h));
+    /* S6 (7-smooth N = n1 n2): the clip as it lies is an [n1][n2] matrix of samples, x[n2 k1 + k2].
+     *   columns: G[q1][k2] = sum_k1 wq[(q1 k1) mod n1] pcm[n2 k1 + k2], q1 <= n1 / 2 -- int16 samples times 23-bit
+     *            fixed-point twiddles: exact integers (|G| < 2^50), rounded ONCE to f32;
+     *   twiddle: z[k2] = G[q1][k2] ts[q1][k2]                      (S1; ts = T_N[q1 k2] 2^-37 from every fourth one, above)
+     *   rows:    Z = FFT_n2(z) (S4), X[q1 + n1 q2] = Z[q2]; bins of the rows q1 > n1 / 2 by X[k] = conj(X[N - k]):
+     *            X[(n1 - q1) + n1 q2] = conj(Z_q1[n2 - 1 - q2]). */
+    const int64_t n1 = p->info.n1, n2 = p->info.n2, hq = n1 / 2 + 1;
+    const int64_t kmin = p->info.kmin, kmax = p->info.kmax;
+    const int64_t q2lo = kmin / n1, q2hi = (kmax - 1) / n1;
+    int64_t *gr = (int64_t *)malloc(sizeof(int64_t) * (size_t)n2);
+    int64_t *gi = (int64_t *)malloc(sizeof(int64_t) * (size_t)n2);
     cf *z = (cf *)malloc(sizeof(cf) * (size_t)n2);
-    for (int64_t a = 0; a < n1; a += 2) {
-        int has_b = (a + 1 < n1);
-        for (int64_t t = 0; t < n2; ++t) {
-            z[t].r = (float)pcm[a + n1 * t] / 32768.0f;
-            z[t].i = has_b ? (float)pcm[a + 1 + n1 * t] / 32768.0f : 0.0f;
+    for (int64_t q1 = 0; q1 < hq; ++q1) {
+        memset(gr, 0, sizeof(int64_t) * (size_t)n2);
+        memset(gi, 0, sizeof(int64_t) * (size_t)n2);
+        for (int64_t k1 = 0; k1 < n1; ++k1) {
+            const int64_t wr = p->wq[2 * ((q1 * k1) % n1)], wi = p->wq[2 * ((q1 * k1) % n1) + 1];
+            const int16_t *row = pcm + n2 * k1;
+            for (int64_t k2 = 0; k2 < n2; ++k2) {
+                gr[k2] += wr * (int64_t)row[k2];
+                gi[k2] += wi * (int64_t)row[k2];
+            }
+        }
+        for (int64_t k2 = 0; k2 < n2; ++k2) {
+            cf g = {(float)gr[k2], (float)gi[k2]}; /* one rounding to nearest-even of the exact integer */
+            z[k2] = c_mul(g, p->ts[q1 * n2 + k2]);
         }
         fft_dif(z, n2, p->info.radix, p->info.n_radix, p->tw_n2);
-        for (int64_t k2 = 0; k2 < h; ++k2) {
-            cf zk = z[p->pos_n2[k2]];
-            cf zm = z[p->pos_n2[(n2 - k2) % n2]];
-            cf ya = {0.5f * (zk.r + zm.r), 0.5f * (zk.i - zm.i)};
-            cf yb = {0.5f * (zk.i + zm.i), 0.5f * (zm.r - zk.r)};
-            yp[a * h + k2] = c_mul(ya, p->tw_big[a * h + k2]);
-            if (has_b) yp[(a + 1) * h + k2] = c_mul(yb, p->tw_big[(a + 1) * h + k2]);
+        for (int64_t q2 = q2lo; q2 <= q2hi; ++q2) {
+            const int64_t k = q1 + n1 * q2;
+            if (k >= kmin && k < kmax) {
+                cf v = z[p->pos_n2[q2]];
+                x_ri[2 * (k - kmin)] = v.r;
+                x_ri[2 * (k - kmin) + 1] = v.i;
+            }
+            const int64_t km = (n1 - q1) + n1 * q2; /* the mirrored row, where it is not computed itself */
+            if (q1 >= 1 && n1 - q1 >= hq && km >= kmin && km < kmax) {
+                cf v = z[p->pos_n2[n2 - 1 - q2]];
+                x_ri[2 * (km - kmin)] = v.r;
+                x_ri[2 * (km - kmin) + 1] = -v.i;
+            }
         }
-    }
-    for (int64_t k = p->info.kmin; k < p->info.kmax; ++k) {
-        int64_t k1 = k / n2, k2 = k % n2;
-        int conj = 0;
-        if (k2 >= h) { /* X[k] = conj(X[N - k]) */
-            k1 = n1 - 1 - k1;
-            k2 = n2 - k2;
-            conj = 1;
-        }
-        float ar = 0.0f, ai = 0.0f;
-        for (int64_t a = 0; a < n1; ++a) {
-            cf d = p->tw_n1[(a * k1) % n1];
-            cf y = yp[a * h + k2];
-            ar = fmaf(d.r, y.r, ar);
-            ar = fmaf(-d.i, y.i, ar);
-            ai = fmaf(d.i, y.r, ai);
-            ai = fmaf(d.r, y.i, ai);
-        }
-        x_ri[2 * (k - p->info.kmin)] = ar;
-        x_ri[2 * (k - p->info.kmin) + 1] = conj ? -ai : ai;
     }
     free(z);
-    free(yp);
+    free(gi);
+    free(gr);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1578,7 +1601,7 @@ void hpfw_oracle_plan_checksum(const hpfw_oracle_plan *p, uint64_t *out8)
     const uint64_t seed = 1469598103934665603ULL;
     out8[0] = fnv1a(p->tw_n2, (size_t)p->info.n2 * 8, seed);
     out8[1] = fnv1a(p->tw_n1, (size_t)p->info.n1 * 8, seed);
-    out8[2] = p->tw_big ? fnv1a(p->tw_big, (size_t)(p->info.n1 * p->info.h) * 8, seed) : seed;
+    out8[2] = p->ts ? fnv1a(p->wq, (size_t)p->info.n1 * 8, fnv1a(p->ts, (size_t)((p->info.n1 / 2 + 1) * p->info.n2) * 8, seed)) : seed;
     out8[3] = fnv1a(p->pos_n2, (size_t)p->info.n2 * 4, seed);
     uint64_t h = fnv1a(p->start, sizeof(p->start), seed);
     h = fnv1a(p->lg, sizeof(p->lg), h);

@@ -42,7 +42,7 @@ static void run_band(const hpfw::HostPlan &hp, const hpfw::BluesteinClass &bc, i
     Checked<cf> lds{lds_mem.data(), lds_mem.size()};
     std::vector<float> red_mem(nt);
     Checked<float> red{red_mem.data(), red_mem.size()};
-    const cf *xs = x + (hp.start[j] - hp.kmin);
+    const hpfw::XsPtr xs{x + (hp.start[j] - hp.kmin)};
     const cf *g = reinterpret_cast<const cf *>(hp.g.data()) + hp.g_off[j];
     hpfw::CqTwiddles tw;
     tw.tab = reinterpret_cast<const cf *>(bc.gtw.data());

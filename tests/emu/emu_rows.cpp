@@ -1,6 +1,8 @@
-// emu_rows.cpp -- host-side SIMT emulation of the forward row-transform kernel body (tests only):
-// hpfw_amd/csrc/fft_rows.h compiled with -DHPFW_SIMT_EMU, every residue pair of one clip, then
-// the length-n1 DFT of the specification on the host, compared with the oracle's forward bins.
+// emu_rows.cpp -- host-side SIMT emulation of the forward transform's row stage (tests only):
+// hpfw_amd/csrc/fft_rows.h compiled with -DHPFW_SIMT_EMU.  The column stage of S6 (exact integer sums, one rounding,
+// the plan's fixed-point twiddles wq) is evaluated here; every row then goes through
+// rows2_body -- load times the twiddles between the stages, FFT_n2 in (bounds-checked) LDS, the pruned stores of the row and of its mirror -- and the bins
+// gathered out of the rows layout are compared with the oracle's forward bins.
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -45,6 +47,8 @@ int main(int argc, char **argv)
         pcm[i] = (int16_t)(9000.0 * std::sin(6.2831853 * 523.25 * t) + 6000.0 * std::sin(6.2831853 * 2093.0 * t + 1.0) +
                            2000.0 * ((double)(s >> 8) / 8388608.0 - 1.0));
     }
+    pcm[0] = 32767; // the ends of the sample range go through the digit split of the column stage (GPU) and through this sum alike
+    pcm[1] = -32768;
     hpfw::RowsArgs a;
     a.n1 = hp.n1;
     a.n2 = hp.n2;
@@ -58,49 +62,39 @@ int main(int argc, char **argv)
         a.groups.r2[g] = hp.groups[g].second;
     }
     a.gtw = reinterpret_cast<const cf *>(hp.rows_gtw.data());
-    a.tw_big = reinterpret_cast<const cf *>(hp.tw_big.data());
+    a.tw_big = nullptr;
     a.pos_n2 = hp.pos_n2.data();
     a.kb_last = hp.kb_last.data();
-    std::vector<float> yp((size_t)2 * hp.n1 * a.hpad, NAN);
+    const hpfw::Rows2Out o{hp.n1, hp.hq, hp.q2lo, hp.q2w, reinterpret_cast<const cf *>(hp.ts_seed.data()),
+                           reinterpret_cast<const cf *>(hp.ts_step.data()), (hp.n2 + 3) / 4};
+    std::vector<cf> x((size_t)hp.n1 * hp.q2w, cf{NAN, NAN});
     const size_t lds_n = (size_t)hp.n2;
-    for (int a0 = 0; a0 < hp.n1; a0 += 2) {
-        std::vector<hpfw::i16x2> pairs(hp.n2);
-        for (int t = 0; t < hp.n2; ++t) {
-            pairs[t].x = pcm[a0 + (long)hp.n1 * t];
-            pairs[t].y = (a0 + 1 < hp.n1) ? pcm[a0 + 1 + (long)hp.n1 * t] : 0;
+    std::vector<float> z((size_t)2 * hp.n2); // Re row, Im row
+    for (int q1 = 0; q1 < hp.hq; ++q1) {
+        for (int k2 = 0; k2 < hp.n2; ++k2) { // S6 column stage, as the plan's tables state it
+            long long gr = 0, gi = 0;
+            for (int k1 = 0; k1 < hp.n1; ++k1) {
+                const size_t m = (size_t)(((long long)q1 * k1) % hp.n1);
+                gr += (long long)hp.wq[2 * m] * pcm[(size_t)hp.n2 * k1 + k2];
+                gi += (long long)hp.wq[2 * m + 1] * pcm[(size_t)hp.n2 * k1 + k2];
+            }
+            z[(size_t)k2] = (float)gr;               // one rounding of the exact integer
+            z[(size_t)hp.n2 + k2] = (float)gi;
         }
         std::vector<cf> lds_mem(lds_n, cf{NAN, NAN});
         Checked<cf> lds{lds_mem.data(), lds_mem.size()};
-        float *ya = yp.data() + (size_t)2 * a0 * a.hpad;
-        float *yb = (a0 + 1 < hp.n1) ? yp.data() + (size_t)2 * (a0 + 1) * a.hpad : nullptr;
         // alternate between the compile-time group sequence (when it applies) and the run-time one
-        if (hpfw::Groups6300::matches(a.groups, 0, a.groups.n) && (a0 & 2) == 0)
-            hpfw::rows_body<hpfw::Groups6300>(lds, a, nthreads, pairs.data(), a0, ya, yb);
+        if (hpfw::Groups6300::matches(a.groups, 0, a.groups.n) && (q1 & 1) == 0)
+            hpfw::rows2_body<hpfw::Groups6300>(lds, a, nthreads, z.data(), q1, o, x.data());
         else
-            hpfw::rows_body<hpfw::RuntimeGroups>(lds, a, nthreads, pairs.data(), a0, ya, yb);
+            hpfw::rows2_body<hpfw::RuntimeGroups>(lds, a, nthreads, z.data(), q1, o, x.data());
     }
-    // S6: X[n2 k1 + k2] = sum_a T_n1[a k1] Y'[a][k2]
     const long nk = hp.kmax - hp.kmin;
     std::vector<float> got(2 * nk), ref(2 * nk);
-    for (long k = hp.kmin; k < hp.kmax; ++k) {
-        long k1 = k / hp.n2, k2 = k % hp.n2;
-        bool conj = false;
-        if (k2 >= hp.h) {
-            k1 = hp.n1 - 1 - k1;
-            k2 = hp.n2 - k2;
-            conj = true;
-        }
-        float ar = 0.f, ai = 0.f;
-        for (long aa = 0; aa < hp.n1; ++aa) {
-            const hpfw::HostCf d = hp.tw_n1[(size_t)((aa * k1) % hp.n1)];
-            const cf y = {yp[(size_t)(2 * aa) * a.hpad + k2], yp[(size_t)(2 * aa + 1) * a.hpad + k2]};
-            ar = __builtin_fmaf(d.r, y.r, ar);
-            ar = __builtin_fmaf(-d.i, y.i, ar);
-            ai = __builtin_fmaf(d.i, y.r, ai);
-            ai = __builtin_fmaf(d.r, y.i, ai);
-        }
-        got[2 * (k - hp.kmin)] = ar;
-        got[2 * (k - hp.kmin) + 1] = conj ? -ai : ai;
+    for (long k = hp.kmin; k < hp.kmax; ++k) { // the bins out of the rows layout: x[k mod n1][k / n1 - q2lo]
+        const cf v = x[(size_t)(k % hp.n1) * hp.q2w + (size_t)(k / hp.n1 - hp.q2lo)];
+        got[2 * (k - hp.kmin)] = v.r;
+        got[2 * (k - hp.kmin) + 1] = v.i;
     }
     hpfw_oracle_plan *op = hpfw_oracle_plan_create(n);
     hpfw_oracle_spectrum(op, pcm.data(), ref.data());

@@ -38,7 +38,7 @@ def emu_rows(tmp_path_factory):
     return str(exe)
 
 
-@pytest.mark.parametrize("n,threads", [(132300, 512), (220500, 448), (154350, 512)])
+@pytest.mark.parametrize("n,threads", [(132300, 512), (220500, 448), (154350, 512), (1323000, 512)])
 def test_row_transform_body_matches_oracle(emu_rows, n, threads):
     """forward row FFT + Hermitian split (fft_rows.h): the compile-time group sequence with its
     transposed last two groups on even residue pairs, the run-time sequence on the others"""

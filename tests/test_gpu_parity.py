@@ -85,8 +85,11 @@ def test_stages_bit_exact(gpu, torch_cuda, oracle, filters, seconds):
     assert np.array_equal(hp_gpu, hp_ref)
     # whole chain, host entry point
     hp_all = gpu.extract(clips)
-    assert np.array_equal(hp_all, hp_ref)
     assert np.array_equal(hp_all, np.stack([plan.extract(filters, c) for c in clips]))
+    # (extraction's default projection is the fixed-point one: against the f32 chain's hashprints above it may differ
+    # where a difference of two projections lies within rounding of zero)
+    flips = sum(bin(int(v)).count("1") for v in (hp_all ^ hp_ref).ravel())
+    assert flips <= 1e-5 * hp_all.size * 64, flips
 
 
 @pytest.mark.parametrize("seconds", [2.0, 4.2, 7.0, 10.0, 12.5, 20.0, 45.0, 49.0, 60.0, 100.0, 180.0])
@@ -126,20 +129,28 @@ def test_mel_front_end(gpu, oracle, seconds):
     assert bits_equal(odd[0], mel.spectrogram(clips[1, :clips.shape[1] - 12345]))
 
 
-def test_rows_in_place_variant(oracle, filters):
-    """HPFW_ROWS_INPLACE=1: the row transform reads the pair words straight from the PCM (no pre-pass);
-    a measured-slower alternative that must give the same bits"""
-    import os
-    clips = np.stack([synth.gen_clip(940 + i, 5.0) for i in range(2)])
-    want = np.stack([oracle.Plan(clips.shape[1]).extract(filters, c) for c in clips])
-    os.environ["HPFW_ROWS_INPLACE"] = "1"
-    try:
-        g = hpfw_amd.Gpu(0)          # the switch is read when the plan of a clip length is built
-        g.set_filters(filters)
-        assert np.array_equal(g.extract(clips), want)
-        g.close()
-    finally:
-        del os.environ["HPFW_ROWS_INPLACE"]
+@pytest.mark.parametrize("n,shift", [(1323000, 0), (1323000, 1), (1323000, 2), (110250, 0), (110250, 1), (99225, 0), (99225, 1),
+                                     (2646000, 0)])
+def test_column_stage_load_widths_and_sample_extremes(gpu, torch_cuda, oracle, n, shift):
+    """S6's column stage reads the PCM where the caller put it: rows of n2 samples in 8-, 4- or 2-byte loads by what n2 and
+    the pointer's alignment allow (n2 = 6300, 5250, 6615; the buffer shifted by one and two samples), two chunks of k1 at
+    60 s (n1 = 420), and the ends of the int16 range through the sample digits (x = 256 hi + lo + 128): forward bins
+    bit-identical to the oracle's exact integer sums"""
+    torch = torch_cuda
+    rng = np.random.default_rng(n + shift)
+    clips = np.stack([synth.gen_clip(970 + i, n / 44100.0)[:n] for i in range(2)])
+    clips[0, ::97] = 32767
+    clips[0, 5::89] = -32768
+    clips[1, : n // 3] = rng.integers(-32768, 32768, n // 3).astype(np.int16)   # full-scale noise: every digit value
+    plan = oracle.Plan(n)
+    buf = torch.zeros(2 * n + 8, dtype=torch.int16, device="cuda")
+    buf[shift: shift + 2 * n] = torch.from_numpy(clips.reshape(-1)).cuda()
+    d_x = torch.empty((2, plan.kmax - plan.kmin, 2), dtype=torch.float32, device="cuda")
+    gpu.stage_spectrum_dev(buf.data_ptr() + 2 * shift, n, 2, d_x.data_ptr())
+    torch.cuda.synchronize()
+    got = d_x.cpu().numpy()
+    for i in range(2):
+        assert bits_equal(got[i], plan.spectrum(clips[i])), (n, shift, i)
 
 
 def test_clip_too_short_is_an_error(gpu, filters):
