@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the oracle altogether (profiling runs: nothing but the product in the process)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) section")
+    ap.add_argument("--no-ffi", action="store_true",
+                    help="skip the file-level section (the reference's FFI entry points over WAV files on tmpfs)")
+    ap.add_argument("--ffi-files", type=int, default=1000)
     ap.add_argument("--no-f32-chain", action="store_true",
                     help="skip the pass with the f32-chain projection and its bit comparison with the fixed-point default")
     ap.add_argument("--no-any-length", action="store_true",
@@ -351,6 +354,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_any_length:
         any_len = bench_any_length(torch, gpu, pcm, n_samples, None if args.no_parity else __import__("oracle.oracle").oracle, filt)
 
+    ffi = None
+    if rank == 0 and world == 1 and not args.no_ffi:
+        ffi = bench_ffi(torch, pcm, n_samples, filt, hp, args.ffi_files)
+
     search = None
     if not args.no_search:
         search = bench_search(torch, tdist if world > 1 else None, gpu, hdist, synth, args, rank, world, device,
@@ -390,7 +397,7 @@ def main():
             "kernel_ms_one_pass": split,
             "roofline": roofline, "roofline_second_kernel": roofline_second, "cpu_baseline": cpu_baseline, "parity": parity,
             "projection_f32_chain": f32_chain,
-            "pcie_inclusive": pcie, "any_length": any_len, "search": search,
+            "pcie_inclusive": pcie, "ffi": ffi, "any_length": any_len, "search": search,
             "stream": stream_res, "filter_learning": learn, "rccl": comm,
         }
         print(json.dumps(line), flush=True)
@@ -507,6 +514,66 @@ def bench_any_length(torch, gpu, pcm, n_samples, oracle_mod, filt, n=256):
         out["clips_checked"] = n
         out["bit_identical"] = bool(np.array_equal(got, want))
         out["hashprints_differing"] = int((got != want).sum())
+    return out
+
+
+def bench_ffi(torch, pcm, n_samples, filt, hp_dev, n_files):
+    """The reference's own boundary takes FILES (parallel_collector_wrapper.hpp:25-30, parallel_collector.h:48-59,82-137):
+    par_collector_calc_hashprints and par_collector_prepare (filters kept: no learning; the spectrogram cache written as
+    the reference writes it) over WAV files on tmpfs, once with equal lengths and once with a different length in every
+    file -- the shape of a directory of real tracks, where every file brings a new clip length and its tables.  Never `value`."""
+    import shutil
+    import tempfile
+    import hpfw_amd
+    from hpfw_amd import synth
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="hpfw_ffi_", dir=base)
+    out = {"files": n_files, "where": "tmpfs" if base else "tmp", "clip_samples": n_samples}
+    try:
+        n_src = min(64, pcm.shape[0])
+        src = pcm[:n_src].cpu().numpy()
+        want = hp_dev[:n_src].cpu().numpy().view(np.uint64)
+        cache = os.path.join(d, "cache") + "/"
+        os.makedirs(cache)
+        with open(os.path.join(cache, "filters.cereal"), "wb") as f:   # cereal image of Filters (utils.h:84-90)
+            f.write(np.array([64, 2420], np.int32).tobytes() + np.ascontiguousarray(filt, np.float32).tobytes())
+        pc = hpfw_amd.ParallelCollector()
+        pc.load(cache)
+        os.environ["HPFW_PREPARE_KEEP_FILTERS"] = "1"
+        for label, lengths in (("equal_lengths", [n_samples] * n_files),
+                               ("distinct_lengths", [n_samples - 3 * i for i in range(n_files)])):
+            sub = os.path.join(d, label)
+            os.makedirs(sub)
+            paths = []
+            for i, n in enumerate(lengths):
+                p = os.path.join(sub, f"t{i:05d}.wav")
+                synth.write_wav(p, src[i % n_src][:n])
+                paths.append(p)
+            res = {}
+            pc.calc_hashprints(paths[:256])                               # first touch: the pinned arena of a full window, the tables
+            t0 = time.perf_counter()
+            got = pc.calc_hashprints(paths)
+            dt = time.perf_counter() - t0
+            ok = sum(1 for a, _ in got if a is not None)
+            res["calc_hashprints_files_per_s"] = round(ok / dt, 1)
+            res["calc_hashprints_s"] = round(dt, 3)
+            if label == "equal_lengths":
+                res["hashprints_equal_to_the_device_path"] = bool(all(np.array_equal(got[i][0], want[i % n_src]) for i in range(ok)))
+            t0 = time.perf_counter()
+            got = pc.prepare(paths)
+            dt = time.perf_counter() - t0
+            res["prepare_files_per_s"] = round(len(got) / dt, 1)
+            res["prepare_s"] = round(dt, 3)
+            res["files_returned"] = len(got)
+            out[label] = res
+            shutil.rmtree(sub, ignore_errors=True)
+            shutil.rmtree(os.path.join(cache, "spectros"), ignore_errors=True)
+        out["note"] = ("par_collector_calc_hashprints / par_collector_prepare through ctypes (hpfw_amd.ParallelCollector, the twin of "
+                       "pyhpfw.py); prepare with HPFW_PREPARE_KEEP_FILTERS=1 (no learning), spectrogram cache written to tmpfs; "
+                       "distinct lengths: every file a different sample count (chirp-z forward transform, tables per length)")
+    finally:
+        os.environ.pop("HPFW_PREPARE_KEEP_FILTERS", None)
+        shutil.rmtree(d, ignore_errors=True)
     return out
 
 

@@ -12,6 +12,7 @@
 // matrix (reference include/hpfw/utils.h:84-90: int32 rows, int32 cols, column-major payload).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
@@ -22,6 +23,10 @@
 #include <thread>
 #include <unordered_set>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -174,6 +179,15 @@ struct hpfw_legacy_collector {
     hpfw_gpu *gpu = nullptr;
     std::string cache_dir = "cache/"; // parallel_collector.h:38
     std::vector<float> filters;
+    // prepare() / calc_hashprints(): one window of files is read straight into pinned host memory (clips of equal length
+    // side by side) and goes to the device in one copy; both buffers are kept between windows and calls
+    void *arena = nullptr, *d_arena = nullptr;
+    size_t arena_cap = 0, d_arena_cap = 0;
+    ~hpfw_legacy_collector()
+    {
+        if (arena) (void)hipHostFree(arena);
+        if (d_arena) (void)hipFree(d_arena);
+    }
 };
 
 // the exported entry points: no exception leaves the C boundary (the reference's wrapper.cpp has no such
@@ -301,42 +315,192 @@ void calc_hashprint_result_free(uint64_t *hp) { delete[] hp; }
 // ---- prepare(): files in windows, equally long clips batched through the device stages ----------
 namespace {
 
-struct Loaded {
-    std::vector<int16_t> pcm;
+// where the samples of a RIFF/WAVE file lie: the chunk walk of read_wav_pcm16_mono on a file descriptor (pread), without
+// reading the payload
+struct WavProbe {
+    int fd = -1;
+    int64_t data_off = 0, frames = 0; // payload offset; samples per channel
+    int channels = 0;
     bool ok = false;
 };
 
-// the reference reads its files on a taskflow pool (parallel_collector.h:95-108); here a team of host
-// threads decodes one window of files while the device stages take whole groups of clips
-// gpu: the reader threads also prepare the host half of the tables of every length they meet (hpfw_gpu_prepare_length:
-// a corpus of full-length tracks brings a new length with almost every file, and that half costs more than the file's
-// extraction), so that the device stages find them ready
-void read_window(const char **filenames, const std::vector<int> &files, size_t first, size_t last, std::vector<Loaded> &out,
-                 hpfw_gpu *gpu)
+bool probe_wav(const std::string &path, WavProbe &w, std::string &why)
+{
+    w = WavProbe();
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
+        why = "cannot open " + path;
+        return false;
+    }
+    struct stat stt;
+    if (fstat(fd, &stt) != 0) {
+        ::close(fd);
+        why = "cannot stat " + path;
+        return false;
+    }
+    const int64_t fsize = (int64_t)stt.st_size;
+    unsigned char hdr[12];
+    if (pread(fd, hdr, 12, 0) != 12 || std::memcmp(hdr, "RIFF", 4) || std::memcmp(hdr + 8, "WAVE", 4)) {
+        ::close(fd);
+        why = path + ": not a RIFF/WAVE file";
+        return false;
+    }
+    uint16_t fmt = 0, channels = 0, bits = 0;
+    uint32_t rate = 0;
+    bool have_fmt = false;
+    for (int64_t pos = 12; pos + 8 <= fsize;) {
+        unsigned char ch[8];
+        if (pread(fd, ch, 8, pos) != 8) break;
+        uint32_t sz;
+        std::memcpy(&sz, ch + 4, 4);
+        if (!std::memcmp(ch, "fmt ", 4)) {
+            if (sz < 16 || sz > 4096) break; // malformed: reported as "no data chunk" below
+            unsigned char b[4096];
+            if (pread(fd, b, sz, pos + 8) != (ssize_t)sz) break;
+            std::memcpy(&fmt, b, 2);
+            std::memcpy(&channels, b + 2, 2);
+            std::memcpy(&rate, b + 4, 4);
+            std::memcpy(&bits, b + 14, 2);
+            if (fmt == 0xFFFE && sz >= 26) std::memcpy(&fmt, b + 24, 2); // WAVE_FORMAT_EXTENSIBLE: the sub-format's tag
+            have_fmt = true;
+        } else if (!std::memcmp(ch, "data", 4)) {
+            if (!have_fmt || fmt != 1 || bits != 16 || (channels != 1 && channels != 2) || rate != 44100) {
+                ::close(fd);
+                why = path + ": only PCM16 mono/stereo at 44100 Hz is supported";
+                return false;
+            }
+            // a streamed file may carry 0 or 0xffffffff as the size: trust the file's length instead
+            const int64_t left = fsize - (pos + 8);
+            int64_t bytes = sz;
+            if (sz == 0 || bytes > left) bytes = std::min<int64_t>(left, 0xfffffffe);
+            w.fd = fd;
+            w.data_off = pos + 8;
+            w.channels = channels;
+            w.frames = bytes / 2 / channels;
+            w.ok = true;
+            return true;
+        }
+        pos += 8 + (int64_t)sz + (sz & 1);
+    }
+    ::close(fd);
+    why = path + ": no data chunk";
+    return false;
+}
+
+struct Loaded {
+    const int16_t *pcm = nullptr; // in the collector's pinned arena
+    int64_t n = 0;                // samples (mono)
+    size_t arena_off = 0;         // byte offset of the clip in the arena (the device copy has the same layout)
+    bool ok = false;
+};
+
+// One window of files into the collector's pinned arena, clips of equal length side by side (so that a group goes
+// through the device stages as one batch, straight from the window's single host-to-device copy).  The reference
+// reads its files on a taskflow pool (parallel_collector.h:95-108); here a team of host threads walks the headers, then
+// reads the payloads with pread() into their slots (stereo is averaged as MonoLoader's "mix" downmix).  The reader
+// threads also prepare the host half of the tables of every length they meet (hpfw_gpu_prepare_length: a corpus of
+// full-length tracks brings a new length with almost every file).
+// Returns the bytes of the arena in use (0: nothing readable).
+size_t read_window(hpfw_legacy_collector *c, const char **filenames, const std::vector<int> &files, size_t first, size_t last,
+                   std::vector<Loaded> &out)
 {
     std::mutex why_mtx;
     std::string first_why; // the reader threads' messages are thread-local: keep the first failure for the caller
     const int count = (int)(last - first);
     out.assign((size_t)count, Loaded());
+    std::vector<WavProbe> probes((size_t)count);
     unsigned team = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-    team = std::min<unsigned>(team, (unsigned)count);
-    std::atomic<int> next{0};
-    auto work = [&] {
-        for (int i; (i = next.fetch_add(1)) < count;) {
-            std::string why;
-            out[(size_t)i].ok = read_clip(filenames[files[first + (size_t)i]], out[(size_t)i].pcm, why);
-            if (out[(size_t)i].ok && gpu) (void)hpfw_gpu_prepare_length(gpu, (int64_t)out[(size_t)i].pcm.size()); // (too short: skipped later)
-            if (!out[(size_t)i].ok) {
-                std::scoped_lock lock(why_mtx);
-                if (first_why.empty()) first_why = why;
-            }
-        }
+    team = std::min<unsigned>(team, (unsigned)std::max(count, 1));
+    auto run = [&](auto fn) {
+        std::atomic<int> next{0};
+        auto work = [&] {
+            for (int i; (i = next.fetch_add(1)) < count;) fn(i);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < team; ++t) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
     };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < team; ++t) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
+    auto fail = [&](const std::string &why) {
+        std::scoped_lock lock(why_mtx);
+        if (first_why.empty()) first_why = why;
+    };
+    run([&](int i) {
+        std::string why;
+        try {
+            if (!probe_wav(filenames[files[first + (size_t)i]], probes[(size_t)i], why)) fail(why);
+            else if (c->gpu) (void)hpfw_gpu_prepare_length(c->gpu, probes[(size_t)i].frames); // (too short: skipped later)
+        } catch (const std::exception &e) {
+            fail(std::string(filenames[files[first + (size_t)i]]) + ": " + e.what());
+        }
+    });
+    // slots: by length, then input order; every group starts 16-byte aligned
+    std::map<int64_t, std::vector<int>> by_len;
+    for (int i = 0; i < count; ++i)
+        if (probes[(size_t)i].ok && probes[(size_t)i].frames > 0) by_len[probes[(size_t)i].frames].push_back(i);
+    size_t bytes = 0;
+    for (auto &kv : by_len) {
+        bytes = (bytes + 15) / 16 * 16;
+        for (int i : kv.second) {
+            out[(size_t)i].arena_off = bytes;
+            out[(size_t)i].n = kv.first;
+            bytes += (size_t)kv.first * 2;
+        }
+    }
+    if (bytes > c->arena_cap) {
+        if (c->arena) (void)hipHostFree(c->arena);
+        c->arena = nullptr;
+        c->arena_cap = 0;
+        const size_t want = std::max(bytes + bytes / 4, (size_t)64 << 20);
+        if (hipHostMalloc(&c->arena, want, hipHostMallocDefault) != hipSuccess) {
+            c->arena = nullptr;
+            hpfw_internal_set_error("prepare: out of pinned host memory");
+            for (WavProbe &w : probes)
+                if (w.fd >= 0) ::close(w.fd);
+            return 0;
+        }
+        c->arena_cap = want;
+    }
+    run([&](int i) {
+        WavProbe &w = probes[(size_t)i];
+        if (!w.ok || w.frames <= 0) {
+            if (w.fd >= 0) ::close(w.fd);
+            return;
+        }
+        int16_t *dst = reinterpret_cast<int16_t *>(static_cast<char *>(c->arena) + out[(size_t)i].arena_off);
+        bool ok = true;
+        try {
+            if (w.channels == 1) {
+                int64_t done = 0;
+                const int64_t want = w.frames * 2;
+                while (done < want) {
+                    const ssize_t r = pread(w.fd, reinterpret_cast<char *>(dst) + done, (size_t)(want - done), w.data_off + done);
+                    if (r <= 0) break;
+                    done += r;
+                }
+                ok = done == want;
+            } else {
+                std::vector<int16_t> raw((size_t)w.frames * 2);
+                int64_t done = 0;
+                const int64_t want = w.frames * 4;
+                while (done < want) {
+                    const ssize_t r = pread(w.fd, reinterpret_cast<char *>(raw.data()) + done, (size_t)(want - done), w.data_off + done);
+                    if (r <= 0) break;
+                    done += r;
+                }
+                ok = done == want;
+                for (int64_t k = 0; ok && k < w.frames; ++k) dst[k] = (int16_t)(((int)raw[(size_t)(2 * k)] + (int)raw[(size_t)(2 * k + 1)]) / 2);
+            }
+        } catch (const std::exception &e) { // e.g. bad_alloc on a huge stereo file
+            ok = false;
+        }
+        ::close(w.fd);
+        if (!ok) fail(std::string(filenames[files[first + (size_t)i]]) + ": short read");
+        out[(size_t)i].pcm = dst;
+        out[(size_t)i].ok = ok;
+    });
     if (!first_why.empty()) hpfw_internal_set_error(first_why.c_str()); // skipped files (parallel_collector.h:101-103): the message survives
+    return bytes;
 }
 
 struct DevMem {
@@ -351,23 +515,35 @@ struct DevMem {
     bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
 };
 
-// dB spectrograms [n][121][C] of n equally long clips of the window (device memory, caller frees)
-float *group_spectrograms(hpfw_gpu *gpu, const std::vector<Loaded> &clips, const std::vector<int> &pos, int64_t len,
-                          const hpfw_geometry &g)
+// the window's clips on the device: one copy of the arena (its layout is kept)
+bool upload_window(hpfw_legacy_collector *c, size_t bytes)
 {
-    DevMem pcm;
+    if (bytes > c->d_arena_cap) {
+        if (c->d_arena) (void)hipFree(c->d_arena);
+        c->d_arena = nullptr;
+        c->d_arena_cap = 0;
+        const size_t want = std::max(bytes + bytes / 4, (size_t)64 << 20);
+        if (hipMalloc(&c->d_arena, want) != hipSuccess) {
+            c->d_arena = nullptr;
+            hpfw_internal_set_error("prepare: out of device memory");
+            return false;
+        }
+        c->d_arena_cap = want;
+    }
+    return bytes == 0 || hipMemcpy(c->d_arena, c->arena, bytes, hipMemcpyHostToDevice) == hipSuccess;
+}
+
+// dB spectrograms [n][121][C] of n equally long clips of the window (device memory, caller frees); the clips lie side by
+// side in the device copy of the arena, the first at `first_off`
+float *group_spectrograms(hpfw_legacy_collector *c, size_t first_off, size_t n, int64_t len, const hpfw_geometry &g)
+{
     float *d_db = nullptr;
-    if (!pcm.alloc(pos.size() * (size_t)len * 2) || hipMalloc((void **)&d_db, pos.size() * (size_t)121 * g.c * 4) != hipSuccess) {
+    if (hipMalloc((void **)&d_db, n * (size_t)121 * g.c * 4) != hipSuccess) {
         hpfw_internal_set_error("prepare: out of device memory");
         return nullptr;
     }
-    bool ok = true;
-    for (size_t k = 0; k < pos.size() && ok; ++k)
-        ok = hipMemcpy((int16_t *)pcm.p + k * (size_t)len, clips[(size_t)pos[k]].pcm.data(), (size_t)len * 2, hipMemcpyHostToDevice) ==
-             hipSuccess;
-    ok = ok && hpfw_gpu_stage_spectrogram(gpu, (const int16_t *)pcm.p, len, (int64_t)pos.size(), d_db, nullptr) == 0 &&
-         hipDeviceSynchronize() == hipSuccess;
-    if (!ok) {
+    const int16_t *d_pcm = reinterpret_cast<const int16_t *>(static_cast<const char *>(c->d_arena) + first_off);
+    if (hpfw_gpu_stage_spectrogram(c->gpu, d_pcm, len, (int64_t)n, d_db, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
         (void)hipFree(d_db);
         return nullptr;
     }
@@ -446,16 +622,38 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
             ++end;
         }
         std::vector<Loaded> clips;
-        read_window(filenames, files, at, end, clips, c->gpu);
-        std::map<int64_t, std::vector<int>> by_len; // length -> positions in the window, in input order
-        for (size_t i = 0; i < clips.size(); ++i)
-            if (clips[i].ok) by_len[(int64_t)clips[i].pcm.size()].push_back((int)i);
-        for (auto &kv : by_len) {
+        const bool timing = std::getenv("HPFW_FFI_TIMING") != nullptr; // where a window's time goes, on stderr
+        const auto t_0 = std::chrono::steady_clock::now();
+        const size_t used = read_window(c, filenames, files, at, end, clips);
+        const auto t_1 = std::chrono::steady_clock::now();
+        if (!upload_window(c, used)) break;
+        const auto t_2 = std::chrono::steady_clock::now();
+        // length -> positions in the window, in input order.  A group whose files were all read lies side by side in the
+        // arena; one with a failed read in its middle is cut into its contiguous runs
+        std::map<int64_t, std::vector<std::vector<int>>> by_len;
+        {
+            std::map<int64_t, std::vector<int>> all;
+            for (size_t i = 0; i < clips.size(); ++i)
+                if (clips[i].n > 0) all[clips[i].n].push_back((int)i);
+            for (auto &kv : all) {
+                std::vector<int> run;
+                for (int i : kv.second) {
+                    if (clips[(size_t)i].ok) {
+                        run.push_back(i);
+                    } else if (!run.empty()) {
+                        by_len[kv.first].push_back(run);
+                        run.clear();
+                    }
+                }
+                if (!run.empty()) by_len[kv.first].push_back(run);
+            }
+        }
+        for (auto &kv : by_len)
+          for (const std::vector<int> &pos : kv.second) {
             const int64_t len = kv.first;
-            const std::vector<int> &pos = kv.second;
             hpfw_geometry g;
             if (hpfw_gpu_geometry(c->gpu, len, &g) != 0 || g.n_frames < 2) continue; // skipped
-            float *d_db = group_spectrograms(c->gpu, clips, pos, len, g);
+            float *d_db = group_spectrograms(c, clips[(size_t)pos[0]].arena_off, pos.size(), len, g);
             if (!d_db) continue;
             std::vector<int> ids;
             for (int q : pos) ids.push_back(files[at + (size_t)q]);
@@ -488,6 +686,12 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
             }
             (void)hipDeviceSynchronize();
             (void)hipFree(d_db);
+        }
+        if (timing) {
+            const auto t_3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[hpfw ffi] window of %zu files, %.1f MB: read %.1f ms, upload %.1f ms, device + results %.1f ms\n", end - at,
+                         used / 1e6, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3));
         }
         at = end;
     }
