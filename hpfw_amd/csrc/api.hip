@@ -403,6 +403,36 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     if ((rc = upload(lg, &c.lg, dp->owned))) return rc;
     if ((rc = upload(p.g_off, &c.g_off, dp->owned))) return rc;
     if ((rc = upload(p.g, reinterpret_cast<const hpfw::HostCf **>(&c.g), dp->owned))) return rc;
+    c.g2 = nullptr;
+    c.g2_off = nullptr;
+    c.q2a = c.nq2 = nullptr;
+    c.nq2_magic = nullptr;
+    c.rows_min = std::getenv("HPFW_CQ_ROWS_MIN") ? std::atoi(std::getenv("HPFW_CQ_ROWS_MIN")) : 8;
+    if (!p.bluestein) { // the windows once more, in the order the rows layout of the forward bins is read (kernels.h XsBandRows)
+        std::vector<int> q2a(121), nq2(121);
+        std::vector<unsigned> magic(121);
+        std::vector<int64_t> g2_off(121);
+        int64_t total = 0;
+        for (int j = 0; j < 121; ++j) {
+            q2a[j] = p.start[j] / p.n1;
+            nq2[j] = (p.start[j] + p.lg[j] - 1) / p.n1 - q2a[j] + 1;
+            magic[j] = nq2[j] >= 2 ? (unsigned)(((1ull << 32) + (unsigned)nq2[j] - 1) / (unsigned)nq2[j]) : 0u;
+            g2_off[j] = total;
+            total += (int64_t)p.n1 * nq2[j];
+        }
+        std::vector<hpfw::HostCf> g2((size_t)total, hpfw::HostCf{0.0f, 0.0f});
+        for (int j = 0; j < 121; ++j)
+            for (int q1 = 0; q1 < p.n1; ++q1)
+                for (int tq = 0; tq < nq2[j]; ++tq) {
+                    const int64_t i = q1 + (int64_t)p.n1 * (q2a[j] + tq) - p.start[j];
+                    if (i >= 0 && i < p.lg[j]) g2[(size_t)(g2_off[j] + (int64_t)q1 * nq2[j] + tq)] = p.g[(size_t)(p.g_off[j] + i)];
+                }
+        if ((rc = upload(g2, reinterpret_cast<const hpfw::HostCf **>(&c.g2), dp->owned))) return rc;
+        if ((rc = upload(g2_off, &c.g2_off, dp->owned))) return rc;
+        if ((rc = upload(q2a, &c.q2a, dp->owned))) return rc;
+        if ((rc = upload(nq2, &c.nq2, dp->owned))) return rc;
+        if ((rc = upload(magic, &c.nq2_magic, dp->owned))) return rc;
+    }
     for (const hpfw::BluesteinClass &bc : p.classes) {
         hpfw::CqClassDev cd;
         cd.p = bc.p;

@@ -243,13 +243,19 @@ HPFW_DEVICE void cq_transform(Lds &lds, const CqTwiddles &tw, int nthreads, int 
 
 // ---- the whole band: window*chirp, forward FFT, times V, inverse FFT, magnitudes ----
 // lds: Size<NP>::DATA complex slots; red: one float per thread (the largest value it stored).
-// xs(i): forward bin start_j + i of the clip (a plain pointer's [] in the emulation, kernels.h XsBand in the kernels:
-// the forward transform leaves the bins in rows k mod n1).
+// xs.for_each(tid, nthreads, lg, g, f): f(i, X[start_j + i] g[i]) for every i < lg, in whatever order the layout of the
+// forward bins makes cheap (a plain pointer in the emulation; kernels.h XsBand / XsBandRows in the kernels: the forward
+// transform leaves the bins in rows k mod n1, and g is then the window permuted likewise).
 // fin(m): what is stored for magnitude m -- m itself, or its dB term (monotone in m, so the
 // largest stored value belongs to the largest magnitude either way).
 struct XsPtr {
     const cf *p;
     HPFW_DEVICE_MEMBER cf operator()(int i) const { return p[i]; }
+    template <class F>
+    HPFW_DEVICE_MEMBER void for_each(int tid, int nthreads, int lg, const cf *__restrict__ g, F f) const
+    {
+        for (int i = tid; i < lg; i += nthreads) f(i, c_mul(p[i], g[i]));
+    }
 };
 
 template <int NP, class Lds, class Red, class Xs, class Fin>
@@ -262,7 +268,7 @@ HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const Xs &xs, co
     const bool prune = lg <= P::N / 4; // the first pass is radix 4 for every admitted length
     HPFW_FOR_THREADS(tid, nthreads)
     {
-        for (int i = tid; i < lg; i += nthreads) lds[pad16(i)] = c_mul(xs(i), g[i]);
+        xs.for_each(tid, nthreads, lg, g, [&](int i, cf v) { lds[pad16(i)] = v; });
         if (!prune)
             for (int i = lg + tid; i < P::N; i += nthreads) lds[pad16(i)] = {0.0f, 0.0f};
     }

@@ -47,10 +47,18 @@ __global__ __launch_bounds__(cq_threads(NP), cq_waves(NP)) void cq_kernel(CqPlan
     float *red = reinterpret_cast<float *>(lds + P::DATA); // one float per thread behind the data
     const int j = cc.band[blockIdx.x];
     const int clip = blockIdx.y;
-    const XsBand xs{cp.view(x, clip), cp.start[j]};
     float *out = mag + ((int64_t)clip * kBins + j) * cp.c;
-    cq_band_body<NP>(lds, red, cq_threads(NP), xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
-                       [](float m) { return DBT ? db_term(m * m) : m; });
+    // natural order (chirp-z forward transform, stage entry point) -- or a band so narrow that a row of the rows layout
+    // holds only a few of its bins: walking the slice element by element then costs less than walking n1 short rows
+    if (cp.xn1 == 1 || cp.nq2[j] < cp.rows_min) {
+        const XsBand xs{cp.view(x, clip), cp.start[j]};
+        cq_band_body<NP>(lds, red, cq_threads(NP), xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
+                           [](float m) { return DBT ? db_term(m * m) : m; });
+    } else {           // rows k mod n1, as the row stage of S6 leaves them
+        const XsBandRows xs{x + (int64_t)clip * cp.xclip, cp.xn1, cp.xw, cp.xq0, cp.start[j], cp.q2a[j], cp.nq2[j], cp.nq2_magic[j]};
+        cq_band_body<NP>(lds, red, cq_threads(NP), xs, cp.g2 + cp.g2_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
+                           [](float m) { return DBT ? db_term(m * m) : m; });
+    }
     // wave maximum -> wavemax[clip][band][wave]: plain stores (clipmax_kernel reduces them); one
     // atomicMax per wave on a per-clip word cost 0.4 ms per 1000 clips in contention
     const float mx = wave_max(red[threadIdx.x]);

@@ -63,6 +63,33 @@ struct XsBand {
     XsView v;
     int start;
     HPFW_DEVICE_MEMBER cf operator()(int i) const { return v(start + i); }
+    // every element of the slice times its window value, in natural order: f(i, x[i] g[i])
+    template <class F>
+    HPFW_DEVICE_MEMBER void for_each(int tid, int nthreads, int lg, const cf *__restrict__ g, F f) const
+    {
+        for (int i = tid; i < lg; i += nthreads) f(i, c_mul(v(start + i), g[i]));
+    }
+};
+// the same slice walked in the order the rows layout stores it (row q1 = k mod n1, then the q2 of the slice, which are
+// consecutive in memory), with the window permuted likewise on the host (CqPlanDev::g2): lanes read runs of a row
+// instead of 64 different rows.  t = q1 nq2 + tq is bin k = q1 + n1 (q2a + tq), element i = k - start (skipped outside
+// [0, lg): there the permuted window holds zeros).
+struct XsBandRows {
+    const cf *base;  // clip's first element
+    int n1, w, q0;   // as XsView
+    int start, q2a, nq2;
+    unsigned magic;  // ceil(2^32 / nq2) (nq2 >= 2): t / nq2 = umulhi(t, magic) for every t < 2^19
+    template <class F>
+    HPFW_DEVICE_MEMBER void for_each(int tid, int nthreads, int lg, const cf *__restrict__ g2, F f) const
+    {
+        const int total = n1 * nq2;
+        for (int t = tid; t < total; t += nthreads) {
+            const int q1 = nq2 == 1 ? t : (int)(((unsigned long long)(unsigned)t * magic) >> 32);
+            const int tq = t - q1 * nq2;
+            const int i = q1 + n1 * (q2a + tq) - start;
+            if (i >= 0 && i < lg) f(i, c_mul(base[(int64_t)q1 * w + (q2a - q0 + tq)], g2[t]));
+        }
+    }
 };
 
 // Forward transform of a clip length with a prime factor above 7 (k_bluestein.hip): a chirp-z
@@ -107,6 +134,12 @@ struct CqPlanDev {
     const int *lg;      // window length                [121]
     const int64_t *g_off; // offset of band j in g     [121]
     const cf *g;        // window * chirp / (M P)       [sum lg]
+    // the same windows in the order of the rows layout (XsBandRows): band j at g2_off[j], n1 * nq2[j] entries
+    const cf *g2;
+    const int64_t *g2_off; // [121]
+    const int *q2a, *nq2;  // [121]
+    const unsigned *nq2_magic; // [121]
+    int rows_min;          // bands whose slice holds fewer than this many bins per row are walked element by element
 };
 
 // S6 column stage: pcm [n_clips][n1][n2] (clips `clip_samples` apart) -> z [n_clips][hq][Re row, Im row][n2]
