@@ -177,8 +177,14 @@ def main():
     ev_ms = gpu.timer_stop(stream)
     torch.cuda.synchronize()
     barrier()
-    dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt)
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local)
+    per_rank_ms = [dt_local * 1e3 / args.steps]
+    if world > 1:                                            # every rank's own time for the same per-GPU work as the N = 1 run
+        mine = torch.tensor([dt_local * 1e3 / args.steps], dtype=torch.float64, device="cpu" if rehearse else device)
+        allt = [torch.empty_like(mine) for _ in range(world)]
+        tdist.all_gather(allt, mine)
+        per_rank_ms = [float(t.item()) for t in allt]
     kt = gpu.kernel_timing()
     gpu.set_kernel_timing(0)
     ms_per_step = dt * 1e3 / args.steps
@@ -394,6 +400,9 @@ def main():
                        "parallelism": f"clips sharded over {world} GPU(s), no collective on this path"},
             "clips_per_s": round(value / geo.n_hp, 1),
             "event_ms_per_step_rank0": round(ev_ms / args.steps, 3),
+            "per_rank_ms_per_step": [round(t, 3) for t in per_rank_ms],
+            "per_gpu_work": {"clips": n_clips, "hashprints": n_clips * geo.n_hp,
+                             "note": "weak scaling: what every rank does per step is what the N = 1 run does"},
             "kernel_ms_one_pass": split,
             "roofline": roofline, "roofline_second_kernel": roofline_second, "cpu_baseline": cpu_baseline, "parity": parity,
             "projection_f32_chain": f32_chain,
@@ -404,6 +413,34 @@ def main():
     gpu.close()
     if world > 1:
         tdist.destroy_process_group()
+
+
+def exchange_hits(tdist, hits, gathered, world, cpu_collectives=False):
+    """the search's one exchange step (storage.h:56-60's global arg-min made a top-k merge): every
+    rank's per-shard top-k list, Q x k x 16 bytes, to every rank.  RCCL (backend "nccl") on device tensors; the gloo
+    rehearsal and the CPU test pass host tensors."""
+    if world <= 1:
+        return
+    if cpu_collectives:
+        tdist.all_gather([gathered[i] for i in range(world)], hits.cpu())
+    else:
+        tdist.all_gather_into_tensor(gathered, hits)          # RCCL over xGMI: Q x k x 16 B per rank
+
+
+def merged_hits(hits, gathered, world, nq, topk):
+    """the per-shard lists -> the global top-k, the same deterministic merge by (dist, clip) on every rank"""
+    import hpfw_amd
+    res = hits.cpu().numpy().reshape(nq, topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(nq, topk)
+    if world > 1:
+        per = gathered.cpu().numpy().reshape(world, nq, topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(world, nq, topk)
+        res = hpfw_amd.merge_topk(per, topk)
+    return res
+
+
+def planted_found(res, nq, n_local, n_hp, kq):
+    """query i was cut from clip i mod n_local of shard 0 at offset 37 i mod (n_hp - kq + 1)"""
+    return bool((res[:, 0]["clip"] == (np.arange(nq) % n_local)).all()
+                and (res[:, 0]["offset"] == ((np.arange(nq) * 37) % (n_hp - kq + 1))).all())
 
 
 def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, stream, barrier, max_over_ranks,
@@ -443,11 +480,7 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
 
     def one():
         gpu.search_topk_dev(q.data_ptr(), q_off, args.topk, hits.data_ptr(), stream)
-        if world > 1 and rehearse:
-            parts = [gathered[i] for i in range(world)]
-            tdist.all_gather(parts, hits.cpu())
-        elif world > 1:
-            tdist.all_gather_into_tensor(gathered, hits)      # RCCL over xGMI: Q x k x 16 B per rank
+        exchange_hits(tdist, hits, gathered, world, rehearse)
 
     one()
     torch.cuda.synchronize()
@@ -464,13 +497,8 @@ def bench_search(torch, tdist, gpu, hdist, synth, args, rank, world, device, str
     kt = gpu.kernel_timing()
     gpu.set_kernel_timing(0)
     pairs = float(nq) * n_local * world * kq * (n_hp - kq + 1) * reps
-    res = hits.cpu().numpy().reshape(nq, args.topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(nq, args.topk)
-    if world > 1:
-        per = gathered.cpu().numpy().reshape(world, nq, args.topk * 4).view(hpfw_amd.HIT_DTYPE).reshape(
-            world, nq, args.topk)
-        res = hpfw_amd.merge_topk(per, args.topk)
-    ok = bool((res[:, 0]["clip"] == (np.arange(nq) % n_local)).all()
-              and (res[:, 0]["offset"] == ((np.arange(nq) * 37) % (n_hp - kq + 1))).all())
+    res = merged_hits(hits, gathered, world, nq, args.topk)
+    ok = planted_found(res, nq, n_local, n_hp, kq)
     scan_ms, scan_l = kt["hamming_scan"]
     pairs_rank_launch = float(nq) * n_local * kq * (n_hp - kq + 1) * reps / max(scan_l, 1)
     scan_rate = pairs_rank_launch / (scan_ms / max(scan_l, 1) * 1e-3) if scan_l else 0.0

@@ -62,6 +62,54 @@ def test_sharded_search_equals_single_rank():
         assert np.array_equal(merged, want)
 
 
+def _bench_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    from oracle import oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # bench_search's shape in small: every rank holds n_local random clips, the queries are cut from shard 0's clips
+    n_local, n_hp, kq, nq, topk = 24, 200, 30, 40, 5
+    def shard(r):
+        return np.random.default_rng(0x1D8 + r).integers(0, 2 ** 64, (n_local, n_hp), dtype=np.uint64)
+    db, db0 = shard(rank), shard(0)
+    src = np.arange(nq) % n_local
+    offs = (np.arange(nq) * 37) % (n_hp - kq + 1)
+    qq = np.stack([db0[src[i], offs[i]:offs[i] + kq] for i in range(nq)])
+    qq ^= np.uint64(1) << np.random.default_rng(0x51).integers(0, 63, qq.shape, dtype=np.uint64)   # a bit flip per hashprint
+    db_off = np.arange(0, (n_local + 1) * n_hp, n_hp, dtype=np.int64)
+    q_off = np.arange(0, (nq + 1) * kq, kq, dtype=np.int64)
+    local = oracle.search_topk(db.ravel(), db_off, qq.ravel(), q_off, topk)          # stands in for the GPU scan of the shard
+    local["clip"][local["clip"] != 0xFFFFFFFF] += rank * n_local                     # hpfw_gpu_index_set_clip_base
+    hits = torch.from_numpy(local.view(np.int32).reshape(nq, topk, 4).copy())
+    gathered = torch.empty((world, nq, topk, 4), dtype=torch.int32)
+    bench.exchange_hits(dist, hits, gathered, world, cpu_collectives=True)           # bench.py's own exchange step
+    res = bench.merged_hits(hits, gathered, world, nq, topk)                         # ... and merge
+    whole = np.concatenate([shard(r) for r in range(world)])
+    want = oracle.search_topk(whole.ravel(), np.arange(0, (world * n_local + 1) * n_hp, n_hp, dtype=np.int64), qq.ravel(), q_off, topk)
+    q.put((rank, bool(np.array_equal(res, want)), bench.planted_found(res, nq, n_local, n_hp, kq)))
+    dist.destroy_process_group()
+
+
+def test_bench_search_exchange_and_merge_two_ranks():
+    """bench.py's N > 1 search leg with gloo in place of RCCL: its exchange step and merge, fed the per-shard lists of two
+    ranks, give the unsharded answer on both ranks and find every planted query"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True, True), (1, True, True)]
+
+
 class _HostLearner:
     """Stands in for hpfw_amd.Gpu in the build container: holds a covariance on the host and solves
     with the product's own host eigen-solver (hpfw_gpu_host_top_eigenvectors needs no GPU)."""
