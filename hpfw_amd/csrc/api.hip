@@ -367,7 +367,8 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     // S6 (7-smooth lengths): the column stage's twiddle digits, digit-offset correction and inter-stage twiddles
     hpfw::ColsQArgs &ca = dp->cols;
     std::memset(&ca, 0, sizeof(ca));
-    dp->rows_out = hpfw::Rows2Out{p.n1, p.hq, p.q2lo, p.q2w, nullptr, nullptr, (p.n2 + 3) / 4};
+    const bool x_natural = std::getenv("HPFW_X_NATURAL") != nullptr;
+    dp->rows_out = hpfw::Rows2Out{p.n1, p.hq, p.q2lo, p.q2w, nullptr, nullptr, (p.n2 + 3) / 4, x_natural ? 1 : 0, p.kmin, p.kmax};
     if (!p.bluestein) {
         ca.n1 = p.n1;
         ca.n2 = p.n2;
@@ -385,7 +386,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     c.kmin = p.kmin;
     c.nk = p.kmax - p.kmin;
     c.c = p.c;
-    if (p.bluestein) { // natural order from kmin on
+    if (p.bluestein || x_natural) { // natural order from kmin on
         c.xn1 = 1;
         c.xw = 0;
         c.xq0 = p.kmin;

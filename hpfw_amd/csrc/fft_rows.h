@@ -160,7 +160,9 @@ HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__rest
 {
     const int nb = (N2C ? N2C : a.n2) / (R1 * R2);
     if (tid >= nb) return;
-    const cf *__restrict__ tb = gt + tid;
+    // the last group's sub-length is R1 R2: j0 = 0 for every butterfly, so its twiddles are the same for all of them --
+    // butterfly 0's entries, read through a wave-uniform address (scalar loads) instead of one vector load per entry
+    const cf *__restrict__ tb = gt;
     cf e[R1][R2];
 #pragma unroll
     for (int q2 = 0; q2 < R2; ++q2) {
@@ -421,6 +423,9 @@ struct Rows2Out {
     // [hq][4] steps T_N[q1 e]; element 4 m + e is seed (e = 0) or seed * step[e] (S1)
     const cf *seed, *step;
     int nq;
+    // natural != 0: the bins go to x[k - kmin] in natural order instead (8 bytes at a stride of n1 elements per thread: the
+    // launcher places the eight rows that share 64-byte lines on one XCD, whose L2 merges them before they leave)
+    int natural, kmin, kmax;
 };
 
 struct alignas(16) f4 {
@@ -484,7 +489,12 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
             const int src = mir ? n2 - 1 - q2 : q2;
             cf v = lds[kNat ? src : pos[src]];
             if (mir) v.i = -v.i;
-            xclip[(int64_t)(mir ? o.n1 - q1 : q1) * o.q2w + j] = v;
+            if (o.natural) {
+                const int k = (mir ? o.n1 - q1 : q1) + o.n1 * q2;
+                if (k >= o.kmin && k < o.kmax) xclip[k - o.kmin] = v;
+            } else {
+                xclip[(int64_t)(mir ? o.n1 - q1 : q1) * o.q2w + j] = v;
+            }
         }
     }
 }

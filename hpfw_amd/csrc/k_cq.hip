@@ -35,7 +35,7 @@ constexpr int cq_threads(int n)
 // at most 256 threads (one wave per SIMD and workgroup) are held to five waves = 96 VGPRs, which costs no scratch and
 // lets a fifth workgroup onto the CU where the LDS has room (P = 3072 and below).  Held to six -- 80 VGPRs, 44-84 bytes
 // of scratch -- the classes whose LDS footprint admits six measured slower, 4.0 against 3.85 ms per 1000 clips.
-constexpr int cq_waves(int n) { return cq_threads(n) <= 256 ? 5 : 1; }
+constexpr int cq_waves(int n) { return cq_threads(n) <= 128 ? 5 : 1; }
 
 template <int NP, bool DBT>
 __global__ __launch_bounds__(cq_threads(NP), cq_waves(NP)) void cq_kernel(CqPlanDev cp, CqClassDev cc,
