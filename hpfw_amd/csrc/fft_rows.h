@@ -423,9 +423,6 @@ struct Rows2Out {
     // [hq][4] steps T_N[q1 e]; element 4 m + e is seed (e = 0) or seed * step[e] (S1)
     const cf *seed, *step;
     int nq;
-    // natural != 0: the bins go to x[k - kmin] in natural order instead (8 bytes at a stride of n1 elements per thread: the
-    // launcher places the eight rows that share 64-byte lines on one XCD, whose L2 merges them before they leave)
-    int natural, kmin, kmax;
 };
 
 struct alignas(16) f4 {
@@ -489,12 +486,7 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
             const int src = mir ? n2 - 1 - q2 : q2;
             cf v = lds[kNat ? src : pos[src]];
             if (mir) v.i = -v.i;
-            if (o.natural) {
-                const int k = (mir ? o.n1 - q1 : q1) + o.n1 * q2;
-                if (k >= o.kmin && k < o.kmax) xclip[k - o.kmin] = v;
-            } else {
-                xclip[(int64_t)(mir ? o.n1 - q1 : q1) * o.q2w + j] = v;
-            }
+            xclip[(int64_t)(mir ? o.n1 - q1 : q1) * o.q2w + j] = v;
         }
     }
 }

@@ -312,19 +312,8 @@ __global__ __launch_bounds__(kFwdThreads, WAVES) void fwd_rows2_kernel(RowsArgs 
     cf *lds = reinterpret_cast<cf *>(smem_raw);
     // clip is the fast grid index: workgroups resident at the same time run the same row, whose butterfly twiddles
     // they share in L2
-    int clip = blockIdx.x, q1 = blockIdx.y;
-    if (o.natural) {
-        // blocks b, b + 8, b + 16 ... share an XCD (round-robin dispatch; speed only): eight consecutive ones of them take
-        // the eight rows 8 g .. 8 g + 7 of one clip, whose outputs interleave inside 64-byte lines
-        const int groups = (o.hq + 7) / 8;
-        const unsigned b = blockIdx.x, xcd = b & 7, i = b >> 3;
-        const unsigned item = (i >> 3) * 8 + xcd;
-        clip = (int)(item / (unsigned)groups);
-        q1 = 8 * (int)(item % (unsigned)groups) + (int)(i & 7);
-        if (clip >= o.natural || q1 >= o.hq) return; // (the flag carries the clip count)
-    }
-    rows2_body<Groups>(lds, a, kFwdThreads, z + ((int64_t)clip * o.hq + q1) * 2 * a.n2, q1, o,
-                       x + (int64_t)clip * (o.natural ? (int64_t)(o.kmax - o.kmin) : (int64_t)o.n1 * o.q2w));
+    const int clip = blockIdx.x, q1 = blockIdx.y;
+    rows2_body<Groups>(lds, a, kFwdThreads, z + ((int64_t)clip * o.hq + q1) * 2 * a.n2, q1, o, x + (int64_t)clip * o.n1 * o.q2w);
 }
 
 __global__ __launch_bounds__(256) void gather_bins_kernel(CqPlanDev cp, const cf *__restrict__ x, cf *__restrict__ out)
@@ -381,18 +370,7 @@ static void launch_rows2_t(const RowsArgs &a, const Rows2Out &o, const float *d_
         attr_set.mark();
     }
     dim3 grid(n_clips, o.hq);
-    if (o.natural) { // one dimension, (clip, group of 8 rows, row) laid out for the XCDs; gridDim.y carries the clip count
-        const int64_t items = (int64_t)n_clips * ((o.hq + 7) / 8);
-        grid = dim3((unsigned)((items + 7) / 8 * 64), (unsigned)n_clips);
-        // (gridDim.y is only read as a number: every block of y > 0 would repeat the work, so launch y = 1 and pass the count)
-    }
-    if (o.natural) {
-        Rows2Out on = o;
-        on.natural = n_clips; // the clip count rides in the flag (non-zero)
-        hipLaunchKernelGGL((fwd_rows2_kernel<Groups, WAVES>), dim3(grid.x), dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, on, d_z, d_x);
-    } else {
-        hipLaunchKernelGGL((fwd_rows2_kernel<Groups, WAVES>), grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, o, d_z, d_x);
-    }
+    hipLaunchKernelGGL((fwd_rows2_kernel<Groups, WAVES>), grid, dim3(kFwdThreads), fwd_rows_lds_bytes(a), s, a, o, d_z, d_x);
 }
 
 void launch_fwd_rows2(const RowsArgs &a, const Rows2Out &o, const float *d_z, int n_clips, cf *d_x, hipStream_t s)
