@@ -12,6 +12,19 @@ struct cf {
     float r, i;
 };
 
+// Per-butterfly twiddle tables of the fused FFT groups (plan.cpp append_group_twiddles): entry e of butterfly b of a table
+// with nb butterflies lies at [e >> 1][b][e & 1] -- two consecutive entries of a butterfly side by side, so that a lane
+// fetches them with ONE 16-byte load and a wave with one contiguous KB (8-byte accesses run at 0.5-0.7 of that rate,
+// and the transforms in LDS are bound by exactly these table loads).
+struct alignas(16) cf2 {
+    cf a, b;
+};
+HPFW_DEVICE cf tw_entry(const cf *__restrict__ gt, int e, int nb, int b)
+{
+    const cf2 p = reinterpret_cast<const cf2 *>(gt)[(e >> 1) * nb + b];
+    return (e & 1) ? p.b : p.a;
+}
+
 HPFW_DEVICE cf c_add(cf a, cf b) { return {a.r + b.r, a.i + b.i}; }
 HPFW_DEVICE cf c_sub(cf a, cf b) { return {a.r - b.r, a.i - b.i}; }
 // a * w

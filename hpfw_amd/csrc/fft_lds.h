@@ -50,7 +50,6 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
     for (int b = tid; b < NB; b += nthreads) {
         const int blk = b / M2, j0 = b % M2;
         const int base = blk * LEN + j0;
-        const cf *__restrict__ tb = gt + b;
         cf e[R1][R2];
 #pragma unroll
         for (int q2 = 0; q2 < R2; ++q2) {
@@ -68,7 +67,7 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
             }
             e[0][q2] = u[0];
 #pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tb[(q2 * (R1 - 1) + (s - 1)) * NB]);
+            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), NB, b));
         }
 #pragma unroll
         for (int s = 0; s < R1; ++s) {
@@ -80,7 +79,7 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
                 lds[pad16(base + s * M1)] = v[0];
 #pragma unroll
                 for (int s2 = 1; s2 < R2; ++s2)
-                    lds[pad16(base + s * M1 + s2 * M2)] = c_mul(v[s2], tb[((R1 - 1) * R2 + (s2 - 1)) * NB]);
+                    lds[pad16(base + s * M1 + s2 * M2)] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), NB, b));
             } else {
                 lds[pad16(base + s * M1)] = e[s][0];
             }
@@ -111,7 +110,6 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
     for (int b = tid; b < NB; b += nthreads) {
         const int blk = b / M2, j0 = b % M2;
         const int base = blk * LEN + j0;
-        const cf *__restrict__ tb = gt + b;
         cf o[R1][R2];
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
@@ -119,7 +117,7 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
             v[0] = lds[pad16(base + q * M1)];
 #pragma unroll
             for (int q2 = 1; q2 < R2; ++q2)
-                v[q2] = c_mulc(lds[pad16(base + q * M1 + q2 * M2)], tb[((R1 - 1) * R2 + (q2 - 1)) * NB]);
+                v[q2] = c_mulc(lds[pad16(base + q * M1 + q2 * M2)], tw_entry(gt, (R1 - 1) * R2 + (q2 - 1), NB, b));
             if constexpr (R2 > 1) idft<R2>(v);
 #pragma unroll
             for (int s2 = 0; s2 < R2; ++s2) o[q][s2] = v[s2];
@@ -130,7 +128,7 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
             cf u[R1];
             u[0] = o[0][s2];
 #pragma unroll
-            for (int q = 1; q < R1; ++q) u[q] = c_mulc(o[q][s2], tb[(s2 * (R1 - 1) + (q - 1)) * NB]);
+            for (int q = 1; q < R1; ++q) u[q] = c_mulc(o[q][s2], tw_entry(gt, s2 * (R1 - 1) + (q - 1), NB, b));
             idft<R1>(u);
 #pragma unroll
             for (int s = 0; s < R1; ++s) {
@@ -176,9 +174,20 @@ HPFW_DEVICE void mid_group(Lds &lds, const cf *__restrict__ mt, int tid, int nth
                 // the stage-2 twiddles are T_N[TS2 * j0 * s2] with j0 = 0, i.e. T_N[0] = (1, -0):
                 // that product returns its operand (only the sign of a zero can differ), so it is skipped
             }
-            // pointwise product at positions base + s M1 + s2
+            // pointwise product at positions base + s M1 + s2: the R2 factors lie side by side, fetched two at a time
+            // where that keeps 16-byte alignment (LEN and M1 even)
+            if constexpr (R2 % 2 == 0 && M1 % 2 == 0 && LEN % 2 == 0) {
+                const cf2 *__restrict__ vp = reinterpret_cast<const cf2 *>(vrev + base + s * M1);
 #pragma unroll
-            for (int s2 = 0; s2 < R2; ++s2) v[s2] = c_mul(v[s2], vrev[base + s * M1 + s2]);
+                for (int s2 = 0; s2 < R2; s2 += 2) {
+                    const cf2 w = vp[s2 >> 1];
+                    v[s2] = c_mul(v[s2], w.a);
+                    v[s2 + 1] = c_mul(v[s2 + 1], w.b);
+                }
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < R2; ++s2) v[s2] = c_mul(v[s2], vrev[base + s * M1 + s2]);
+            }
             // inverse inner radix R2 at j0 = 0: the twiddles conj(T_N[0]) are skipped likewise
             if constexpr (R2 > 1) idft<R2>(v);
 #pragma unroll

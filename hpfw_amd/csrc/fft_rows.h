@@ -2,8 +2,8 @@
 // (DESIGN.md S4, S6).  Same arithmetic as the specification's radix-7/5/4/3/2 passes; two
 // consecutive passes are fused in registers (up to 36 points per thread and LDS round trip).
 // The twiddles of a fused group are read from a per-butterfly table in global memory (L2 resident,
-// built by the host from T_n2: entry e of butterfly b at [e][b], so a wave reads 512 contiguous
-// bytes per entry): no index arithmetic and no LDS traffic for twiddles.  n2 <= 6826 keeps the data
+// built by the host from T_n2: entries e, e + 1 of butterfly b side by side at [e >> 1][b], so a wave reads one
+// contiguous KB per pair of entries, device_math.h tw_entry): no index arithmetic and no LDS traffic for twiddles.  n2 <= 6826 keeps the data
 // under 55 KB of LDS, so several workgroups share a CU and one's loads hide behind another's passes.
 #pragma once
 #include "device_math.h"
@@ -64,7 +64,7 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
         }
         const int j0 = b - blk * m2;
         const int base = blk * len + j0;
-        const cf *__restrict__ tb = gt + b;
+        const int TWB = b;
         cf e[R1][R2];
 #pragma unroll
         for (int q2 = 0; q2 < R2; ++q2) {
@@ -74,7 +74,7 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
             Dft<R1>::run(u);
             e[0][q2] = u[0];
 #pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tb[(q2 * (R1 - 1) + (s - 1)) * nb]);
+            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), nb, TWB));
         }
 #pragma unroll
         for (int s = 0; s < R1; ++s) {
@@ -86,7 +86,7 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
                 lds[base + s * m1] = v[0];
 #pragma unroll
                 for (int s2 = 1; s2 < R2; ++s2)
-                    lds[base + s * m1 + s2 * m2] = c_mul(v[s2], tb[((R1 - 1) * R2 + (s2 - 1)) * nb]);
+                    lds[base + s * m1 + s2 * m2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), nb, TWB));
             } else {
                 lds[base + s * m1] = e[s][0];
             }
@@ -109,7 +109,7 @@ HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restr
     if (tid >= nb) return;
     const int blk = tid / m2, j0 = tid - blk * m2;
     const int base = blk * len + j0;
-    const cf *__restrict__ tb = gt + tid;
+    const int TWB = tid;
     cf e[R1][R2];
 #pragma unroll
     for (int q2 = 0; q2 < R2; ++q2) {
@@ -119,7 +119,7 @@ HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restr
         Dft<R1>::run(u);
         e[0][q2] = u[0];
 #pragma unroll
-        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tb[(q2 * (R1 - 1) + (s - 1)) * nb]);
+        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), nb, TWB));
     }
 #pragma unroll
     for (int s = 0; s < R1; ++s) {
@@ -130,7 +130,7 @@ HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restr
             Dft<R2>::run(v);
             out[s * R2] = v[0];
 #pragma unroll
-            for (int s2 = 1; s2 < R2; ++s2) out[s * R2 + s2] = c_mul(v[s2], tb[((R1 - 1) * R2 + (s2 - 1)) * nb]);
+            for (int s2 = 1; s2 < R2; ++s2) out[s * R2 + s2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), nb, TWB));
         } else {
             out[s] = e[s][0];
         }
@@ -162,7 +162,7 @@ HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__rest
     if (tid >= nb) return;
     // the last group's sub-length is R1 R2: j0 = 0 for every butterfly, so its twiddles are the same for all of them --
     // butterfly 0's entries, read through a wave-uniform address (scalar loads) instead of one vector load per entry
-    const cf *__restrict__ tb = gt;
+    const int TWB = 0;
     cf e[R1][R2];
 #pragma unroll
     for (int q2 = 0; q2 < R2; ++q2) {
@@ -172,7 +172,7 @@ HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__rest
         Dft<R1>::run(u);
         e[0][q2] = u[0];
 #pragma unroll
-        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tb[(q2 * (R1 - 1) + (s - 1)) * nb]);
+        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), nb, TWB));
     }
 #pragma unroll
     for (int s = 0; s < R1; ++s) {
@@ -183,7 +183,7 @@ HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__rest
             Dft<R2>::run(v);
             out[s] = v[0];
 #pragma unroll
-            for (int s2 = 1; s2 < R2; ++s2) out[s + R1 * s2] = c_mul(v[s2], tb[((R1 - 1) * R2 + (s2 - 1)) * nb]);
+            for (int s2 = 1; s2 < R2; ++s2) out[s + R1 * s2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), nb, TWB));
         } else {
             out[s] = e[s][0];
         }

@@ -127,7 +127,7 @@ int64_t chirpz_length(int64_t need)
 } // namespace
 
 // Twiddles of one fused (r1, r2) DIF group at sub-length len of a length-n transform, laid out
-// [entry][butterfly] (nb = n / (r1 r2) butterflies): entry q2 (r1-1) + (s-1) = T_n[ts1 (j0 + q2 m2) s],
+// [entry pair][butterfly][2] (nb = n / (r1 r2) butterflies): entry q2 (r1-1) + (s-1) = T_n[ts1 (j0 + q2 m2) s],
 // entry (r1-1) r2 + (s2-1) = T_n[ts2 j0 s2], with j0 = b mod m2.  The inverse DIT group uses the
 // same values (conjugated by the kernel).
 void append_group_twiddles(const std::vector<HostCf> &tw, int64_t n, int64_t len, int r1, int r2,
@@ -135,14 +135,15 @@ void append_group_twiddles(const std::vector<HostCf> &tw, int64_t n, int64_t len
 {
     const int64_t m1 = len / r1, m2 = m1 / r2, ts1 = n / len, ts2 = n / m1, nb = nb_out ? nb_out : n / (r1 * r2);
     const size_t off = out.size();
-    out.resize(off + (size_t)((r1 - 1) * r2 + (r2 - 1)) * nb);
+    const int entries = (r1 - 1) * r2 + (r2 - 1);
+    // entry e of butterfly b at [e >> 1][b][e & 1] (device_math.h tw_entry); an odd count leaves the last half empty
+    out.resize(off + (size_t)((entries + 1) / 2) * 2 * nb, HostCf{0.0f, 0.0f});
+    auto at = [&](int e, int64_t b) -> HostCf & { return out[off + ((size_t)(e >> 1) * nb + b) * 2 + (e & 1)]; };
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t j0 = b % m2;
         for (int q2 = 0; q2 < r2; ++q2)
-            for (int s = 1; s < r1; ++s)
-                out[off + (size_t)(q2 * (r1 - 1) + (s - 1)) * nb + b] = tw[(size_t)(ts1 * (j0 + q2 * m2) * s)];
-        for (int s2 = 1; s2 < r2; ++s2)
-            out[off + (size_t)((r1 - 1) * r2 + (s2 - 1)) * nb + b] = tw[(size_t)(ts2 * j0 * s2)];
+            for (int s = 1; s < r1; ++s) at(q2 * (r1 - 1) + (s - 1), b) = tw[(size_t)(ts1 * (j0 + q2 * m2) * s)];
+        for (int s2 = 1; s2 < r2; ++s2) at((r1 - 1) * r2 + (s2 - 1), b) = tw[(size_t)(ts2 * j0 * s2)];
     }
 }
 
@@ -493,7 +494,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
                     append_group_twiddles(bc.tw, ps, len, r1, r2, tmp, blk / (r1 * r2));
                     const int64_t nb = blk / (r1 * r2);
                     bc.mid_off = (int)bc.gtw.size();
-                    for (int e = 0; e < (r1 - 1) * r2; ++e) bc.gtw.push_back(tmp[(size_t)e * nb]);
+                    for (int e = 0; e < (r1 - 1) * r2; ++e) bc.gtw.push_back(tmp[((size_t)(e >> 1) * nb) * 2 + (e & 1)]); // butterfly 0's entries
                     break;
                 }
                 if (g >= 4) {
