@@ -167,7 +167,8 @@ def main():
         step()
     torch.cuda.synchronize()
     # the two largest kernels (the row transforms and the projection): one HIP event pair per launch, on the launch stream
-    gpu.set_kernel_timing((1 << hpfw_amd.KERNEL_KINDS.index("project_mfma")) | (1 << hpfw_amd.KERNEL_KINDS.index("fwd_rows")))
+    gpu.set_kernel_timing((1 << hpfw_amd.KERNEL_KINDS.index("project_mfma")) | (1 << hpfw_amd.KERNEL_KINDS.index("fwd_rows")) |
+                          (1 << hpfw_amd.KERNEL_KINDS.index("fwd_cols")))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -238,23 +239,33 @@ def main():
                    "avg_launch_ms": round(pj_ms / max(pj_launches, 1), 4), "launches": pj_launches,
                    "flop_per_clip": PROJECT_FLOP_PER_CLIP * (geo.n_frames / 2400.0),
                    "clips_per_launch": clips_per_launch}
-    # the row transforms: one complex FFT of n2 points per residue pair in LDS; algorithmic bytes = the residue streams
-    # in (4 bytes per pair and time step) + the planar half spectra out
-    rw_ms, rw_launches = kt["fwd_rows"]
-    rows_bytes = ((geo.n1 + 1) // 2) * geo.n2 * 4 + 2 * geo.n1 * ((geo.n2 // 2 + 1 + 31) // 32 * 32) * 4
-    rows_clips = n_clips * args.steps / max(rw_launches, 1)
-    rows_gbs = rows_bytes * rows_clips / (rw_ms / max(rw_launches, 1) * 1e-3) / 1e9 if rw_launches else 0.0
-    roof_rows = {"kernel": "fwd_rows_kernel (residue pairs: FFT_n2 in LDS, Hermitian split, twiddle)", "bound": "hbm",
-                 "achieved": round(rows_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rows_gbs / HBM_PEAK_GBS, 4),
-                 "traffic": (traffic_json.get("fwd_rows_hbm_bytes_per_clip") * rows_clips
-                             if traffic_json.get("fwd_rows_hbm_bytes_per_clip") is not None else None),
-                 "avg_launch_ms": round(rw_ms / max(rw_launches, 1), 4), "launches": rw_launches,
-                 "bytes_per_clip": rows_bytes, "clips_per_launch": rows_clips,
-                 "note": "latency- and issue-bound (profiles/*_sq.json: 22 % VALU issue, 60 % of wave-cycles parked on "
-                         "barriers and waits), not HBM-bound"}
-    dominant_is_rows = roof_rows["avg_launch_ms"] > roof_pj["avg_launch_ms"]
-    roofline = roof_rows if dominant_is_rows else roof_pj
-    roofline_second = roof_pj if dominant_is_rows else roof_rows
+    # the forward transform's two kernels (7-smooth lengths), both bound by HBM on paper:
+    #  column stage: int16 samples in, the rounded integer sums z out (planar f32, hq rows of n2 complex);
+    #  row stage: z in (+ every fourth inter-stage twiddle), the consumed bins out
+    hq, q2w = geo.n1 // 2 + 1, (geo.kmax - 1) // geo.n1 - geo.kmin // geo.n1 + 1
+
+    def hbm_roof(kind, name, bytes_per_clip, key, note):
+        ms, launches = kt[kind]
+        clips = n_clips * args.steps / max(launches, 1)
+        gbs = bytes_per_clip * clips / (ms / max(launches, 1) * 1e-3) / 1e9 if launches else 0.0
+        return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": (traffic_json.get(key) * clips if traffic_json.get(key) is not None else None),
+                "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
+                "bytes_per_clip": bytes_per_clip, "clips_per_launch": clips, "note": note}
+
+    cols_bytes = geo.n1 * geo.n2 * 2 + hq * geo.n2 * 8
+    rows_bytes = hq * geo.n2 * 8 + hq * ((geo.n2 + 3) // 4) * 8 + geo.n1 * q2w * 8
+    roof_cols = hbm_roof("fwd_cols", "fwd_cols_q_kernel (column DFT of the sample matrix as six int8 digit products on "
+                         "v_mfma_i32_32x32x32_i8, exact; one rounding)", cols_bytes, "fwd_cols_hbm_bytes_per_clip",
+                         f"also {6 * 2 * 2 * hq * geo.n1 * geo.n2 / 1e9:.2f} G int8 operations per clip on the matrix pipe "
+                         "(a quarter of its time at the probe's rate); the twiddle digits (147 KB per 128 columns) come from L2")
+    roof_rows = hbm_roof("fwd_rows", "fwd_rows2_kernel (per row: inter-stage twiddles, FFT_n2 in LDS, pruned stores)", rows_bytes,
+                         "fwd_rows_hbm_bytes_per_clip",
+                         "bound by the per-butterfly twiddle tables it streams from L2 (144 KB per transform against 50 KB of "
+                         "data), not by HBM")
+    ranked = sorted([roof_pj, roof_cols, roof_rows], key=lambda r: -r["avg_launch_ms"])
+    roofline, roofline_second, roofline_third = ranked
 
     # per-kernel split of one extra (untimed) pass, for the record
     gpu.set_kernel_timing(-1)
@@ -404,7 +415,8 @@ def main():
             "per_gpu_work": {"clips": n_clips, "hashprints": n_clips * geo.n_hp,
                              "note": "weak scaling: what every rank does per step is what the N = 1 run does"},
             "kernel_ms_one_pass": split,
-            "roofline": roofline, "roofline_second_kernel": roofline_second, "cpu_baseline": cpu_baseline, "parity": parity,
+            "roofline": roofline, "roofline_second_kernel": roofline_second, "roofline_third_kernel": roofline_third,
+            "cpu_baseline": cpu_baseline, "parity": parity,
             "projection_f32_chain": f32_chain,
             "pcie_inclusive": pcie, "ffi": ffi, "any_length": any_len, "search": search,
             "stream": stream_res, "filter_learning": learn, "rccl": comm,
