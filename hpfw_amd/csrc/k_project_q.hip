@@ -16,11 +16,13 @@
 // (|sum| <= 3 * 2420 * 128 * 128 < 2^27), D = sum_c acc_c 2^(8c) in int64.
 //
 // K is taken as k' = 128 t + bin (bins padded to 128 with zero digits) so that the sixteen bytes a lane hands the
-// matrix instruction are sixteen consecutive bins of one column.  A workgroup = 4 waves = 64 filters x 128 hashprints;
-// the digits of its [121 bins][128 + 19 columns] slab of Du live in LDS as 16-byte units [bin chunk][column][digit],
-// the filter digits stream through a double buffer in half steps (t, pair of 32-bin chunks: 12 KB).  81 KB of LDS and
-// 256 registers: TWO workgroups share a CU, so one's staging (loads, quantisation: vector ALU) and epilogue run under
-// the other's matrix instructions.
+// matrix instruction are sixteen consecutive bins of one column.  A workgroup = 4 waves = 64 filters x 128 hashprints,
+// and a wave = 16 FILTERS x all 128 hashprints on v_mfma_i32_16x16x64_i8: the digits of the workgroup's
+// [121 bins][128 + 19 columns] slab of Du live in LDS as 16-byte units [bin chunk][column][digit], shared and read-only
+// after the prologue, while every wave takes the digits of ITS filters straight from L2 into registers (3 KB per step of
+// 64 k', two steps ahead) -- nothing is exchanged between the waves in the main loop, so it has no barrier: the two
+// waves of a SIMD (two workgroups share a CU: 62 KB of LDS, 256 registers) interleave their matrix instructions freely,
+// and one workgroup's staging (loads, quantisation: vector ALU) and epilogue run under the other's products.
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -34,15 +36,17 @@ extern __shared__ __align__(16) unsigned char smem_raw[];
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int kQThreads = 256;                 // 4 waves; each owns 64 filters x 32 hashprints
+constexpr int kQThreads = 256;                 // 4 waves; each owns 16 filters x 128 hashprints
 constexpr int kQTileN = 128;                   // hashprints per workgroup
 constexpr int kQCols = kQTileN + kCtx - 1;     // 147 columns of Du in the slab
+constexpr int kQPitch = 160;                   // columns per chunk as stored: with this pitch the operand reads (ds_read_b128,
+                                               // lanes = 16 columns x 4 chunks) meet no bank conflict (147 .. 157: two-way)
 constexpr int kQChunks = 8;                    // bin chunks of 16 (121 bins padded to 128)
 constexpr int kQUnit = 48;                     // bytes per (chunk, column): three digits x 16 bins
-constexpr int kQSlabBytes = kQChunks * kQCols * kQUnit;       // 56 448
-constexpr int kQHalfBytes = 2 * 3 * 2 * 64 * 16;              // filter digits of one half step: [tile][digit][chunk pair member][lane][16] = 12 288
-constexpr int kQHalfSteps = 2 * kCtx;                         // 40
-constexpr int kQLdsBytes = kQSlabBytes + 2 * kQHalfBytes;     // 81 024: two workgroups per CU
+constexpr int kQSlabBytes = kQChunks * kQPitch * kQUnit;      // 61 440
+constexpr int kQStepBytes = 3 * 64 * 16;                      // a wave's filter digits of one step (t, half of the chunks): [digit][lane][16] = 3 072
+constexpr int kQSteps = 2 * kCtx;                             // 40 steps of 64 k'
+constexpr int kQLdsBytes = kQSlabBytes + kQTileN * 4 * 2;     // + the waves' 16-bit parts of every hashprint: 62 464, two workgroups per CU
 constexpr float kQScale = 98304.0f;
 
 // the three balanced base-256 digits of u as the three low bytes of one word (|u| < 2^23)
@@ -60,19 +64,22 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
                                                                    const float *__restrict__ tmax, int c, int nhp,
                                                                    uint64_t *__restrict__ hp, long long *__restrict__ dbg)
 {
-    unsigned char *slab = smem_raw;                                   // [chunk][column][digit][16]
-    v4i *abuf = reinterpret_cast<v4i *>(smem_raw + kQSlabBytes);      // [2][tile][digit][pair member][lane]
+    unsigned char *slab = smem_raw;                                   // [chunk][column (pitch 160)][digit][16]
+    unsigned short *parts = reinterpret_cast<unsigned short *>(smem_raw + kQSlabBytes); // [hashprint][wave]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, nl = lane & 31;
+    const int kg = lane >> 4, cl = lane & 15;  // this lane's group of 16 k' inside a step; its column (B) / filter (A) in a tile
     const int clip = blockIdx.y;
     const int n0 = blockIdx.x * kQTileN;
     const float *S = sdb + (int64_t)clip * kBins * c;
     const float ref = FROM_T ? tmax[clip] : 0.0f;
-    // the filter digits of half step 0 are on their way while the slab is quantised
-    constexpr int kAPer = kQHalfBytes / 16 / kQThreads; // 3 pieces of 16 bytes per thread and half step
-    v4i areg[kAPer];
+    // the wave's filter digits of the first two steps are on their way while the slab is quantised
+    const v4i *img = fq_image + (size_t)wave * kQSteps * (kQStepBytes / 16) + lane;
+    v4i a[3][3]; // three register sets in turn: the loads of step s + 2 are issued before the products of step s
 #pragma unroll
-    for (int e = 0; e < kAPer; ++e) areg[e] = fq_image[tid + e * kQThreads];
+    for (int d = 0; d < 3; ++d) {
+        a[0][d] = img[d * 64];
+        a[1][d] = img[(kQStepBytes / 16) + d * 64];
+    }
     // slab: one (chunk, column) unit = 16 bins of one column of Du, three digit planes.  The loads of a round (16 bins x
     // the column and its partner 80 on) are all issued before the first value is quantised
     constexpr int kUnits = (kQChunks * kQCols + kQThreads - 1) / kQThreads; // 5
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
         for (int rr = 0; rr < 2; ++rr) {
             const int unit = tid + (r0 + rr) * kQThreads;
             if (r0 + rr >= kUnits || unit >= kQChunks * kQCols) break;
+            const int q = unit / kQCols, col = unit - q * kQCols;
             unsigned w0[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -111,86 +119,88 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
                 w1[e >> 2] |= ((d >> 8) & 255u) << (8 * (e & 3));
                 w2[e >> 2] |= ((d >> 16) & 255u) << (8 * (e & 3));
             }
-            v4i *dst = reinterpret_cast<v4i *>(slab + (size_t)unit * kQUnit);
+            v4i *dst = reinterpret_cast<v4i *>(slab + (size_t)(q * kQPitch + col) * kQUnit);
             dst[0] = v4i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3]};
             dst[1] = v4i{(int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
             dst[2] = v4i{(int)w2[0], (int)w2[1], (int)w2[2], (int)w2[3]};
         }
     }
+    __syncthreads(); // the only barrier before the epilogue: the slab is read-only from here on
+    // tiles of 16 hashprints that hold any (the last workgroup of a clip); the products of the others are skipped
+    const int n_tiles = min(8, (nhp - n0 + 15) / 16);
+    v4i acc[8][5];
 #pragma unroll
-    for (int e = 0; e < kAPer; ++e) abuf[tid + e * kQThreads] = areg[e];
-    __syncthreads();
-    v16i acc[2][5];
+    for (int f = 0; f < 8; ++f)
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+        for (int cls = 0; cls < 5; ++cls) acc[f][cls] = v4i{0, 0, 0, 0};
+    // B operand of (step, tile f): chunk 4 (s & 1) + kg, column 16 f + cl + (s >> 1)
+    const unsigned char *bl = slab + (size_t)(kg * kQPitch + cl) * kQUnit;
+    auto step = [&](int s, const v4i (&aw)[3]) {
+        const unsigned char *bs = bl + (size_t)((4 * (s & 1)) * kQPitch + (s >> 1)) * kQUnit;
 #pragma unroll
-        for (int cl = 0; cl < 5; ++cl) acc[t2][cl] = v16i{0};
-    const bool active = n0 + wave * 32 < nhp; // a wave whose hashprints lie past the clip only helps staging
-    const int colw = wave * 32 + nl;          // this lane's hashprint inside the tile
-    v4i a[2][2][3], b[2][3]; // two sets in turn: one per member of the chunk pair
-    auto fetch = [&](int set, int hs, int m) {
-        const v4i *ab = abuf + (hs & 1) * (kQHalfBytes / 16);
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) a[set][t2][i] = ab[((t2 * 3 + i) * 2 + m) * 64 + lane];
-        const int cc = 2 * (hs & 1) + m, t = hs >> 1;
-        const v4i *bu = reinterpret_cast<const v4i *>(slab + ((size_t)(2 * cc + h) * kQCols + colw + t) * kQUnit);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) b[set][j] = bu[j];
+        for (int f = 0; f < 8; ++f) {
+            if (f < n_tiles) {
+                const v4i *bu = reinterpret_cast<const v4i *>(bs + (size_t)(16 * f) * kQUnit);
+                const v4i b0 = bu[0], b1 = bu[1], b2 = bu[2];
+                // filter digit i times spectrogram digit j goes to accumulator i + j
+                acc[f][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[0], b0, acc[f][0], 0, 0, 0);
+                acc[f][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[0], b1, acc[f][1], 0, 0, 0);
+                acc[f][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[0], b2, acc[f][2], 0, 0, 0);
+                acc[f][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[1], b2, acc[f][3], 0, 0, 0);
+                acc[f][4] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[2], b2, acc[f][4], 0, 0, 0);
+                acc[f][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[1], b0, acc[f][1], 0, 0, 0);
+                acc[f][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[1], b1, acc[f][2], 0, 0, 0);
+                acc[f][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[2], b1, acc[f][3], 0, 0, 0);
+                acc[f][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[2], b0, acc[f][2], 0, 0, 0);
+            }
+        }
     };
-    auto mult = [&](int set) {
-        // the two filter tiles in turn: instructions on the same accumulator (digit products of equal weight) stay apart
+    auto load_a = [&](int s, v4i (&aw)[3]) {
+        if (s < kQSteps) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2)
-                    acc[t2][i + j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[set][t2][i], b[set][j], acc[t2][i + j], 0, 0, 0);
+            for (int d = 0; d < 3; ++d) aw[d] = img[(size_t)s * (kQStepBytes / 16) + d * 64];
+        }
     };
-    for (int hs = 0; hs < kQHalfSteps; ++hs) {
-        if (hs + 1 < kQHalfSteps) { // next half step's filter digits: loads now, LDS writes after this one's matrix instructions
-#pragma unroll
-            for (int e = 0; e < kAPer; ++e) areg[e] = fq_image[(size_t)(hs + 1) * (kQHalfBytes / 16) + tid + e * kQThreads];
+    if (n_tiles > 0) {
+#pragma unroll 1
+        for (int s = 0; s < kQSteps - 1; s += 3) { // 40 steps = 13 x 3 + 1
+            load_a(s + 2, a[2]);
+            step(s, a[0]);
+            load_a(s + 3, a[0]);
+            step(s + 1, a[1]);
+            load_a(s + 4, a[1]);
+            step(s + 2, a[2]);
         }
-        if (active) {
-            fetch(0, hs, 0);
-            fetch(1, hs, 1);
-            mult(0);
-            mult(1);
-        }
-        if (hs + 1 < kQHalfSteps) {
-            v4i *an = abuf + ((hs + 1) & 1) * (kQHalfBytes / 16);
-#pragma unroll
-            for (int e = 0; e < kAPer; ++e) an[tid + e * kQThreads] = areg[e];
-        }
-        __syncthreads();
+        step(kQSteps - 1, a[0]);
     }
-    if (!active) return;
-    // S10q: D = sum_c acc_c 2^(8c); D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-    const int n = n0 + colw;
-    uint64_t bits = 0;
+    // S10q: D = sum_c acc_c 2^(8c); D layout of the 16x16 tile: column (hashprint) = lane & 15, row (filter) = 4 (lane >> 4) + reg
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+    for (int f = 0; f < 8; ++f) {
+        const int n = n0 + 16 * f + cl;
+        unsigned bits = 0; // this wave's 16 filters of hashprint n, filter 16 wave + row at bit 15 - row
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = 32 * t2 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            long long v = acc[t2][4][reg];
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = 4 * kg + reg;
+            long long v = acc[f][4][reg];
 #pragma unroll
-            for (int cl = 3; cl >= 0; --cl) v = v * 256 + acc[t2][cl][reg];
-            bits |= (uint64_t)(v >= 0) << (63 - row);
-            if (dbg && n < nhp) dbg[((int64_t)clip * kFilters + row) * nhp + n] = v;
+            for (int cls = 3; cls >= 0; --cls) v = v * 256 + acc[f][cls][reg];
+            bits |= (unsigned)(v >= 0) << (15 - row);
+            if (dbg && f < n_tiles && n < nhp) dbg[((int64_t)clip * kFilters + 16 * wave + row) * nhp + n] = v;
         }
-    // the two halves of the wave hold complementary rows of the same 32 hashprints
-    const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
-    const unsigned olo = (unsigned)__shfl_xor((int)lo, 32), ohi = (unsigned)__shfl_xor((int)hi, 32);
-    bits |= ((uint64_t)ohi << 32) | olo;
-    if (h == 0 && n < nhp) hp[(int64_t)clip * nhp + n] = bits;
+        // the four lanes of a column hold four filters each
+        bits |= (unsigned)__shfl_xor((int)bits, 16);
+        bits |= (unsigned)__shfl_xor((int)bits, 32);
+        if (kg == 0) parts[(16 * f + cl) * 4 + wave] = (unsigned short)bits;
+    }
+    __syncthreads();
+    if (tid < kQTileN && n0 + tid < nhp) {
+        const unsigned short *p = parts + tid * 4;
+        hp[(int64_t)clip * nhp + n0 + tid] = ((uint64_t)p[0] << 48) | ((uint64_t)p[1] << 32) | ((uint64_t)p[2] << 16) | (uint64_t)p[3];
+    }
 }
 
-// host: the filters' digits as the A operand of v_mfma_i32_32x32x32_i8, [t][pair p][tile][digit][member m][lane][16 bytes]:
-// byte e of lane l = digit of fq[row = 32 tile + (l & 31)][k = 20 bin + t], bin = 32 (2 p + m) + 16 (l >> 5) + e (zero for bin >= 121)
+// host: the filters' digits as the A operand of v_mfma_i32_16x16x64_i8, [wave][step s = 2 t + p][digit][lane][16 bytes]:
+// byte e of lane l = digit of fq[row = 16 wave + (l & 15)][k = 20 bin + t], bin = 64 p + 16 (l >> 4) + e (zero for bin >= 121)
 void pack_filters_q(const float *f, std::vector<int8_t> &image)
 {
     std::vector<int32_t> fq((size_t)kFilters * kFrame);
@@ -200,24 +210,23 @@ void pack_filters_q(const float *f, std::vector<int8_t> &image)
         const int e = m > 0.0f ? 21 - std::ilogb(m) : 0;
         for (int k = 0; k < kFrame; ++k) fq[(size_t)r * kFrame + k] = (int32_t)std::rint(std::ldexp(f[(size_t)k * kFilters + r], e));
     }
-    image.assign((size_t)kQHalfSteps * kQHalfBytes, 0);
-    for (int t = 0; t < kCtx; ++t)
-        for (int p = 0; p < 2; ++p)
-            for (int t2 = 0; t2 < 2; ++t2)
-                for (int m = 0; m < 2; ++m)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 16; ++e) {
-                            const int bin = 32 * (2 * p + m) + 16 * (l >> 5) + e;
-                            if (bin >= kBins) continue;
-                            const int u = fq[(size_t)(32 * t2 + (l & 31)) * kFrame + bin * kCtx + t];
-                            const int d0 = ((u + 128) & 255) - 128, u1 = (u - d0) >> 8, d1 = ((u1 + 128) & 255) - 128, d2 = (u1 - d1) >> 8;
-                            const int d[3] = {d0, d1, d2};
-                            for (int i = 0; i < 3; ++i)
-                                image[(size_t)(2 * t + p) * kQHalfBytes + ((((size_t)t2 * 3 + i) * 2 + m) * 64 + l) * 16 + e] = (int8_t)d[i];
-                        }
+    image.assign((size_t)4 * kQSteps * kQStepBytes, 0);
+    for (int w = 0; w < 4; ++w)
+        for (int t = 0; t < kCtx; ++t)
+            for (int p = 0; p < 2; ++p)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 16; ++e) {
+                        const int bin = 64 * p + 16 * (l >> 4) + e;
+                        if (bin >= kBins) continue;
+                        const int u = fq[(size_t)(16 * w + (l & 15)) * kFrame + bin * kCtx + t];
+                        const int d0 = ((u + 128) & 255) - 128, u1 = (u - d0) >> 8, d1 = ((u1 + 128) & 255) - 128, d2 = (u1 - d1) >> 8;
+                        const int d[3] = {d0, d1, d2};
+                        for (int i = 0; i < 3; ++i)
+                            image[((size_t)w * kQSteps + (2 * t + p)) * kQStepBytes + ((size_t)i * 64 + l) * 16 + e] = (int8_t)d[i];
+                    }
 }
 
-size_t project_q_image_bytes() { return (size_t)kQHalfSteps * kQHalfBytes; }
+size_t project_q_image_bytes() { return (size_t)4 * kQSteps * kQStepBytes; }
 
 // dB terms (d_tmax != NULL) or dB spectrograms -> hashprints [n_clips][c - 99]; d_dbg: NULL, or D [n_clips][64][c - 99] (tests)
 void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float *d_tmax, int n_clips, int c, uint64_t *d_hp,
