@@ -14,6 +14,43 @@ namespace hpfw {
 
 HPFW_DEVICE int pad16(int i) { return i + (i >> 4); }
 
+// Padded positions of the points base + q2 M2 + q M1 of a butterfly (base = blk LEN + j0, j0 < M2) without a shift and an
+// add per access: where the spare slots fall is known at compile time in most groups, and the position is then one
+// per-thread value plus a constant the LDS instruction carries as its offset.
+//   FOLD:  LEN a multiple of 16 and M2 a multiple or a divisor of 16 -- (j0 + c) >> 4 = (j0 >> 4) + (c >> 4) for every
+//          offset c (a multiple of M2): position = pad16(base) + c + (c >> 4);
+//   ROWS:  only M1 a multiple of 16 -- one padded position per q2, plus q (M1 + M1 / 16);
+//   else the general form.
+template <int LEN, int M1, int M2, int R2>
+struct PadAt {
+    static constexpr bool FOLD = LEN % 16 == 0 && (M2 % 16 == 0 || 16 % M2 == 0);
+    static constexpr bool ROWS = !FOLD && M1 % 16 == 0;
+    int base;
+    int p[FOLD ? 1 : (ROWS ? R2 : 1)];
+    HPFW_DEVICE_MEMBER explicit PadAt(int b) : base(b)
+    {
+        if constexpr (FOLD) {
+            p[0] = pad16(b);
+        } else if constexpr (ROWS) {
+#pragma unroll
+            for (int q2 = 0; q2 < R2; ++q2) p[q2] = pad16(b + q2 * M2);
+        } else {
+            p[0] = 0;
+        }
+    }
+    HPFW_DEVICE_MEMBER int operator()(int q2, int q) const // the position of base + q2 M2 + q M1
+    {
+        if constexpr (FOLD) {
+            const int c = q2 * M2 + q * M1;
+            return p[0] + c + (c >> 4);
+        } else if constexpr (ROWS) {
+            return p[q2] + q * (M1 + M1 / 16);
+        } else {
+            return pad16(base + q2 * M2 + q * M1);
+        }
+    }
+};
+
 template <int N_>
 struct Size {
     static constexpr int N = N_;
@@ -50,6 +87,7 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
     for (int b = tid; b < NB; b += nthreads) {
         const int blk = b / M2, j0 = b % M2;
         const int base = blk * LEN + j0;
+        const PadAt<LEN, M1, M2, R2> at(base);
         cf e[R1][R2];
 #pragma unroll
         for (int q2 = 0; q2 < R2; ++q2) {
@@ -57,17 +95,17 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
             cf u[R1];
             if (PRUNE) {
                 cf u0 = {0.0f, 0.0f};
-                if (j < nz) u0 = lds[pad16(j)];
+                if (j < nz) u0 = lds[at(q2, 0)]; // LEN = N: blk = 0 and base + q2 M2 = j
 #pragma unroll
                 for (int s = 0; s < R1; ++s) u[s] = u0;
             } else {
 #pragma unroll
-                for (int q = 0; q < R1; ++q) u[q] = lds[pad16(base + q2 * M2 + q * M1)];
+                for (int q = 0; q < R1; ++q) u[q] = lds[at(q2, q)];
                 Dft<R1>::run(u);
             }
             e[0][q2] = u[0];
 #pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), NB, b));
+            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), M2, j0));
         }
 #pragma unroll
         for (int s = 0; s < R1; ++s) {
@@ -76,26 +114,68 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
 #pragma unroll
                 for (int q2 = 0; q2 < R2; ++q2) v[q2] = e[s][q2];
                 Dft<R2>::run(v);
-                lds[pad16(base + s * M1)] = v[0];
+                lds[at(0, s)] = v[0];
 #pragma unroll
                 for (int s2 = 1; s2 < R2; ++s2)
-                    lds[pad16(base + s * M1 + s2 * M2)] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), NB, b));
+                    lds[at(s2, s)] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), M2, j0));
             } else {
-                lds[pad16(base + s * M1)] = e[s][0];
+                lds[at(0, s)] = e[s][0];
             }
         }
     }
 }
 
-// inverse butterfly of the specification: swap, forward codelet, swap
+// inverse butterfly of the specification: swap, forward codelet, swap.  For radix 2, 3 and 4 the same operations on the
+// same values, written without the swaps (which cost register moves between the packed operations): multiplying by +i
+// instead of -i, x - (-y) for x + y and x + (-y) for x - y, which round identically.
+template <int R>
+struct Idft {
+    HPFW_DEVICE_STATIC void run(cf *u)
+    {
+#pragma unroll
+        for (int q = 0; q < R; ++q) u[q] = {u[q].i, u[q].r};
+        Dft<R>::run(u);
+#pragma unroll
+        for (int q = 0; q < R; ++q) u[q] = {u[q].i, u[q].r};
+    }
+};
+template <>
+struct Idft<2> {
+    HPFW_DEVICE_STATIC void run(cf *u) { Dft<2>::run(u); }
+};
+template <>
+struct Idft<3> {
+    HPFW_DEVICE_STATIC void run(cf *u)
+    {
+        const float s = 0.86602540378443864676f;
+        cf t1 = c_add(u[1], u[2]);
+        cf d = c_sub(u[1], u[2]);
+        cf m1 = c_fma_s(-0.5f, t1, u[0]);
+        cf jd = {-(s * d.i), s * d.r};
+        u[0] = c_add(u[0], t1);
+        u[1] = c_add(m1, jd);
+        u[2] = c_sub(m1, jd);
+    }
+};
+template <>
+struct Idft<4> {
+    HPFW_DEVICE_STATIC void run(cf *u)
+    {
+        cf t0 = c_add(u[0], u[2]);
+        cf t1 = c_sub(u[0], u[2]);
+        cf t2 = c_add(u[1], u[3]);
+        cf d = c_sub(u[1], u[3]);
+        cf t3 = {-d.i, d.r}; // +i d
+        u[0] = c_add(t0, t2);
+        u[2] = c_sub(t0, t2);
+        u[1] = c_add(t1, t3);
+        u[3] = c_sub(t1, t3);
+    }
+};
 template <int R>
 HPFW_DEVICE void idft(cf *u)
 {
-#pragma unroll
-    for (int q = 0; q < R; ++q) u[q] = {u[q].i, u[q].r};
-    Dft<R>::run(u);
-#pragma unroll
-    for (int q = 0; q < R; ++q) u[q] = {u[q].i, u[q].r};
+    Idft<R>::run(u);
 }
 
 // ---- one fused group of the inverse DIT: radix R2 (or 1) at sub-length LEN / R1, then R1 ----
@@ -110,14 +190,15 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
     for (int b = tid; b < NB; b += nthreads) {
         const int blk = b / M2, j0 = b % M2;
         const int base = blk * LEN + j0;
+        const PadAt<LEN, M1, M2, R2> at(base);
         cf o[R1][R2];
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
             cf v[R2];
-            v[0] = lds[pad16(base + q * M1)];
+            v[0] = lds[at(0, q)];
 #pragma unroll
             for (int q2 = 1; q2 < R2; ++q2)
-                v[q2] = c_mulc(lds[pad16(base + q * M1 + q2 * M2)], tw_entry(gt, (R1 - 1) * R2 + (q2 - 1), NB, b));
+                v[q2] = c_mulc(lds[at(q2, q)], tw_entry(gt, (R1 - 1) * R2 + (q2 - 1), M2, j0));
             if constexpr (R2 > 1) idft<R2>(v);
 #pragma unroll
             for (int s2 = 0; s2 < R2; ++s2) o[q][s2] = v[s2];
@@ -128,12 +209,12 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
             cf u[R1];
             u[0] = o[0][s2];
 #pragma unroll
-            for (int q = 1; q < R1; ++q) u[q] = c_mulc(o[q][s2], tw_entry(gt, s2 * (R1 - 1) + (q - 1), NB, b));
+            for (int q = 1; q < R1; ++q) u[q] = c_mulc(o[q][s2], tw_entry(gt, s2 * (R1 - 1) + (q - 1), M2, j0));
             idft<R1>(u);
 #pragma unroll
             for (int s = 0; s < R1; ++s) {
                 const int idx = blk * LEN + j + s * M1;
-                if (idx < keep) lds[pad16(idx)] = u[s];
+                if (idx < keep) lds[at(s2, s)] = u[s];
             }
         }
     }
@@ -152,13 +233,15 @@ HPFW_DEVICE void mid_group(Lds &lds, const cf *__restrict__ mt, int tid, int nth
     constexpr int NB = P::N / LEN;
     for (int b = tid; b < NB; b += nthreads) {
         const int base = b * LEN;
+        // the block's LEN points start at a multiple of LEN: LEN a multiple of 16, or a divisor (no spare slot inside the block)
+        const PadAt<(LEN % 16 == 0 || 16 % LEN == 0) ? 16 : LEN, M1, M2, R2> at(base);
         cf e[R1][R2];
         // forward: radix R1 over q at j = q2 (j0 = 0), then radix R2
 #pragma unroll
         for (int q2 = 0; q2 < R2; ++q2) {
             cf u[R1];
 #pragma unroll
-            for (int q = 0; q < R1; ++q) u[q] = lds[pad16(base + q2 * M2 + q * M1)];
+            for (int q = 0; q < R1; ++q) u[q] = lds[at(q2, q)];
             Dft<R1>::run(u);
             e[0][q2] = u[0];
 #pragma unroll
@@ -202,7 +285,7 @@ HPFW_DEVICE void mid_group(Lds &lds, const cf *__restrict__ mt, int tid, int nth
             for (int q = 1; q < R1; ++q) u[q] = c_mulc(e[q][s2], mt[s2 * (R1 - 1) + (q - 1)]);
             idft<R1>(u);
 #pragma unroll
-            for (int s = 0; s < R1; ++s) lds[pad16(base + s2 + s * M1)] = u[s];
+            for (int s = 0; s < R1; ++s) lds[at(s2, s)] = u[s];
         }
     }
 }

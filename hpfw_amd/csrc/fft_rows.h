@@ -64,7 +64,7 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
         }
         const int j0 = b - blk * m2;
         const int base = blk * len + j0;
-        const int TWB = b;
+        const int TWB = j0, TWN = m2; // the entries depend on j0 only: the table holds the m2 butterflies of one block
         cf e[R1][R2];
 #pragma unroll
         for (int q2 = 0; q2 < R2; ++q2) {
@@ -74,7 +74,7 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
             Dft<R1>::run(u);
             e[0][q2] = u[0];
 #pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), nb, TWB));
+            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), TWN, TWB));
         }
 #pragma unroll
         for (int s = 0; s < R1; ++s) {
@@ -86,7 +86,7 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
                 lds[base + s * m1] = v[0];
 #pragma unroll
                 for (int s2 = 1; s2 < R2; ++s2)
-                    lds[base + s * m1 + s2 * m2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), nb, TWB));
+                    lds[base + s * m1 + s2 * m2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), TWN, TWB));
             } else {
                 lds[base + s * m1] = e[s][0];
             }
@@ -109,7 +109,7 @@ HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restr
     if (tid >= nb) return;
     const int blk = tid / m2, j0 = tid - blk * m2;
     const int base = blk * len + j0;
-    const int TWB = tid;
+    const int TWB = j0, TWN = m2;
     cf e[R1][R2];
 #pragma unroll
     for (int q2 = 0; q2 < R2; ++q2) {
@@ -119,7 +119,7 @@ HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restr
         Dft<R1>::run(u);
         e[0][q2] = u[0];
 #pragma unroll
-        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), nb, TWB));
+        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), TWN, TWB));
     }
 #pragma unroll
     for (int s = 0; s < R1; ++s) {
@@ -130,7 +130,7 @@ HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restr
             Dft<R2>::run(v);
             out[s * R2] = v[0];
 #pragma unroll
-            for (int s2 = 1; s2 < R2; ++s2) out[s * R2 + s2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), nb, TWB));
+            for (int s2 = 1; s2 < R2; ++s2) out[s * R2 + s2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), TWN, TWB));
         } else {
             out[s] = e[s][0];
         }
@@ -162,7 +162,7 @@ HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__rest
     if (tid >= nb) return;
     // the last group's sub-length is R1 R2: j0 = 0 for every butterfly, so its twiddles are the same for all of them --
     // butterfly 0's entries, read through a wave-uniform address (scalar loads) instead of one vector load per entry
-    const int TWB = 0;
+    const int TWB = 0, TWN = 1;
     cf e[R1][R2];
 #pragma unroll
     for (int q2 = 0; q2 < R2; ++q2) {
@@ -172,7 +172,7 @@ HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__rest
         Dft<R1>::run(u);
         e[0][q2] = u[0];
 #pragma unroll
-        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), nb, TWB));
+        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), TWN, TWB));
     }
 #pragma unroll
     for (int s = 0; s < R1; ++s) {
@@ -183,7 +183,7 @@ HPFW_DEVICE void rows_last_compute(Lds &lds, const RowsArgs &a, const cf *__rest
             Dft<R2>::run(v);
             out[s] = v[0];
 #pragma unroll
-            for (int s2 = 1; s2 < R2; ++s2) out[s + R1 * s2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), nb, TWB));
+            for (int s2 = 1; s2 < R2; ++s2) out[s + R1 * s2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), TWN, TWB));
         } else {
             out[s] = e[s][0];
         }

@@ -131,16 +131,18 @@ int64_t chirpz_length(int64_t need)
 // entry (r1-1) r2 + (s2-1) = T_n[ts2 j0 s2], with j0 = b mod m2.  The inverse DIT group uses the
 // same values (conjugated by the kernel).
 void append_group_twiddles(const std::vector<HostCf> &tw, int64_t n, int64_t len, int r1, int r2,
-                           std::vector<HostCf> &out, int64_t nb_out)
+                           std::vector<HostCf> &out)
 {
-    const int64_t m1 = len / r1, m2 = m1 / r2, ts1 = n / len, ts2 = n / m1, nb = nb_out ? nb_out : n / (r1 * r2);
+    // the entries of butterfly b depend on j0 = b mod m2 only: the table holds the m2 butterflies of one block (the inner
+    // groups' tables are a few KB and stay in the L1 of every CU)
+    const int64_t m1 = len / r1, m2 = m1 / r2, ts1 = n / len, ts2 = n / m1, nb = m2;
     const size_t off = out.size();
     const int entries = (r1 - 1) * r2 + (r2 - 1);
     // entry e of butterfly b at [e >> 1][b][e & 1] (device_math.h tw_entry); an odd count leaves the last half empty
     out.resize(off + (size_t)((entries + 1) / 2) * 2 * nb, HostCf{0.0f, 0.0f});
     auto at = [&](int e, int64_t b) -> HostCf & { return out[off + ((size_t)(e >> 1) * nb + b) * 2 + (e & 1)]; };
     for (int64_t b = 0; b < nb; ++b) {
-        const int64_t j0 = b % m2;
+        const int64_t j0 = b;
         for (int q2 = 0; q2 < r2; ++q2)
             for (int s = 1; s < r1; ++s) at(q2 * (r1 - 1) + (s - 1), b) = tw[(size_t)(ts1 * (j0 + q2 * m2) * s)];
         for (int s2 = 1; s2 < r2; ++s2) at((r1 - 1) * r2 + (s2 - 1), b) = tw[(size_t)(ts2 * j0 * s2)];
@@ -484,17 +486,16 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
                 ++bc.outer;
             }
             bc.len0 = (int)len;
-            const int64_t blk = len; // butterfly tables cover one block (the whole transform when it fits)
             int g = 0;
             for (;;) {
                 const int r1 = next_radix(len);
                 const int r2 = len / r1 > 1 ? next_radix(len / r1) : 1;
-                if (len / (r1 * r2) == 1) {
+                const int64_t rest = len / (r1 * r2);
+                if (rest == 1) {
                     std::vector<HostCf> tmp;
-                    append_group_twiddles(bc.tw, ps, len, r1, r2, tmp, blk / (r1 * r2));
-                    const int64_t nb = blk / (r1 * r2);
+                    append_group_twiddles(bc.tw, ps, len, r1, r2, tmp);
                     bc.mid_off = (int)bc.gtw.size();
-                    for (int e = 0; e < (r1 - 1) * r2; ++e) bc.gtw.push_back(tmp[((size_t)(e >> 1) * nb) * 2 + (e & 1)]); // butterfly 0's entries
+                    for (int e = 0; e < (r1 - 1) * r2; ++e) bc.gtw.push_back(tmp[(size_t)e]); // m2 = 1: one butterfly, entries in order
                     break;
                 }
                 if (g >= 4) {
@@ -502,7 +503,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
                     return;
                 }
                 bc.goff[g++] = (int)bc.gtw.size();
-                append_group_twiddles(bc.tw, ps, len, r1, r2, bc.gtw, blk / (r1 * r2));
+                append_group_twiddles(bc.tw, ps, len, r1, r2, bc.gtw);
                 len /= r1 * r2;
             }
         }

@@ -96,8 +96,8 @@ void twiddle_d(int64_t m, int64_t n, double &re, double &im);
 // mixed-radix digit reversal of the DIF pass list
 int64_t digit_pos(int64_t k, int64_t n, const std::vector<int> &radix);
 bool make_radix_list(int64_t n, std::vector<int> &radix);
-// nb_out > 0: only the first nb_out butterflies (the table of one block of a larger transform)
+// the table of one fused group: entry e of the butterflies j0 = 0 .. m2 - 1 of a block (device_math.h tw_entry)
 void append_group_twiddles(const std::vector<HostCf> &tw, int64_t n, int64_t len, int r1, int r2,
-                           std::vector<HostCf> &out, int64_t nb_out = 0);
+                           std::vector<HostCf> &out);
 
 } // namespace hpfw

@@ -1,12 +1,11 @@
 #!/bin/bash
-# extraction-only timing: bench.py's JSON reduced to the per-kernel line
+# kernel times of the extraction step, twice (one box): tools/quick_bench.sh [reps]
 cd "$(dirname "$0")/.."
-timeout -k 10 600 python bench.py --no-cpu-baseline --no-search "$@" > gpurun_out/qb.log 2> gpurun_out/qb.err
-python3 - <<'PY'
-import json
-for ln in open('gpurun_out/qb.log'):
+for rep in $(seq ${1:-2}); do
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-search --no-pcie --no-any-length --no-learn --no-f32-chain --no-ffi --steps 5 --warmup 2 2>/dev/null | python3 -c "
+import json,sys
+for ln in sys.stdin:
     if ln.startswith('{'):
-        d = json.loads(ln)
-        print(d['clips_per_s'], d['ms_per_step'], d['kernel_ms_one_pass'], d['roofline']['frac'], d.get('parity'))
-PY
-tail -3 gpurun_out/qb.err
+        d=json.loads(ln); print(d['ms_per_step'], d['kernel_ms_one_pass'], d.get('parity'))
+"
+done
