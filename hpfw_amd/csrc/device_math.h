@@ -25,8 +25,18 @@ HPFW_DEVICE cf tw_entry(const cf *__restrict__ gt, int e, int nb, int b)
     return (e & 1) ? p.b : p.a;
 }
 
+// The complex helpers.  Each is a fixed sequence of IEEE operations (stated by the scalar form, which is what the host-side
+// emulation of tests/emu compiles); on the GPU the same operations are issued as packed instructions on the (Re, Im) register
+// pair -- v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 round each half exactly as the scalar instruction does, and their
+// operand-select and negate modifiers do the swaps and sign changes of a rotation by +-i or a complex product for free.
+// Left to itself the compiler pairs values across butterflies and pays for it in register moves: about twice the
+// instructions per fused group.
+#if defined(HPFW_SIMT_EMU)
 HPFW_DEVICE cf c_add(cf a, cf b) { return {a.r + b.r, a.i + b.i}; }
 HPFW_DEVICE cf c_sub(cf a, cf b) { return {a.r - b.r, a.i - b.i}; }
+// a + (-i) d and a - (-i) d
+HPFW_DEVICE cf c_add_mi(cf a, cf d) { return {a.r + d.i, a.i - d.r}; }
+HPFW_DEVICE cf c_sub_mi(cf a, cf d) { return {a.r - d.i, a.i + d.r}; }
 // a * w
 HPFW_DEVICE cf c_mul(cf a, cf w)
 {
@@ -41,13 +51,58 @@ HPFW_DEVICE cf c_mulc(cf a, cf w)
     float q = a.r * w.i;
     return {HPFW_FMAF(a.r, w.r, p), HPFW_FMAF(a.i, w.r, -q)};
 }
-// -i * a
-HPFW_DEVICE cf c_mulmi(cf a) { return {a.i, -a.r}; }
 HPFW_DEVICE cf c_fma_s(float s, cf a, cf b)
 {
     return {HPFW_FMAF(s, a.r, b.r), HPFW_FMAF(s, a.i, b.i)};
 }
 HPFW_DEVICE cf c_scale(float s, cf a) { return {s * a.r, s * a.i}; }
+#else
+typedef float v2f __attribute__((ext_vector_type(2)));
+HPFW_DEVICE v2f c_pair(cf a) { return v2f{a.r, a.i}; }
+HPFW_DEVICE cf c_unpair(v2f v) { return cf{v.x, v.y}; }
+#define HPFW_PK_BINARY(name, ins)                                                         \
+    HPFW_DEVICE cf name(cf a, cf b)                                                       \
+    {                                                                                     \
+        v2f o;                                                                            \
+        asm(ins : "=v"(o) : "v"(c_pair(a)), "v"(c_pair(b)));                              \
+        return c_unpair(o);                                                               \
+    }
+HPFW_PK_BINARY(c_add, "v_pk_add_f32 %0, %1, %2")
+HPFW_PK_BINARY(c_sub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")
+// a + (-i) d = (a.r + d.i, a.i - d.r) and a - (-i) d = (a.r - d.i, a.i + d.r)
+HPFW_PK_BINARY(c_add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
+HPFW_PK_BINARY(c_sub_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
+#undef HPFW_PK_BINARY
+// a * w: (p, q) = (a.i w.i, a.i w.r); (fma(a.r, w.r, -p), fma(a.r, w.i, q))
+HPFW_DEVICE cf c_mul(cf a, cf w)
+{
+    v2f t, o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(c_pair(a)), "v"(c_pair(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(o) : "v"(c_pair(a)), "v"(c_pair(w)), "v"(t));
+    return c_unpair(o);
+}
+// a * conj(w): (p, q) = (a.i w.i, a.r w.i); (fma(a.r, w.r, p), fma(a.i, w.r, -q))
+HPFW_DEVICE cf c_mulc(cf a, cf w)
+{
+    v2f t, o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t) : "v"(c_pair(a)), "v"(c_pair(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(o) : "v"(c_pair(a)), "v"(c_pair(w)), "v"(t));
+    return c_unpair(o);
+}
+// s real (a compile-time constant at every call: it sits in a scalar register pair, both halves read from the low word)
+HPFW_DEVICE cf c_fma_s(float s, cf a, cf b)
+{
+    v2f o;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(o) : "s"(v2f{s, s}), "v"(c_pair(a)), "v"(c_pair(b)));
+    return c_unpair(o);
+}
+HPFW_DEVICE cf c_scale(float s, cf a)
+{
+    v2f o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(o) : "s"(v2f{s, s}), "v"(c_pair(a)));
+    return c_unpair(o);
+}
+#endif
 
 // ---- forward DFT butterflies (sign -), in place on u[0..R) -------------------------------
 template <int R>
@@ -71,10 +126,10 @@ struct Dft<3> {
         cf t1 = c_add(u[1], u[2]);
         cf d = c_sub(u[1], u[2]);
         cf m1 = c_fma_s(-0.5f, t1, u[0]);
-        cf jd = {s * d.i, -(s * d.r)};
+        cf sd = c_scale(s, d); // m1 +- (-i) s d
         u[0] = c_add(u[0], t1);
-        u[1] = c_add(m1, jd);
-        u[2] = c_sub(m1, jd);
+        u[1] = c_add_mi(m1, sd);
+        u[2] = c_sub_mi(m1, sd);
     }
 };
 
@@ -85,11 +140,11 @@ struct Dft<4> {
         cf t0 = c_add(u[0], u[2]);
         cf t1 = c_sub(u[0], u[2]);
         cf t2 = c_add(u[1], u[3]);
-        cf t3 = c_mulmi(c_sub(u[1], u[3]));
+        cf d = c_sub(u[1], u[3]);
         u[0] = c_add(t0, t2);
         u[2] = c_sub(t0, t2);
-        u[1] = c_add(t1, t3);
-        u[3] = c_sub(t1, t3);
+        u[1] = c_add_mi(t1, d); // t1 +- (-i) d
+        u[3] = c_sub_mi(t1, d);
     }
 };
 
@@ -105,12 +160,11 @@ struct Dft<5> {
         cf p2 = c_fma_s(c1, a2, c_fma_s(c2, a1, u[0]));
         cf q1 = c_fma_s(s2, b2, c_scale(s1, b1));
         cf q2 = c_fma_s(-s1, b2, c_scale(s2, b1));
-        cf jq1 = c_mulmi(q1), jq2 = c_mulmi(q2);
         u[0] = c_add(c_add(u[0], a1), a2);
-        u[1] = c_add(p1, jq1);
-        u[4] = c_sub(p1, jq1);
-        u[2] = c_add(p2, jq2);
-        u[3] = c_sub(p2, jq2);
+        u[1] = c_add_mi(p1, q1); // p +- (-i) q
+        u[4] = c_sub_mi(p1, q1);
+        u[2] = c_add_mi(p2, q2);
+        u[3] = c_sub_mi(p2, q2);
     }
 };
 
@@ -130,14 +184,13 @@ struct Dft<7> {
         cf q1 = c_fma_s(s3, b3, c_fma_s(s2, b2, c_scale(s1, b1)));
         cf q2 = c_fma_s(-s1, b3, c_fma_s(-s3, b2, c_scale(s2, b1)));
         cf q3 = c_fma_s(s2, b3, c_fma_s(-s1, b2, c_scale(s3, b1)));
-        cf jq1 = c_mulmi(q1), jq2 = c_mulmi(q2), jq3 = c_mulmi(q3);
         u[0] = c_add(c_add(c_add(u[0], a1), a2), a3);
-        u[1] = c_add(p1, jq1);
-        u[6] = c_sub(p1, jq1);
-        u[2] = c_add(p2, jq2);
-        u[5] = c_sub(p2, jq2);
-        u[3] = c_add(p3, jq3);
-        u[4] = c_sub(p3, jq3);
+        u[1] = c_add_mi(p1, q1); // p +- (-i) q
+        u[6] = c_sub_mi(p1, q1);
+        u[2] = c_add_mi(p2, q2);
+        u[5] = c_sub_mi(p2, q2);
+        u[3] = c_add_mi(p3, q3);
+        u[4] = c_sub_mi(p3, q3);
     }
 };
 

@@ -151,10 +151,10 @@ struct Idft<3> {
         cf t1 = c_add(u[1], u[2]);
         cf d = c_sub(u[1], u[2]);
         cf m1 = c_fma_s(-0.5f, t1, u[0]);
-        cf jd = {-(s * d.i), s * d.r};
+        cf sd = c_scale(s, d); // m1 +- i s d
         u[0] = c_add(u[0], t1);
-        u[1] = c_add(m1, jd);
-        u[2] = c_sub(m1, jd);
+        u[1] = c_sub_mi(m1, sd);
+        u[2] = c_add_mi(m1, sd);
     }
 };
 template <>
@@ -165,11 +165,10 @@ struct Idft<4> {
         cf t1 = c_sub(u[0], u[2]);
         cf t2 = c_add(u[1], u[3]);
         cf d = c_sub(u[1], u[3]);
-        cf t3 = {-d.i, d.r}; // +i d
         u[0] = c_add(t0, t2);
         u[2] = c_sub(t0, t2);
-        u[1] = c_add(t1, t3);
-        u[3] = c_sub(t1, t3);
+        u[1] = c_sub_mi(t1, d); // t1 +- i d
+        u[3] = c_add_mi(t1, d);
     }
 };
 template <int R>
