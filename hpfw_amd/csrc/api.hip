@@ -130,6 +130,12 @@ struct hpfw_gpu {
     float *d_cov = nullptr;
     float *d_cov_ws = nullptr; // scratch of the covariance kernels
     void *d_cqwork = nullptr;  // chirp-z bands too long for the LDS (k_cq_big.hip)
+    // the size classes of the chirp-z stage run side by side (run_front): their workgroups differ in LDS footprint and
+    // one class alone leaves part of every CU's LDS and issue slots unused
+    static constexpr int kCqSide = 4;
+    hipStream_t cq_side[kCqSide] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t cq_fork = nullptr, cq_join[kCqSide] = {nullptr, nullptr, nullptr, nullptr};
+    int cq_concurrent = 1; // HPFW_CQ_SERIAL=1 in the environment at creation: one class after the other on the caller's stream
     void *d_topk_scratch = nullptr;
     size_t topk_scratch_cap = 0;
     // Mel front-end: tables (owned by mel_owned), workspaces
@@ -575,12 +581,42 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
     float *mm = (float *)h->ws[4] + (size_t)slot * 121 * hpfw::kCqMaxWaves; // this pass's wave maxima
     int rc;
     if ((rc = run_forward(h, dp, d_pcm, nb, x, s))) return rc;
-    for (const hpfw::CqClassDev &cd : dp->cls) {
+    {
+        // fork: classes that run in LDS alone go to the side streams in turn (the caller's stream takes one too), largest
+        // first -- dp->cls is in ascending order of size; classes with passes through the shared global workspace stay
+        // on the caller's stream.  join: the caller's stream waits for every side stream used.
         Timed t(h, K_CQ, s);
-        if (cd.outer)
-            hpfw::launch_cq_big_class(dp->cq, cd, x, nb, (cf *)h->d_cqwork, mag, mm, true, s);
-        else
-            hpfw::launch_cq_class(dp->cq, cd, x, nb, mag, mm, true, s);
+        int n_lds = 0;
+        for (const hpfw::CqClassDev &cd : dp->cls) n_lds += cd.outer ? 0 : 1;
+        const bool fork = h->cq_concurrent && n_lds > 1;
+        if (fork && !h->cq_fork) {
+            bool ok = hipEventCreateWithFlags(&h->cq_fork, hipEventDisableTiming) == hipSuccess;
+            for (int k = 0; k < hpfw_gpu::kCqSide && ok; ++k)
+                ok = hipStreamCreateWithFlags(&h->cq_side[k], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&h->cq_join[k], hipEventDisableTiming) == hipSuccess;
+            if (!ok) return fail(HPFW_E_HIP, "streams of the chirp-z classes");
+        }
+        if (fork) {
+            HIP_TRY(hipEventRecord(h->cq_fork, s));
+            for (int k = 0; k < hpfw_gpu::kCqSide; ++k) HIP_TRY(hipStreamWaitEvent(h->cq_side[k], h->cq_fork, 0));
+        }
+        unsigned used = 0;
+        int turn = 0;
+        for (size_t ci = dp->cls.size(); ci-- > 0;) {
+            const hpfw::CqClassDev &cd = dp->cls[ci];
+            if (cd.outer) {
+                hpfw::launch_cq_big_class(dp->cq, cd, x, nb, (cf *)h->d_cqwork, mag, mm, true, s);
+                continue;
+            }
+            const int lane = fork ? turn++ % (hpfw_gpu::kCqSide + 1) : 0; // 0: the caller's stream
+            if (lane) used |= 1u << (lane - 1);
+            hpfw::launch_cq_class(dp->cq, cd, x, nb, mag, mm, true, lane ? h->cq_side[lane - 1] : s);
+        }
+        for (int k = 0; k < hpfw_gpu::kCqSide; ++k)
+            if (used >> k & 1u) {
+                HIP_TRY(hipEventRecord(h->cq_join[k], h->cq_side[k]));
+                HIP_TRY(hipStreamWaitEvent(s, h->cq_join[k], 0));
+            }
     }
     if ((rc = check_launch("cq_chirpz"))) return rc;
     {
@@ -638,6 +674,7 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     HIP_TRY(hipSetDevice(device));
     auto *h = new hpfw_gpu();
     h->device = device;
+    if (std::getenv("HPFW_CQ_SERIAL")) h->cq_concurrent = 0;
     if (const char *e = std::getenv("HPFW_PROJECTION")) // "f32": handles start with the f32 fma chain (hpfw_gpu_set_projection(h, 0))
         h->projection = std::strcmp(e, "f32") == 0 ? 0 : 1;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
@@ -678,6 +715,11 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
         if (h->stage_consumed[b]) (void)hipEventDestroy(h->stage_consumed[b]);
     }
     if (h->stage_hp) (void)hipFree(h->stage_hp);
+    for (int k = 0; k < hpfw_gpu::kCqSide; ++k) {
+        if (h->cq_side[k]) (void)hipStreamDestroy(h->cq_side[k]);
+        if (h->cq_join[k]) (void)hipEventDestroy(h->cq_join[k]);
+    }
+    if (h->cq_fork) (void)hipEventDestroy(h->cq_fork);
     if (h->stage_copy) (void)hipStreamDestroy(h->stage_copy);
     if (h->stage_comp) (void)hipStreamDestroy(h->stage_comp);
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);

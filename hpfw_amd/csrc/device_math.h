@@ -21,7 +21,9 @@ struct alignas(16) cf2 {
 };
 HPFW_DEVICE cf tw_entry(const cf *__restrict__ gt, int e, int nb, int b)
 {
-    const cf2 p = reinterpret_cast<const cf2 *>(gt)[(e >> 1) * nb + b];
+    // (an unsigned 32-bit index: the load then takes the table's address from scalar registers and the index as its
+    // 32-bit offset, instead of a 64-bit address computed with two adds per entry)
+    const cf2 p = reinterpret_cast<const cf2 *>(gt)[(unsigned)((e >> 1) * nb + b)];
     return (e & 1) ? p.b : p.a;
 }
 
