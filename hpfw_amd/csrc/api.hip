@@ -1743,12 +1743,13 @@ int hpfw_gpu_search_topk_device(hpfw_gpu *h, const uint64_t *d_q_hp, const int64
         const bool few = (!mfma || std::getenv("HPFW_SEARCH_SHIFT")) && !std::getenv("HPFW_SEARCH_POPC") && k_max > 0 && n_max > 0 &&
                          hpfw::hamming_shift_lds_bytes((int)k_max) <= 160 * 1024;
         if (few) { // a handful of queries: one launch each, the tile rows are shifts of the query
+            if ((rc = ensure((void **)&h->d_qa, &h->qa_cap, hpfw::hamming_shift_image_bytes((int)k_max)))) return rc;
             Timed t(h, K_SCAN, s);
             for (int i = 0; i < ng; ++i) {
                 const int kq = (int)(q_off[g0 + i + 1] - q_off[g0 + i]);
                 if (kq <= 0) continue;
                 hpfw::launch_hamming_shift(h->d_db, h->d_db_off, (int)n_clips, (int)std::max<int64_t>(n_max - std::min<int64_t>(kq, n_max) + 1, 1),
-                                           d_q_hp + q_off[g0 + i], kq, h->d_best + (size_t)i * n_clips, s);
+                                           d_q_hp + q_off[g0 + i], kq, h->d_qa, h->d_best + (size_t)i * n_clips, s);
             }
         } else if (mfma && n_max > 0) {
             gk.assign((size_t)(ng + 31) / 32 * 2, 0); // per group: longest query, shortest non-empty query

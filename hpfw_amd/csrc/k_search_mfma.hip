@@ -274,27 +274,78 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
 // ---- one query (or a few, one launch each): the rows of the MFMA tile are 32 shifts of the query ----
 // acc(m, n) = sum_j <Q[j - m], R[t0 + 32 n + j]> = the dot product at offset t0 + 32 n + m, so one tile is
 // 1024 consecutive offsets of one clip and every row does useful work (a tile of hamming_mfma_kernel
-// would carry 31 rows of padding).  Workgroup = one tile; its four waves split the k + 31 steps and
+// would carry 31 rows of padding).  Workgroup = TILES tiles; its waves split the k + 31 steps and
 // add their accumulators through LDS.  The clip window is stored transposed (slot i at row i mod 32)
 // so that the columns' operands, 32 slots apart, are read from consecutive addresses.
+// The query operand never touches LDS: row m of step j + 1 is row m - 1 of step j, so a wave keeps the operand in four
+// registers and moves it down one lane per step (DPP wave_shr:1), with the step's new hashprint entering at row 0 of
+// both halves of K from the query's expanded image in global memory (one 16-byte load per lane and step, two distinct
+// addresses per wave).  One LDS read per matrix instruction remains (the window's column operand), and the LDS holds
+// nothing but the window: two workgroups share a CU for queries up to 5 s, one stages while the other multiplies.
 struct SearchShiftArgs {
     const uint64_t *db;
     const int64_t *db_off;
     int n_clips;
-    const uint64_t *q; // the query's hashprints (device)
-    int k;             // its length
+    const v4i *qexp;   // [2][k + 63]: slot i = half h of Q[i - 32] expanded (expand32p), zeros outside the query
+    int k;             // the query's length
     uint64_t *best;    // [n_clips], initialised to ~0
-    int chunks;        // tiles (of 1024 offsets) per clip
+    int chunks;        // workgroups (of 1024 TILES offsets) per clip
     int w32;           // row stride of the transposed window (odd)
 };
 
-// TILES tiles of 1024 offsets per workgroup share the query operand of every step (one LDS read for TILES matrix
-// instructions); WAVES waves split the steps.
+// 32 bits -> 32 E2M1 nibbles (0 -> +1.0 = 0x2, 1 -> -1.0 = 0xA) by byte permutes: a selector byte holds one 2-bit field
+// of the word and picks the byte with its two nibbles out of a four-byte table.  The nibbles come out in a permuted
+// order of the bits (dword c = the fields at bits 2c, 2c + 1 of the four bytes), which the contraction over K does not
+// see as long as both operands are expanded alike -- this kernel's query and window both are.
+__device__ __forceinline__ v4i expand32p(uint32_t w)
+{
+    const uint32_t pool = 0xAAA22A22u; // field 0 -> 0x22, 1 -> 0x2A, 2 -> 0xA2, 3 -> 0xAA
+    const uint32_t m = 0x03030303u;
+    v4i r;
+    r.x = (int)__builtin_amdgcn_perm(0u, pool, w & m);
+    r.y = (int)__builtin_amdgcn_perm(0u, pool, (w >> 2) & m);
+    r.z = (int)__builtin_amdgcn_perm(0u, pool, (w >> 4) & m);
+    r.w = (int)__builtin_amdgcn_perm(0u, pool, (w >> 6) & m);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void expand_query_shift_kernel(const uint64_t *__restrict__ q, int k, v4i *__restrict__ qexp)
+{
+    const int qlen = k + 63;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= qlen) return;
+    const int j = i - 32;
+    const bool in = j >= 0 && j < k;
+    const uint64_t w = in ? q[j] : 0ull;
+    qexp[i] = in ? expand32p((uint32_t)w) : v4i{0, 0, 0, 0};
+    qexp[qlen + i] = in ? expand32p((uint32_t)(w >> 32)) : v4i{0, 0, 0, 0};
+}
+
+// a <- (row m of a = row m - 1 of a, row 0 = fresh) in both halves of the wave; `fresh` is consumed.
+// Lane 0 has no lane to take from and keeps the destination's value (DPP with bound_ctrl off), which is `fresh`;
+// lane 32 would take lane 31's and is switched to `fresh` by the mask.
+__device__ __forceinline__ v4i shift_rows_insert(v4i a, v4i fresh)
+{
+    const unsigned long long lane32 = 1ull << 32;
+    asm volatile("s_nop 1\n\t"
+                 "s_mov_b64 vcc, %8\n\t"
+                 "v_cndmask_b32_dpp %0, %4, %0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_dpp %1, %5, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_dpp %2, %6, %2, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_cndmask_b32_dpp %3, %7, %3, vcc wave_shr:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(fresh.x), "+v"(fresh.y), "+v"(fresh.z), "+v"(fresh.w)
+                 : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "s"(lane32)
+                 : "vcc");
+    return fresh;
+}
+
+// TILES tiles of 1024 offsets per workgroup share the query operand of every step; WAVES waves split the steps.
+// (registers: two workgroups of eight waves on a CU are four waves per SIMD, 128 registers each)
 template <int TILES, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void hamming_shift_kernel(SearchShiftArgs a)
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void hamming_shift_kernel(SearchShiftArgs a)
 {
     constexpr int kThr = 64 * WAVES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m_lane = lane & 31, h = lane >> 5;
     const int clip = blockIdx.x / a.chunks;
     const int64_t r0 = a.db_off[clip];
@@ -307,30 +358,14 @@ __global__ __launch_bounds__(64 * WAVES) void hamming_shift_kernel(SearchShiftAr
     const int win = 1024 * TILES + steps;          // window slots used: 32 n + j + 1024 tile < 1024 TILES - 32 + steps
     const int plane = 32 * a.w32;                  // v4i per half-plane of the transposed window
     v4i *wB = reinterpret_cast<v4i *>(smem_raw);   // [2][32][w32]
-    v4i *wA = wB + 2 * plane;                      // [2][steps + 31]: slot i = Q[i - 31]
-    const int qlen = steps + 31;
-    // byte -> eight E2M1 nibbles by table: the expansion is this kernel's largest VALU item otherwise
-    // (every workgroup expands its own window for a single query)
-    uint32_t *lut = reinterpret_cast<uint32_t *>(wA + 2 * qlen);
-    if (tid < 256) lut[tid] = expand8((uint32_t)tid);
-    __syncthreads();
-    auto expand32_lut = [&](uint32_t w) {
-        v4i r;
-        r.x = (int)lut[w & 0xff];
-        r.y = (int)lut[(w >> 8) & 0xff];
-        r.z = (int)lut[(w >> 16) & 0xff];
-        r.w = (int)lut[w >> 24];
-        return r;
-    };
-    // every load of the staging (query first, then up to 8 window slots per thread and round) is issued
-    // before the first value is expanded, so their latencies overlap instead of adding up
-    constexpr int kLq = 512 / kThr, kLd = 8;
-    uint64_t wq[kLq];
-#pragma unroll
-    for (int e = 0; e < kLq; ++e) {
-        const int j = tid + e * kThr - 31;
-        wq[e] = (j >= 0 && j < a.k) ? a.q[j] : 0ull;
-    }
+    // this wave's steps, and the query operand of the step before its first: row m = Q[j0 - 1 - m] = slot j0 + 31 - m
+    const int per = (steps + WAVES - 1) / WAVES, j0 = wave * per, j1 = min(steps, j0 + per);
+    const int qlen = a.k + 63;
+    const v4i *qh = a.qexp + h * qlen;
+    v4i av = qh[min(j0, steps) + 31 - m_lane];
+    // every load of a staging round (up to 8 window slots per thread) is issued before the first value is expanded,
+    // so their latencies overlap instead of adding up
+    constexpr int kLd = 8;
     for (int i0 = tid; i0 < win; i0 += kLd * kThr) {
         uint64_t w[kLd];
 #pragma unroll
@@ -342,58 +377,42 @@ __global__ __launch_bounds__(64 * WAVES) void hamming_shift_kernel(SearchShiftAr
         for (int e = 0; e < kLd; ++e) {
             const int i = i0 + e * kThr;
             if (i < win) {
-                const bool in = t0 + i < n; // past the end of the clip: fp4 zeros, not expand(0) = all +1
+                const bool in = t0 + i < n; // past the end of the clip: fp4 zeros, not the expansion of 0 = all +1
                 const int slot = (i & 31) * a.w32 + (i >> 5);
-                wB[slot] = in ? expand32_lut((uint32_t)w[e]) : v4i{0, 0, 0, 0};
-                wB[plane + slot] = in ? expand32_lut((uint32_t)(w[e] >> 32)) : v4i{0, 0, 0, 0};
+                wB[slot] = in ? expand32p((uint32_t)w[e]) : v4i{0, 0, 0, 0};
+                wB[plane + slot] = in ? expand32p((uint32_t)(w[e] >> 32)) : v4i{0, 0, 0, 0};
             }
         }
-    }
-#pragma unroll
-    for (int e = 0; e < kLq; ++e) {
-        const int i = tid + e * kThr, j = i - 31;
-        if (i < qlen) {
-            const bool in = j >= 0 && j < a.k;
-            wA[i] = in ? expand32_lut((uint32_t)wq[e]) : v4i{0, 0, 0, 0};
-            wA[qlen + i] = in ? expand32_lut((uint32_t)(wq[e] >> 32)) : v4i{0, 0, 0, 0};
-        }
-    }
-    for (int i = tid + kLq * kThr; i < qlen; i += kThr) { // queries longer than 450 hashprints: the rest, plainly
-        const int j = i - 31;
-        const bool in = j >= 0 && j < a.k;
-        const uint64_t w = in ? a.q[j] : 0ull;
-        wA[i] = in ? expand32_lut((uint32_t)w) : v4i{0, 0, 0, 0};
-        wA[qlen + i] = in ? expand32_lut((uint32_t)(w >> 32)) : v4i{0, 0, 0, 0};
     }
     __syncthreads();
     f32x16 acc[TILES];
 #pragma unroll
     for (int tl = 0; tl < TILES; ++tl) acc[tl] = f32x16{0};
     const int one = 0x7f7f7f7f;
-    const int per = (steps + WAVES - 1) / WAVES, j0 = wave * per, j1 = min(steps, j0 + per);
-    const v4i *ap = wA + h * qlen + 31 - m_lane;   // + j
+    const v4i *ap = qh + 32;                       // + j: Q[j], the row that enters at step j
     const v4i *bp = wB + h * plane + m_lane;       // lane index = column n here
-    // four steps per round: the eight operand reads of the next round are in flight behind the MFMAs of this one
-    constexpr int kSt = 4;
+    // 8 / TILES steps per round: the operand reads of the next round are in flight behind the MFMAs of this one
+    constexpr int kSt = 8 / TILES / 2;
     v4i ca[kSt], cb[TILES][kSt], na[kSt], nb[TILES][kSt];
     auto fetch = [&](int j, v4i (&fa)[kSt], v4i (&fb)[TILES][kSt]) {
 #pragma unroll
         for (int e = 0; e < kSt; ++e) {
-            const int jj = j + e < j1 ? j + e : j1 - 1; // the tail re-reads the last step (its product is not used)
+            const int jj = j + e < j1 ? j + e : j1 - 1; // the tail re-reads the last step (not used)
             fa[e] = ap[jj];
 #pragma unroll
             for (int tl = 0; tl < TILES; ++tl) fb[tl][e] = bp[(jj & 31) * a.w32 + (jj >> 5) + 32 * tl];
         }
     };
-    auto mult = [&](int j, const v4i (&fa)[kSt], const v4i (&fb)[TILES][kSt]) {
+    auto mult = [&](int j, v4i (&fa)[kSt], const v4i (&fb)[TILES][kSt]) {
 #pragma unroll
         for (int e = 0; e < kSt; ++e) {
             if (j + e < j1) {
-                const v8i av = {fa[e].x, fa[e].y, fa[e].z, fa[e].w, 0, 0, 0, 0};
+                av = shift_rows_insert(av, fa[e]);
+                const v8i a8 = {av.x, av.y, av.z, av.w, 0, 0, 0, 0};
 #pragma unroll
                 for (int tl = 0; tl < TILES; ++tl) {
                     const v8i bv = {fb[tl][e].x, fb[tl][e].y, fb[tl][e].z, fb[tl][e].w, 0, 0, 0, 0};
-                    acc[tl] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[tl], 4, 4, 0, one, 0, one);
+                    acc[tl] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, bv, acc[tl], 4, 4, 0, one, 0, one);
                 }
             }
         }
@@ -462,15 +481,17 @@ static bool shift_two_tiles()
 
 static size_t shift_lds_bytes(int k, int tiles)
 {
-    const size_t win = (size_t)2 * 32 * shift_w32(k, tiles) * 16, qa = (size_t)2 * (k + 62) * 16, lut = 1024;
-    return std::max(win + qa + lut, (size_t)(tiles == 1 ? 16 : 64) * 1024); // (the partial sums overlay the windows)
+    const size_t win = (size_t)2 * 32 * shift_w32(k, tiles) * 16;
+    return std::max(win, (size_t)(tiles == 1 ? 16 : 64) * 1024); // (the partial sums overlay the windows)
 }
 
 size_t hamming_shift_lds_bytes(int k) { return shift_lds_bytes(k, 1); }
+size_t hamming_shift_image_bytes(int k) { return (size_t)2 * (k + 63) * 16; }
 
-// one query of k hashprints at d_q against the whole index: best[clip] (preset to ~0) gets (dist << 32) | offset
+// one query of k hashprints at d_q against the whole index: best[clip] (preset to ~0) gets (dist << 32) | offset.
+// d_qexp: hamming_shift_image_bytes(k) of scratch for the query's expanded image.
 void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_clips, int n_off_max, const uint64_t *d_q,
-                          int k, uint64_t *d_best, hipStream_t s)
+                          int k, void *d_qexp, uint64_t *d_best, hipStream_t s)
 {
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
@@ -480,11 +501,12 @@ void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_c
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set.mark();
     }
+    hipLaunchKernelGGL(expand_query_shift_kernel, dim3((k + 63 + 255) / 256), dim3(256), 0, s, d_q, k, reinterpret_cast<v4i *>(d_qexp));
     SearchShiftArgs a;
     a.db = d_db;
     a.db_off = d_db_off;
     a.n_clips = n_clips;
-    a.q = d_q;
+    a.qexp = reinterpret_cast<const v4i *>(d_qexp);
     a.k = k;
     a.best = d_best;
     const int tiles1 = (n_off_max + 1023) / 1024;

@@ -256,8 +256,9 @@ size_t hamming_mfma_lds_bytes(int k_max);      // dynamic LDS of the scan; > 160
 void launch_expand_queries(const uint64_t *d_q, const int64_t *d_q_off, int n_q, int kt_pad, void *d_qa, hipStream_t s);
 // one query against the whole index with the tile rows = 32 shifts of the query (few queries: no padded rows)
 size_t hamming_shift_lds_bytes(int k);
+size_t hamming_shift_image_bytes(int k);       // scratch for the query's expanded image (d_qexp)
 void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_clips, int n_off_max, const uint64_t *d_q,
-                          int k, uint64_t *d_best, hipStream_t s);
+                          int k, void *d_qexp, uint64_t *d_best, hipStream_t s);
 // nearest windows (AnnStorage semantics with exact neighbours): rows = windows of `win` hashprints
 void launch_expand_windows(const uint64_t *d_q, const int64_t *d_w_start, int n_win, int win, int kt_pad, void *d_qa,
                            hipStream_t s);

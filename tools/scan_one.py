@@ -1,26 +1,41 @@
-"""One-query scans over a 125 000-clip random index (configs[4]'s shard), for rocprofv3.  python tools/scan_one.py [reps]"""
-import sys
-import time
-
+"""One query against a resident shard: time of the scan kernels and a check of the hit (run on the GPU box).
+   python tools/scan_one.py [clips] [query hashprints] [rounds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-
-sys.path.insert(0, ".")
 import hpfw_amd
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-n_clips, per, k = 125000, 2320, 305
-g = hpfw_amd.Gpu(0)
-db = torch.randint(-2 ** 63, 2 ** 63 - 1, (n_clips * per,), dtype=torch.int64, device="cuda")
-off = np.arange(0, (n_clips + 1) * per, per, dtype=np.int64)
-g.index_add_dev(db.data_ptr(), off, 0)
-q = db[777 * per + 100: 777 * per + 100 + k].cpu().numpy().view(np.uint64)
-q_off = np.array([0, k], np.int64)
-hits = g.search_topk(q, q_off, 10)
-assert hits[0, 0]["clip"] == 777 and hits[0, 0]["offset"] == 100 and hits[0, 0]["dist"] == 0
+n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 125000
+kq = int(sys.argv[2]) if len(sys.argv) > 2 else 304
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+n_hp = 2320
+gpu = hpfw_amd.Gpu(0)
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(5)
+db = torch.randint(-2 ** 63, 2 ** 63 - 1, (n_clips, n_hp), dtype=torch.int64, generator=g, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+gpu.index_clear()
+gpu.index_add_dev(db.data_ptr(), np.arange(0, (n_clips + 1) * n_hp, n_hp, dtype=np.int64), stream)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(reps):
-    g.search_topk(q, q_off, 10)
-dt = (time.perf_counter() - t0) / reps
-print(f"one query of {k} hashprints against {n_clips} clips: {dt * 1e3:.3f} ms per search")
+hits = torch.empty((1, 5, 4), dtype=torch.int32, device=dev)
+q_off = np.array([0, kq], dtype=np.int64)
+wrong = 0
+scan_idx = hpfw_amd.KERNEL_KINDS.index("hamming_scan")
+gpu.set_kernel_timing(1 << scan_idx)
+lat = []
+for r in range(rounds):
+    clip, off = (r * 7919 + 13) % n_clips, (r * 131) % (n_hp - kq + 1)
+    q = db[clip, off:off + kq].clone()
+    q[::7] ^= 1 << (r % 62)                       # a few flipped bits
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gpu.search_topk_dev(q.data_ptr(), q_off, 5, hits.data_ptr(), stream)
+    res = hits.cpu().numpy().reshape(-1).view(hpfw_amd.HIT_DTYPE).reshape(1, 5)
+    lat.append((time.perf_counter() - t0) * 1e3)
+    top = res[0, 0]
+    wrong += int(top["clip"] != clip or top["offset"] != off)
+kt = gpu.kernel_timing()
+print({"clips": n_clips, "kq": kq, "rounds": rounds, "wrong": wrong, "latency_ms_p50": round(float(np.median(lat)), 3),
+       "scan": kt.get("hamming_scan"), "pairs_per_s": None if not kt.get("hamming_scan") else
+       round(n_clips * (n_hp - kq + 1) * kq / (kt["hamming_scan"][0] / max(kt["hamming_scan"][1], 1) * 1e-3), 1)})
