@@ -271,26 +271,29 @@ __global__ __launch_bounds__(kSmThreads, 4) void hamming_mfma_kernel(SearchMfmaA
     }
 }
 
-// ---- one query (or a few, one launch each): the rows of the MFMA tile are 32 shifts of the query ----
-// acc(m, n) = sum_j <Q[j - m], R[t0 + 32 n + j]> = the dot product at offset t0 + 32 n + m, so one tile is
-// 1024 consecutive offsets of one clip and every row does useful work (a tile of hamming_mfma_kernel
-// would carry 31 rows of padding).  Workgroup = TILES tiles; its waves split the k + 31 steps and
-// add their accumulators through LDS.  The clip window is stored transposed (slot i at row i mod 32)
-// so that the columns' operands, 32 slots apart, are read from consecutive addresses.
-// The query operand never touches LDS: row m of step j + 1 is row m - 1 of step j, so a wave keeps the operand in four
-// registers and moves it down one lane per step (DPP wave_shr:1), with the step's new hashprint entering at row 0 of
-// both halves of K from the query's expanded image in global memory (one 16-byte load per lane and step, two distinct
-// addresses per wave).  One LDS read per matrix instruction remains (the window's column operand), and the LDS holds
-// nothing but the window: two workgroups share a CU for queries up to 5 s, one stages while the other multiplies.
+// ---- one query (or a few, one launch each): the rows of the MFMA tiles are shifts of the query ----
+// acc_tu(m, n) = sum_j <Q[j - 32 t - m], R[t0 + S (n + 32 u) + j]> = the dot product at offset t0 + 1024 MT u + S n +
+// 32 t + m, S = 32 MT: MT tiles of 32 shifts stacked in M, NT tiles of 32 columns (S offsets apart) side by side in N,
+// cover 1024 MT NT consecutive offsets of one clip and every row does useful work (a tile of hamming_mfma_kernel would
+// carry 31 rows of padding).  The MT NT matrix instructions of a step share MT query operands and NT column operands.
+// Measured at 125 000 clips of 2320, query 304: (MT, NT) = (1, 2) 2.65 ms, (2, 1) 3.47 ms, (1, 1) 4.3 ms -- the query
+// operands' register moves (vector ALU, which the SIMD shares with the issue of the matrix instructions) cost more than
+// the column operands' LDS reads.
+// Workgroup = one such item; its waves split the k + S - 1 steps and add their accumulators through LDS.  The clip window
+// is stored transposed (slot i at row i mod S) so that the columns' operands, S slots apart, are read from consecutive
+// addresses.
+// The query operands never touch LDS: row m of step j + 1 is row m - 1 of step j, so a wave keeps each in four
+// registers and moves it down one lane per step (DPP wave_shr:1); the step's new hashprint enters at row 0 of both
+// halves of K from a feeder register that holds the next 32 steps' hashprints, one per lane, and rotates with it.
 struct SearchShiftArgs {
     const uint64_t *db;
     const int64_t *db_off;
     int n_clips;
-    const v4i *qexp;   // [2][k + 63]: slot i = half h of Q[i - 32] expanded (expand32p), zeros outside the query
+    const v4i *qexp;   // [2][k + 128 MT]: slot i = half h of Q[i - 32 MT] expanded (expand32p), zeros outside the query
     int k;             // the query's length
     uint64_t *best;    // [n_clips], initialised to ~0
-    int chunks;        // workgroups (of 1024 TILES offsets) per clip
-    int w32;           // row stride of the transposed window (odd)
+    int chunks;        // workgroups (of 1024 MT NT offsets) per clip
+    int ws;            // row stride of the transposed window (odd)
 };
 
 // 32 bits -> 32 E2M1 nibbles (0 -> +1.0 = 0x2, 1 -> -1.0 = 0xA) by byte permutes: a selector byte holds one 2-bit field
@@ -309,42 +312,50 @@ __device__ __forceinline__ v4i expand32p(uint32_t w)
     return r;
 }
 
-__global__ __launch_bounds__(256) void expand_query_shift_kernel(const uint64_t *__restrict__ q, int k, v4i *__restrict__ qexp)
+__global__ __launch_bounds__(256) void expand_query_shift_kernel(const uint64_t *__restrict__ q, int k, int lead, int qlen,
+                                                                 v4i *__restrict__ qexp)
 {
-    const int qlen = k + 63;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= qlen) return;
-    const int j = i - 32;
+    const int j = i - lead;
     const bool in = j >= 0 && j < k;
     const uint64_t w = in ? q[j] : 0ull;
     qexp[i] = in ? expand32p((uint32_t)w) : v4i{0, 0, 0, 0};
     qexp[qlen + i] = in ? expand32p((uint32_t)(w >> 32)) : v4i{0, 0, 0, 0};
 }
 
-// a <- (row m of a = row m - 1 of a, row 0 = fresh) in both halves of the wave; `fresh` is consumed.
-// Lane 0 has no lane to take from and keeps the destination's value (DPP with bound_ctrl off), which is `fresh`;
-// lane 32 would take lane 31's and is switched to `fresh` by the mask.
-__device__ __forceinline__ v4i shift_rows_insert(v4i a, v4i fresh)
+// One step of a query operand: row m <- row m - 1 (DPP wave_shr:1), row 0 of either half of K <- the value at the head
+// of the feeder f (lanes 0 and 32, picked by the mask; lane 0 has no lane to take from and reads zero under bound_ctrl,
+// which the mask discards); then the feeder moves up one lane (wave_rol:1), bringing the next step's rows to its lanes
+// 0 and 32.  The feeder is loaded once per 32 steps -- lane L of a half holds the hashprint of step L -- so the loop
+// issues no global load: nothing but the window's LDS reads feeds the matrix instructions.
+// (The result goes to registers of its own: the matrix instructions of the step before may still be reading a.)
+__device__ __forceinline__ v4i shift_rows_feed(const v4i &a, v4i &f)
 {
-    const unsigned long long lane32 = 1ull << 32;
+    const unsigned long long heads = 1ull | (1ull << 32);
+    v4i r;
     asm volatile("s_nop 1\n\t"
-                 "s_mov_b64 vcc, %8\n\t"
-                 "v_cndmask_b32_dpp %0, %4, %0, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_cndmask_b32_dpp %1, %5, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_cndmask_b32_dpp %2, %6, %2, vcc wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_cndmask_b32_dpp %3, %7, %3, vcc wave_shr:1 row_mask:0xf bank_mask:0xf"
-                 : "+v"(fresh.x), "+v"(fresh.y), "+v"(fresh.z), "+v"(fresh.w)
-                 : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "s"(lane32)
+                 "s_mov_b64 vcc, %12\n\t"
+                 "v_cndmask_b32_dpp %0, %8, %4, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_cndmask_b32_dpp %1, %9, %5, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_cndmask_b32_dpp %2, %10, %6, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_cndmask_b32_dpp %3, %11, %7, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "v_mov_b32_dpp %4, %4 wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %5, %5 wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %6, %6 wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %7, %7 wave_rol:1 row_mask:0xf bank_mask:0xf"
+                 : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w), "+v"(f.x), "+v"(f.y), "+v"(f.z), "+v"(f.w)
+                 : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "s"(heads)
                  : "vcc");
-    return fresh;
+    return r;
 }
 
-// TILES tiles of 1024 offsets per workgroup share the query operand of every step; WAVES waves split the steps.
-// (registers: two workgroups of eight waves on a CU are four waves per SIMD, 128 registers each)
-template <int TILES, int WAVES>
+// WAVES waves split the steps; KST steps of column operands are in flight behind the matrix instructions of the KST
+// before them.  (registers: two workgroups of eight waves on a CU are four waves per SIMD, 128 registers each)
+template <int MT, int NT, int WAVES, int KST>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void hamming_shift_kernel(SearchShiftArgs a)
 {
-    constexpr int kThr = 64 * WAVES;
+    constexpr int kThr = 64 * WAVES, S = 32 * MT;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m_lane = lane & 31, h = lane >> 5;
     const int clip = blockIdx.x / a.chunks;
@@ -352,17 +363,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void hamming_shift_
     const int n = (int)(a.db_off[clip + 1] - r0);
     if (n <= 0 || a.k <= 0) return;
     const int keff = a.k < n ? a.k : n; // storage.h:37-39
-    const int t0 = (blockIdx.x - clip * a.chunks) * 1024 * TILES;
+    const int t0 = (blockIdx.x - clip * a.chunks) * 1024 * MT * NT;
     if (t0 > n - keff) return;
-    const int steps = a.k + 31;
-    const int win = 1024 * TILES + steps;          // window slots used: 32 n + j + 1024 tile < 1024 TILES - 32 + steps
-    const int plane = 32 * a.w32;                  // v4i per half-plane of the transposed window
-    v4i *wB = reinterpret_cast<v4i *>(smem_raw);   // [2][32][w32]
-    // this wave's steps, and the query operand of the step before its first: row m = Q[j0 - 1 - m] = slot j0 + 31 - m
+    const int steps = a.k + S - 1;
+    const int win = 1024 * MT * NT + steps;        // window slots used: S (n + 32 u) + j <= S (32 NT - 1) + steps - 1
+    const int plane = S * a.ws;                    // v4i per half-plane of the transposed window
+    v4i *wB = reinterpret_cast<v4i *>(smem_raw);   // [2][S][ws]
+    // this wave's steps; its query operands of the step before its first (row m of tile t = Q[j0 - 1 - 32 t - m]) and
+    // the feeders of its first segment (lane L of tile t = Q[j0 - 32 t + L]); slot of Q[j] = j + S
     const int per = (steps + WAVES - 1) / WAVES, j0 = wave * per, j1 = min(steps, j0 + per);
-    const int qlen = a.k + 63;
+    const int qlen = a.k + 4 * S;
     const v4i *qh = a.qexp + h * qlen;
-    v4i av = qh[min(j0, steps) + 31 - m_lane];
+    v4i av[MT], feed[MT], feed_next[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        av[t] = qh[min(j0, steps) - 1 - 32 * t - m_lane + S];
+        feed_next[t] = qh[min(j0 - 32 * t + m_lane + S, qlen - 1)];
+    }
     // every load of a staging round (up to 8 window slots per thread) is issued before the first value is expanded,
     // so their latencies overlap instead of adding up
     constexpr int kLd = 8;
@@ -378,73 +395,86 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void hamming_shift_
             const int i = i0 + e * kThr;
             if (i < win) {
                 const bool in = t0 + i < n; // past the end of the clip: fp4 zeros, not the expansion of 0 = all +1
-                const int slot = (i & 31) * a.w32 + (i >> 5);
+                const int slot = (i % S) * a.ws + i / S;
                 wB[slot] = in ? expand32p((uint32_t)w[e]) : v4i{0, 0, 0, 0};
                 wB[plane + slot] = in ? expand32p((uint32_t)(w[e] >> 32)) : v4i{0, 0, 0, 0};
             }
         }
     }
     __syncthreads();
-    f32x16 acc[TILES];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int tl = 0; tl < TILES; ++tl) acc[tl] = f32x16{0};
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x16{0};
     const int one = 0x7f7f7f7f;
-    const v4i *ap = qh + 32;                       // + j: Q[j], the row that enters at step j
     const v4i *bp = wB + h * plane + m_lane;       // lane index = column n here
-    // 8 / TILES steps per round: the operand reads of the next round are in flight behind the MFMAs of this one
-    constexpr int kSt = 8 / TILES / 2;
-    v4i ca[kSt], cb[TILES][kSt], na[kSt], nb[TILES][kSt];
-    auto fetch = [&](int j, v4i (&fa)[kSt], v4i (&fb)[TILES][kSt]) {
+    v4i cb[NT][KST], nb[NT][KST];
+    auto fetch = [&](int j, int jend, v4i (&fb)[NT][KST]) {
 #pragma unroll
-        for (int e = 0; e < kSt; ++e) {
-            const int jj = j + e < j1 ? j + e : j1 - 1; // the tail re-reads the last step (not used)
-            fa[e] = ap[jj];
+        for (int e = 0; e < KST; ++e) {
+            const int jj = j + e < jend ? j + e : jend - 1; // the tail re-reads the last step (not used)
 #pragma unroll
-            for (int tl = 0; tl < TILES; ++tl) fb[tl][e] = bp[(jj & 31) * a.w32 + (jj >> 5) + 32 * tl];
+            for (int u = 0; u < NT; ++u) fb[u][e] = bp[(jj % S) * a.ws + jj / S + 32 * u];
         }
     };
-    auto mult = [&](int j, v4i (&fa)[kSt], const v4i (&fb)[TILES][kSt]) {
+    auto mult = [&](int j, int jend, const v4i (&fb)[NT][KST]) {
 #pragma unroll
-        for (int e = 0; e < kSt; ++e) {
-            if (j + e < j1) {
-                av = shift_rows_insert(av, fa[e]);
-                const v8i a8 = {av.x, av.y, av.z, av.w, 0, 0, 0, 0};
+        for (int e = 0; e < KST; ++e) {
+            if (j + e < jend) {
 #pragma unroll
-                for (int tl = 0; tl < TILES; ++tl) {
-                    const v8i bv = {fb[tl][e].x, fb[tl][e].y, fb[tl][e].z, fb[tl][e].w, 0, 0, 0, 0};
-                    acc[tl] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, bv, acc[tl], 4, 4, 0, one, 0, one);
+                for (int t = 0; t < MT; ++t) {
+                    av[t] = shift_rows_feed(av[t], feed[t]);
+                    const v8i a8 = {av[t].x, av[t].y, av[t].z, av[t].w, 0, 0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) {
+                        const v8i bv = {fb[u][e].x, fb[u][e].y, fb[u][e].z, fb[u][e].w, 0, 0, 0, 0};
+                        acc[t][u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, bv, acc[t][u], 4, 4, 0, one, 0, one);
+                    }
                 }
             }
         }
     };
-    if (j0 < j1) fetch(j0, ca, cb);
-    for (int j = j0; j < j1; j += 2 * kSt) { // two register sets in turn, no copies
-        if (j + kSt < j1) fetch(j + kSt, na, nb);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(j, ca, cb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 2 * kSt < j1) fetch(j + 2 * kSt, ca, cb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + kSt < j1) mult(j + kSt, na, nb);
-        __builtin_amdgcn_sched_barrier(0);
+    // segments of at most 32 steps, one feeder per tile each (fetched one segment ahead)
+    for (int ja = j0; ja < j1; ja += 32) {
+        const int jb = min(j1, ja + 32);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            feed[t] = feed_next[t];
+            feed_next[t] = qh[min(ja + 32 - 32 * t + m_lane + S, qlen - 1)];
+        }
+        fetch(ja, jb, cb);
+        for (int j = ja; j < jb; j += 2 * KST) { // two register sets in turn, no copies
+            if (j + KST < jb) fetch(j + KST, jb, nb);
+            __builtin_amdgcn_sched_barrier(0);
+            mult(j, jb, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 2 * KST < jb) fetch(j + 2 * KST, jb, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + KST < jb) mult(j + KST, jb, nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
-    __syncthreads(); // the windows are no longer read: their memory takes the partial sums
-    float *red = reinterpret_cast<float *>(smem_raw); // [WAVES][TILES][16 regs][64 lanes]
+    __syncthreads(); // the window is no longer read: its memory takes the partial sums
+    constexpr int TILES = MT * NT;
+    float *red = reinterpret_cast<float *>(smem_raw); // [WAVES][MT][NT][16 regs][64 lanes]
 #pragma unroll
-    for (int tl = 0; tl < TILES; ++tl)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) red[((wave * TILES + tl) * 16 + reg) * 64 + lane] = acc[tl][reg];
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) red[((wave * TILES + t * NT + u) * 16 + reg) * 64 + lane] = acc[t][u][reg];
     __syncthreads();
-    // thread (reg = tid / 64 .. , lane): 16 regs x 64 lanes = 1024 sums, four per thread
+    // thread (tile, reg, lane): 16 TILES regs x 64 lanes sums, 16 TILES / WAVES per thread
     unsigned key = 0xffffffffu;
 #pragma unroll
     for (int e = 0; e < 16 * TILES / WAVES; ++e) {
-        const int idx = wave * (16 * TILES / WAVES) + e, tl = idx >> 4, reg = idx & 15;
+        const int idx = wave * (16 * TILES / WAVES) + e, tu = idx >> 4, reg = idx & 15, t = tu / NT, u = tu % NT;
         float dot = 0.0f; // (integers below 2^24: any order of the partial sums gives the same value)
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) dot += red[((w * TILES + tl) * 16 + reg) * 64 + lane];
-        const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h; // shift = offset inside the group of 32
-        const int lo = 1024 * tl + 32 * m_lane + m;        // column m_lane: base offset 32 n
+        for (int w = 0; w < WAVES; ++w) dot += red[((w * TILES + tu) * 16 + reg) * 64 + lane];
+        const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h; // row of the tile
+        const int lo = S * (m_lane + 32 * u) + 32 * t + m; // column m_lane of tile u: base offset S (n + 32 u)
         const int dist = (64 * keff - (int)dot) >> 1;
         const unsigned cand = ((unsigned)dist << 12) | (unsigned)lo;
         if (t0 + lo <= n - keff && cand < key) key = cand;
@@ -454,22 +484,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void hamming_shift_
         const unsigned o = (unsigned)__shfl_xor((int)key, s2);
         key = o < key ? o : key;
     }
-    __syncthreads();
-    unsigned *kr = reinterpret_cast<unsigned *>(smem_raw);
-    if (lane == 0) kr[wave] = key;
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < WAVES; ++w) key = kr[w] < key ? kr[w] : key;
-        if (key != 0xffffffffu) {
-            const unsigned long long full = ((unsigned long long)(key >> 12) << 32) | (unsigned)(t0 + (int)(key & 0xfff));
-            atomicMin(reinterpret_cast<unsigned long long *>(a.best) + clip, full);
-        }
+    // one atomic per wave: no further pass through LDS
+    if (lane == 0 && key != 0xffffffffu) {
+        const unsigned long long full = ((unsigned long long)(key >> 12) << 32) | (unsigned)(t0 + (int)(key & 0xfff));
+        atomicMin(reinterpret_cast<unsigned long long *>(a.best) + clip, full);
     }
 }
 
-static int shift_w32(int k, int tiles)
+static int shift_ws(int k, int mt, int nt)
 {
-    int w = (1024 * tiles + k + 31 + 31) / 32 + 1;
+    const int s = 32 * mt;
+    const int w = (1024 * mt * nt + k + s - 1 + s - 1) / s; // rows of s slots that hold the window
     return w | 1;
 }
 
@@ -479,14 +504,14 @@ static bool shift_two_tiles()
     return on;
 }
 
-static size_t shift_lds_bytes(int k, int tiles)
+static size_t shift_lds_bytes(int k, int mt, int nt, int waves)
 {
-    const size_t win = (size_t)2 * 32 * shift_w32(k, tiles) * 16;
-    return std::max(win, (size_t)(tiles == 1 ? 16 : 64) * 1024); // (the partial sums overlay the windows)
+    const size_t win = (size_t)2 * 32 * mt * shift_ws(k, mt, nt) * 16;
+    return std::max(win, (size_t)waves * mt * nt * 4096); // (the partial sums overlay the window)
 }
 
-size_t hamming_shift_lds_bytes(int k) { return shift_lds_bytes(k, 1); }
-size_t hamming_shift_image_bytes(int k) { return (size_t)2 * (k + 63) * 16; }
+size_t hamming_shift_lds_bytes(int k) { return shift_lds_bytes(k, 1, 1, 4); }
+size_t hamming_shift_image_bytes(int k) { return (size_t)2 * (k + 4 * 32) * 16; }
 
 // one query of k hashprints at d_q against the whole index: best[clip] (preset to ~0) gets (dist << 32) | offset.
 // d_qexp: hamming_shift_image_bytes(k) of scratch for the query's expanded image.
@@ -495,13 +520,12 @@ void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_c
 {
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel<1, 4>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel<1, 1, 4, 4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel<2, 8>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_shift_kernel<1, 2, 8, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set.mark();
     }
-    hipLaunchKernelGGL(expand_query_shift_kernel, dim3((k + 63 + 255) / 256), dim3(256), 0, s, d_q, k, reinterpret_cast<v4i *>(d_qexp));
     SearchShiftArgs a;
     a.db = d_db;
     a.db_off = d_db_off;
@@ -510,18 +534,20 @@ void launch_hamming_shift(const uint64_t *d_db, const int64_t *d_db_off, int n_c
     a.k = k;
     a.best = d_best;
     const int tiles1 = (n_off_max + 1023) / 1024;
-    // two tiles per workgroup share every step's query operand; one tile when the clips have a single one, or when
-    // the doubled window does not fit the LDS
-    const bool two = shift_two_tiles() && tiles1 > 1 && shift_lds_bytes(k, 2) <= 160 * 1024;
-    if (two) {
-        a.chunks = (tiles1 + 1) / 2;
-        a.w32 = shift_w32(k, 2);
-        hipLaunchKernelGGL((hamming_shift_kernel<2, 8>), dim3((unsigned)a.chunks * (unsigned)n_clips), dim3(512), shift_lds_bytes(k, 2), s, a);
-    } else {
-        a.chunks = tiles1;
-        a.w32 = shift_w32(k, 1);
-        hipLaunchKernelGGL((hamming_shift_kernel<1, 4>), dim3((unsigned)a.chunks * (unsigned)n_clips), dim3(256), shift_lds_bytes(k, 1), s, a);
-    }
+    // two tiles of columns per workgroup share every step's query operand; one tile when the clips have no more than
+    // 1024 offsets, or when the doubled window does not fit the LDS
+    const bool two = shift_two_tiles() && tiles1 > 1 && shift_lds_bytes(k, 1, 2, 8) <= 160 * 1024;
+    const int lead = 32, qlen = k + 4 * lead;
+    hipLaunchKernelGGL(expand_query_shift_kernel, dim3((qlen + 255) / 256), dim3(256), 0, s, d_q, k, lead, qlen,
+                       reinterpret_cast<v4i *>(d_qexp));
+    const int nt = two ? 2 : 1;
+    a.chunks = (tiles1 + nt - 1) / nt;
+    a.ws = shift_ws(k, 1, nt);
+    const dim3 grid((unsigned)a.chunks * (unsigned)n_clips);
+    if (two)
+        hipLaunchKernelGGL((hamming_shift_kernel<1, 2, 8, 2>), grid, dim3(512), shift_lds_bytes(k, 1, 2, 8), s, a);
+    else
+        hipLaunchKernelGGL((hamming_shift_kernel<1, 1, 4, 4>), grid, dim3(256), shift_lds_bytes(k, 1, 1, 4), s, a);
 }
 
 size_t hamming_mfma_lds_bytes(int kt)
