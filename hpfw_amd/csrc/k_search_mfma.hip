@@ -28,6 +28,7 @@ extern __shared__ __align__(16) unsigned char smem_raw[];
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kSmThreads = 512;            // 8 waves
 constexpr int kSmTiles = 4;                // offset tiles of 32 per wave
@@ -390,14 +391,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void hamming_shift_
             const int gi = t0 + i0 + e * kThr;
             w[e] = (i0 + e * kThr < win && gi < n) ? a.db[r0 + gi] : 0ull;
         }
+        if (t0 + win <= n) { // the whole window lies inside the clip (all but the last item of a clip)
 #pragma unroll
-        for (int e = 0; e < kLd; ++e) {
-            const int i = i0 + e * kThr;
-            if (i < win) {
-                const bool in = t0 + i < n; // past the end of the clip: fp4 zeros, not the expansion of 0 = all +1
-                const int slot = (i % S) * a.ws + i / S;
-                wB[slot] = in ? expand32p((uint32_t)w[e]) : v4i{0, 0, 0, 0};
-                wB[plane + slot] = in ? expand32p((uint32_t)(w[e] >> 32)) : v4i{0, 0, 0, 0};
+            for (int e = 0; e < kLd; ++e) {
+                const int i = i0 + e * kThr;
+                if (i < win) {
+                    const int slot = (i % S) * a.ws + i / S;
+                    wB[slot] = expand32p((uint32_t)w[e]);
+                    wB[plane + slot] = expand32p((uint32_t)(w[e] >> 32));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < kLd; ++e) {
+                const int i = i0 + e * kThr;
+                if (i < win) {
+                    const bool in = t0 + i < n; // past the end of the clip: fp4 zeros, not the expansion of 0 = all +1
+                    const int slot = (i % S) * a.ws + i / S;
+                    wB[slot] = in ? expand32p((uint32_t)w[e]) : v4i{0, 0, 0, 0};
+                    wB[plane + slot] = in ? expand32p((uint32_t)(w[e] >> 32)) : v4i{0, 0, 0, 0};
+                }
             }
         }
     }
@@ -457,22 +470,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void hamming_shift_
     }
     __syncthreads(); // the window is no longer read: its memory takes the partial sums
     constexpr int TILES = MT * NT;
-    float *red = reinterpret_cast<float *>(smem_raw); // [WAVES][MT][NT][16 regs][64 lanes]
+    static_assert(16 * TILES / WAVES == 4, "a thread sums one group of four accumulator registers");
+    f32x4 *red = reinterpret_cast<f32x4 *>(smem_raw); // [WAVES][MT][NT][4 groups of 4 regs][64 lanes]
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) red[((wave * TILES + t * NT + u) * 16 + reg) * 64 + lane] = acc[t][u][reg];
+            for (int g = 0; g < 4; ++g)
+                red[((wave * TILES + t * NT + u) * 4 + g) * 64 + lane] =
+                    f32x4{acc[t][u][4 * g], acc[t][u][4 * g + 1], acc[t][u][4 * g + 2], acc[t][u][4 * g + 3]};
     __syncthreads();
-    // thread (tile, reg, lane): 16 TILES regs x 64 lanes sums, 16 TILES / WAVES per thread
+    // wave w sums group (w mod 4) of tile (w / 4) over the waves: four sums per thread
     unsigned key = 0xffffffffu;
+    const int tu = wave >> 2, g4 = wave & 3, t = tu / NT, u = tu % NT;
+    f32x4 dots = {0.0f, 0.0f, 0.0f, 0.0f}; // (integers below 2^24: any order of the partial sums gives the same value)
 #pragma unroll
-    for (int e = 0; e < 16 * TILES / WAVES; ++e) {
-        const int idx = wave * (16 * TILES / WAVES) + e, tu = idx >> 4, reg = idx & 15, t = tu / NT, u = tu % NT;
-        float dot = 0.0f; // (integers below 2^24: any order of the partial sums gives the same value)
+    for (int w = 0; w < WAVES; ++w) dots += red[((w * TILES + tu) * 4 + g4) * 64 + lane];
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) dot += red[((w * TILES + tu) * 16 + reg) * 64 + lane];
+    for (int e = 0; e < 4; ++e) {
+        const int reg = 4 * g4 + e;
+        const float dot = dots[e];
         const int m = (reg & 3) + 8 * (reg >> 2) + 4 * h; // row of the tile
         const int lo = S * (m_lane + 32 * u) + 32 * t + m; // column m_lane of tile u: base offset S (n + 32 u)
         const int dist = (64 * keff - (int)dot) >> 1;
