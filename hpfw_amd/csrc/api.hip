@@ -104,7 +104,7 @@ struct hpfw_gpu {
     std::mutex host_mtx;
     std::condition_variable host_cv;
     std::map<int64_t, std::unique_ptr<hpfw::HostPlan>> host_ready;
-    std::set<int64_t> host_seen; // lengths prepared or planned at least once (never prepared twice)
+    std::set<int64_t> host_seen; // lengths being prepared, prepared, or resident on the device (not prepared again while they are)
     size_t plan_bytes = 0;
     uint64_t plan_clock = 0;
     unsigned conventions = 0; // hpfw_gpu_set_conventions: essentia conventions that cannot be checked offline
@@ -484,6 +484,11 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
             for (auto q = h->plans.begin(); q != h->plans.end(); ++q)
                 if (q->second->last_use < lru->second->last_use) lru = q;
             h->plan_bytes -= lru->second->bytes;
+            {
+                // an evicted length may be prepared ahead again by the reader threads the next time a file brings it
+                std::scoped_lock lock(h->host_mtx);
+                h->host_seen.erase(lru->first);
+            }
             h->plans.erase(lru);
         }
     }

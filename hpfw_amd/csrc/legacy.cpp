@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
+#include <future>
 #include <fstream>
 #include <map>
 #include <mutex>
@@ -181,12 +182,19 @@ struct hpfw_legacy_collector {
     std::vector<float> filters;
     // prepare() / calc_hashprints(): one window of files is read straight into pinned host memory (clips of equal length
     // side by side) and goes to the device in one copy; both buffers are kept between windows and calls
-    void *arena = nullptr, *d_arena = nullptr;
-    size_t arena_cap = 0, d_arena_cap = 0;
+    // two pinned host arenas in turn: the files of the next window are read while this one is copied and extracted
+    // (spare_db: the spectrogram buffer of the last group that was not kept, for the next one -- freeing and allocating
+    // hundreds of MB of device memory per window stalls the reader threads, who share the address space)
+    void *spare_db = nullptr;
+    size_t spare_db_cap = 0;
+    void *arena[2] = {nullptr, nullptr}, *d_arena = nullptr;
+    size_t arena_cap[2] = {0, 0}, d_arena_cap = 0;
     ~hpfw_legacy_collector()
     {
-        if (arena) (void)hipHostFree(arena);
+        for (void *a : arena)
+            if (a) (void)hipHostFree(a);
         if (d_arena) (void)hipFree(d_arena);
+        if (spare_db) (void)hipFree(spare_db);
     }
 };
 
@@ -401,11 +409,12 @@ struct Loaded {
 // threads also prepare the host half of the tables of every length they meet (hpfw_gpu_prepare_length: a corpus of
 // full-length tracks brings a new length with almost every file).
 // Returns the bytes of the arena in use (0: nothing readable).
-size_t read_window(hpfw_legacy_collector *c, const char **filenames, const std::vector<int> &files, size_t first, size_t last,
-                   std::vector<Loaded> &out)
+size_t read_window(hpfw_legacy_collector *c, int slot, const char **filenames, const std::vector<int> &files, size_t first, size_t last,
+                   std::vector<Loaded> &out, std::string &first_why)
 {
+    const auto t_begin = std::chrono::steady_clock::now();
     std::mutex why_mtx;
-    std::string first_why; // the reader threads' messages are thread-local: keep the first failure for the caller
+    first_why.clear(); // error messages are thread-local and this runs on a thread of its own: the first failure goes back to the caller
     const int count = (int)(last - first);
     out.assign((size_t)count, Loaded());
     std::vector<WavProbe> probes((size_t)count);
@@ -434,6 +443,7 @@ size_t read_window(hpfw_legacy_collector *c, const char **filenames, const std::
             fail(std::string(filenames[files[first + (size_t)i]]) + ": " + e.what());
         }
     });
+    const auto t_probe = std::chrono::steady_clock::now();
     // slots: by length, then input order; every group starts 16-byte aligned
     std::map<int64_t, std::vector<int>> by_len;
     for (int i = 0; i < count; ++i)
@@ -447,19 +457,19 @@ size_t read_window(hpfw_legacy_collector *c, const char **filenames, const std::
             bytes += (size_t)kv.first * 2;
         }
     }
-    if (bytes > c->arena_cap) {
-        if (c->arena) (void)hipHostFree(c->arena);
-        c->arena = nullptr;
-        c->arena_cap = 0;
+    if (bytes > c->arena_cap[slot]) {
+        if (c->arena[slot]) (void)hipHostFree(c->arena[slot]);
+        c->arena[slot] = nullptr;
+        c->arena_cap[slot] = 0;
         const size_t want = std::max(bytes + bytes / 4, (size_t)64 << 20);
-        if (hipHostMalloc(&c->arena, want, hipHostMallocDefault) != hipSuccess) {
-            c->arena = nullptr;
-            hpfw_internal_set_error("prepare: out of pinned host memory");
+        if (hipHostMalloc(&c->arena[slot], want, hipHostMallocDefault) != hipSuccess) {
+            c->arena[slot] = nullptr;
+            first_why = "prepare: out of pinned host memory";
             for (WavProbe &w : probes)
                 if (w.fd >= 0) ::close(w.fd);
             return 0;
         }
-        c->arena_cap = want;
+        c->arena_cap[slot] = want;
     }
     run([&](int i) {
         WavProbe &w = probes[(size_t)i];
@@ -467,7 +477,7 @@ size_t read_window(hpfw_legacy_collector *c, const char **filenames, const std::
             if (w.fd >= 0) ::close(w.fd);
             return;
         }
-        int16_t *dst = reinterpret_cast<int16_t *>(static_cast<char *>(c->arena) + out[(size_t)i].arena_off);
+        int16_t *dst = reinterpret_cast<int16_t *>(static_cast<char *>(c->arena[slot]) + out[(size_t)i].arena_off);
         bool ok = true;
         try {
             if (w.channels == 1) {
@@ -499,8 +509,13 @@ size_t read_window(hpfw_legacy_collector *c, const char **filenames, const std::
         out[(size_t)i].pcm = dst;
         out[(size_t)i].ok = ok;
     });
-    if (!first_why.empty()) hpfw_internal_set_error(first_why.c_str()); // skipped files (parallel_collector.h:101-103): the message survives
-    return bytes;
+    if (std::getenv("HPFW_FFI_TIMING")) {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[hpfw ffi]   reader: headers + tables of new lengths %.1f ms, payloads %.1f ms (%u threads)\n", ms(t_begin, t_probe),
+                     ms(t_probe, t_end), team);
+    }
+    return bytes; // (skipped files, parallel_collector.h:101-103: first_why holds the message)
 }
 
 struct DevMem {
@@ -516,7 +531,7 @@ struct DevMem {
 };
 
 // the window's clips on the device: one copy of the arena (its layout is kept)
-bool upload_window(hpfw_legacy_collector *c, size_t bytes)
+bool upload_window(hpfw_legacy_collector *c, int slot, size_t bytes)
 {
     if (bytes > c->d_arena_cap) {
         if (c->d_arena) (void)hipFree(c->d_arena);
@@ -530,17 +545,26 @@ bool upload_window(hpfw_legacy_collector *c, size_t bytes)
         }
         c->d_arena_cap = want;
     }
-    return bytes == 0 || hipMemcpy(c->d_arena, c->arena, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    return bytes == 0 || hipMemcpy(c->d_arena, c->arena[slot], bytes, hipMemcpyHostToDevice) == hipSuccess;
 }
 
 // dB spectrograms [n][121][C] of n equally long clips of the window (device memory, caller frees); the clips lie side by
 // side in the device copy of the arena, the first at `first_off`
-float *group_spectrograms(hpfw_legacy_collector *c, size_t first_off, size_t n, int64_t len, const hpfw_geometry &g)
+// (the buffer comes from release_spectrograms' spare when that is large enough; *cap = its size)
+float *group_spectrograms(hpfw_legacy_collector *c, size_t first_off, size_t n, int64_t len, const hpfw_geometry &g, size_t *cap)
 {
     float *d_db = nullptr;
-    if (hipMalloc((void **)&d_db, n * (size_t)121 * g.c * 4) != hipSuccess) {
+    const size_t need = n * (size_t)121 * g.c * 4;
+    if (c->spare_db && c->spare_db_cap >= need) {
+        d_db = static_cast<float *>(c->spare_db);
+        *cap = c->spare_db_cap;
+        c->spare_db = nullptr;
+        c->spare_db_cap = 0;
+    } else if (hipMalloc((void **)&d_db, need) != hipSuccess) {
         hpfw_internal_set_error("prepare: out of device memory");
         return nullptr;
+    } else {
+        *cap = need;
     }
     const int16_t *d_pcm = reinterpret_cast<const int16_t *>(static_cast<const char *>(c->d_arena) + first_off);
     if (hpfw_gpu_stage_spectrogram(c->gpu, d_pcm, len, (int64_t)n, d_db, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
@@ -548,6 +572,18 @@ float *group_spectrograms(hpfw_legacy_collector *c, size_t first_off, size_t n, 
         return nullptr;
     }
     return d_db;
+}
+
+// a group's spectrogram buffer is done with: the larger of it and the spare stays for the next group
+void release_spectrograms(hpfw_legacy_collector *c, float *d_db, size_t cap)
+{
+    if (cap > c->spare_db_cap) {
+        if (c->spare_db) (void)hipFree(c->spare_db);
+        c->spare_db = d_db;
+        c->spare_db_cap = cap;
+    } else {
+        (void)hipFree(d_db);
+    }
 }
 
 // hashprints of n clips from their dB spectrograms: out[k] = new uint64_t[g.n_hp]
@@ -611,22 +647,54 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
     size_t keep_budget = (size_t)32 << 30;
     if (const char *e = std::getenv("HPFW_PREPARE_KEEP_GB")) keep_budget = (size_t)std::max(0.0, std::atof(e) * 1073741824.0);
     (void)hipSetDevice(hpfw_gpu_device(c->gpu));
-    size_t at = 0;
-    while (at < files.size()) {
+    // the windows: at most 256 files and about 1 GiB of audio each
+    std::vector<std::pair<size_t, size_t>> windows;
+    for (size_t at = 0; at < files.size();) {
         size_t end = at;
-        uintmax_t bytes = 0; // a window: at most 256 files and about 1 GiB of audio
+        uintmax_t bytes = 0;
         while (end < files.size() && end - at < 256 && (end == at || bytes < ((uintmax_t)1 << 30))) {
             std::error_code ec;
             const uintmax_t sz = std::filesystem::file_size(filenames[files[end]], ec);
             if (!ec) bytes += sz;
             ++end;
         }
+        windows.emplace_back(at, end);
+        at = end;
+    }
+    // window w + 1 is read (into the other arena) by a task of its own while window w is copied and extracted
+    struct Read {
         std::vector<Loaded> clips;
-        const bool timing = std::getenv("HPFW_FFI_TIMING") != nullptr; // where a window's time goes, on stderr
+        size_t used = 0;
+        double ms = 0.0;
+        std::string why;
+    };
+    const int device = hpfw_gpu_device(c->gpu);
+    auto start_read = [&](size_t w) {
+        return std::async(std::launch::async, [&, w] {
+            Read r;
+            const auto t_a = std::chrono::steady_clock::now();
+            (void)hipSetDevice(device);
+            r.used = read_window(c, (int)(w & 1), filenames, files, windows[w].first, windows[w].second, r.clips, r.why);
+            r.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count();
+            return r;
+        });
+    };
+    const bool timing = std::getenv("HPFW_FFI_TIMING") != nullptr; // where a window's time goes, on stderr
+    std::future<Read> ahead;
+    if (!windows.empty()) ahead = start_read(0);
+    for (size_t w = 0; w < windows.size(); ++w) {
+        const size_t at = windows[w].first, end = windows[w].second;
         const auto t_0 = std::chrono::steady_clock::now();
-        const size_t used = read_window(c, filenames, files, at, end, clips);
+        Read got = ahead.get();
+        if (!got.why.empty()) hpfw_internal_set_error(got.why.c_str()); // the message survives the skipped files
+        if (w + 1 < windows.size()) ahead = start_read(w + 1);
+        std::vector<Loaded> &clips = got.clips;
+        const size_t used = got.used;
         const auto t_1 = std::chrono::steady_clock::now();
-        if (!upload_window(c, used)) break;
+        if (!upload_window(c, (int)(w & 1), used)) {
+            if (ahead.valid()) (void)ahead.get(); // the task works on this function's state: it ends before we return
+            break;
+        }
         const auto t_2 = std::chrono::steady_clock::now();
         // length -> positions in the window, in input order.  A group whose files were all read lies side by side in the
         // arena; one with a failed read in its middle is cut into its contiguous runs
@@ -653,7 +721,8 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
             const int64_t len = kv.first;
             hpfw_geometry g;
             if (hpfw_gpu_geometry(c->gpu, len, &g) != 0 || g.n_frames < 2) continue; // skipped
-            float *d_db = group_spectrograms(c, clips[(size_t)pos[0]].arena_off, pos.size(), len, g);
+            size_t db_cap = 0;
+            float *d_db = group_spectrograms(c, clips[(size_t)pos[0]].arena_off, pos.size(), len, g, &db_cap);
             if (!d_db) continue;
             std::vector<int> ids;
             for (int q : pos) ids.push_back(files[at + (size_t)q]);
@@ -685,15 +754,14 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                     }
             }
             (void)hipDeviceSynchronize();
-            (void)hipFree(d_db);
+            release_spectrograms(c, d_db, db_cap);
         }
         if (timing) {
             const auto t_3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            std::fprintf(stderr, "[hpfw ffi] window of %zu files, %.1f MB: read %.1f ms, upload %.1f ms, device + results %.1f ms\n", end - at,
-                         used / 1e6, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3));
+            std::fprintf(stderr, "[hpfw ffi] window of %zu files, %.1f MB: read %.1f ms (waited %.1f ms), upload %.1f ms, device + results %.1f ms\n",
+                         end - at, used / 1e6, got.ms, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3));
         }
-        at = end;
     }
 }
 
