@@ -21,6 +21,8 @@
 #include "kernels.h"
 #include "plan.h"
 
+struct hpfw_gpu;
+
 namespace {
 
 thread_local std::string g_err;
@@ -65,7 +67,23 @@ hpfw::RadixList to_radix(const std::vector<int> &r)
     return rl;
 }
 
+// Device memory of the per-length tables.  A plan takes its memory from the handle's pool: small tables are carved out of
+// 4 MB chunks, large ones are blocks of their own, and an evicted plan's chunks and blocks go back to the pool for the next
+// length (a corpus of tracks brings a new length with every file: ~40 hipMalloc and, at eviction, as many hipFree per plan
+// cost more than generating the tables).
+void *pool_take(hpfw_gpu *h, size_t bytes);
+void pool_give(hpfw_gpu *h, void *p, size_t bytes);
+
 struct DevPlan {
+    hpfw_gpu *owner = nullptr;
+    std::vector<std::pair<void *, size_t>> blocks; // what this plan holds of the pool
+    char *cur = nullptr;                           // the open chunk
+    size_t left = 0;
+    // small tables are written to a host image of the open chunk and go over in one copy per run of them (plan_flush):
+    // some thirty-five synchronous copies of a few KB each cost more than the tables' bytes
+    char *chunk_base = nullptr;
+    std::vector<char> stage;
+    std::vector<std::pair<size_t, size_t>> staged; // (offset, bytes) written to the image, in order
     hpfw::HostPlan hp;
     hpfw::ColsQArgs cols;
     hpfw::Rows2Out rows_out;
@@ -73,14 +91,80 @@ struct DevPlan {
     hpfw::BzArgs bz; // clip lengths with a prime factor above 7 (hp.bluestein)
     hpfw::CqPlanDev cq;
     std::vector<hpfw::CqClassDev> cls;
-    std::vector<void *> owned;
     size_t bytes = 0;      // device memory of the tables
     uint64_t last_use = 0; // for the least-recently-used eviction in get_plan
     ~DevPlan()
     {
-        for (void *p : owned) (void)hipFree(p);
+        for (auto &b : blocks) pool_give(owner, b.first, b.second);
     }
 };
+
+constexpr size_t kPlanChunk = (size_t)4 << 20;
+
+int plan_flush(DevPlan *dp)
+{
+    size_t i = 0;
+    while (i < dp->staged.size()) {
+        size_t off = dp->staged[i].first, end = off + dp->staged[i].second;
+        // (a run = tables in adjacent 256-byte slots; a table the device fills itself, in between, ends the run)
+        for (++i; i < dp->staged.size() && dp->staged[i].first == (end + 255) / 256 * 256; ++i) end = dp->staged[i].first + dp->staged[i].second;
+        HIP_TRY(hipMemcpy(dp->chunk_base + off, dp->stage.data() + off, end - off, hipMemcpyHostToDevice));
+    }
+    dp->staged.clear();
+    return 0;
+}
+
+int plan_alloc(DevPlan *dp, size_t bytes, void **out)
+{
+    bytes = (bytes + 255) / 256 * 256;
+    if (bytes >= kPlanChunk / 4) { // a block of its own, in 64 KB steps (equal sizes recur: lengths near each other share n1 and n2)
+        const size_t size = (bytes + 65535) / 65536 * 65536;
+        void *p = pool_take(dp->owner, size);
+        if (!p) return fail(HPFW_E_HIP, "out of device memory for the tables of a clip length");
+        dp->blocks.emplace_back(p, size);
+        *out = p;
+        return 0;
+    }
+    if (dp->left < bytes) {
+        int rc = plan_flush(dp);
+        if (rc) return rc;
+        void *p = pool_take(dp->owner, kPlanChunk);
+        if (!p) return fail(HPFW_E_HIP, "out of device memory for the tables of a clip length");
+        dp->blocks.emplace_back(p, kPlanChunk);
+        dp->cur = dp->chunk_base = static_cast<char *>(p);
+        dp->left = kPlanChunk;
+        dp->stage.resize(kPlanChunk);
+    }
+    *out = dp->cur;
+    dp->cur += bytes;
+    dp->left -= bytes;
+    return 0;
+}
+
+template <class T>
+int upload(const std::vector<T> &v, const T **out, DevPlan *dp)
+{
+    g_uploaded += v.size() * sizeof(T);
+    if (v.empty()) {
+        *out = nullptr;
+        return 0;
+    }
+    void *d = nullptr;
+    const size_t bytes = v.size() * sizeof(T);
+    int rc = plan_alloc(dp, bytes, &d);
+    if (rc) return rc;
+    const bool in_chunk = dp->chunk_base && static_cast<char *>(d) >= dp->chunk_base && static_cast<char *>(d) < dp->chunk_base + kPlanChunk &&
+                          bytes < kPlanChunk / 4;
+    if (in_chunk) {
+        const size_t off = (size_t)(static_cast<char *>(d) - dp->chunk_base);
+        std::memcpy(dp->stage.data() + off, v.data(), bytes);
+        dp->staged.emplace_back(off, bytes);
+    } else {
+        HIP_TRY(hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
+    }
+    *out = reinterpret_cast<const T *>(d);
+    return 0;
+}
 
 enum KernelKind { K_ROWS = 0, K_COLS, K_CQ, K_DB, K_PROJECT, K_PACK, K_SCAN, K_TOPK, K_PAIRS, K_COUNT };
 const char *const kKernelNames[K_COUNT] = {"fwd_rows", "fwd_cols", "cq_chirpz", "db",
@@ -107,6 +191,8 @@ struct hpfw_gpu {
     std::set<int64_t> host_seen; // lengths being prepared, prepared, or resident on the device (not prepared again while they are)
     size_t plan_bytes = 0;
     uint64_t plan_clock = 0;
+    std::multimap<size_t, void *> dev_pool; // free chunks and blocks of evicted plans, by size
+    size_t dev_pool_bytes = 0;
     unsigned conventions = 0; // hpfw_gpu_set_conventions: essentia conventions that cannot be checked offline
     int batch = 1024; // clips per pass: ~10 GB of workspace at 30 s; every launch fills the 256 CUs many times over
     // extraction workspace
@@ -202,6 +288,38 @@ int ensure(void **p, size_t *cap, size_t need)
     return 0;
 }
 
+
+void *pool_take(hpfw_gpu *h, size_t bytes)
+{
+    auto it = h->dev_pool.find(bytes);
+    if (it != h->dev_pool.end()) {
+        void *p = it->second;
+        h->dev_pool.erase(it);
+        h->dev_pool_bytes -= bytes;
+        return p;
+    }
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) { // the pool may be holding what is missing
+        for (auto &kv : h->dev_pool) (void)hipFree(kv.second);
+        h->dev_pool.clear();
+        h->dev_pool_bytes = 0;
+        (void)hipGetLastError();
+        if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    }
+    return d;
+}
+
+void pool_give(hpfw_gpu *h, void *p, size_t bytes)
+{
+    if (h && h->dev_pool_bytes + bytes <= ((size_t)4 << 30)) {
+        h->dev_pool.emplace(bytes, p);
+        h->dev_pool_bytes += bytes;
+    } else {
+        (void)hipFree(p);
+    }
+}
+
+
 // Every entry point of a handle works in the handle's shared workspaces (ws[], d_clipmax, d_best, d_qa, the
 // index itself ...) and only enqueues on the caller's stream.  Two calls on different streams (a torch
 // side stream and the null stream, or the private non-blocking streams of the *_host entry points) would
@@ -267,6 +385,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     }
     g_uploaded = 0;
     auto dp = std::make_unique<DevPlan>();
+    dp->owner = h;
     std::string why;
     bool have_host = false;
     {
@@ -302,9 +421,9 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         ra.groups.r2[g] = p.groups[g].second;
         ra.groups.tw_off[g] = p.rows_gtw_off[g];
     }
-    if ((rc = upload(p.rows_gtw, reinterpret_cast<const hpfw::HostCf **>(&ra.gtw), dp->owned))) return rc;
-    if ((rc = upload(p.pos_n2, &ra.pos_n2, dp->owned))) return rc;
-    if ((rc = upload(p.kb_last, &ra.kb_last, dp->owned))) return rc;
+    if ((rc = upload(p.rows_gtw, reinterpret_cast<const hpfw::HostCf **>(&ra.gtw), dp.get()))) return rc;
+    if ((rc = upload(p.pos_n2, &ra.pos_n2, dp.get()))) return rc;
+    if ((rc = upload(p.kb_last, &ra.kb_last, dp.get()))) return rc;
     if (hpfw::fwd_rows_lds_bytes(ra) > 160 * 1024) return fail(HPFW_E_UNSUPPORTED, "n2 exceeds the LDS");
     hpfw::BzArgs &bz = dp->bz;
     std::memset(&bz, 0, sizeof(bz));
@@ -339,11 +458,11 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
             const float **slot[3] = {&bz.apack1, &bz.apack3, &bz.apack2};
             for (int i = 0; i < 3; ++i) {
                 void *d = nullptr;
-                HIP_TRY(hipMalloc(&d, bytes[i]));
-                dp->owned.push_back(d);
+                if ((rc = plan_alloc(dp.get(), bytes[i], &d))) return rc;
                 g_uploaded += bytes[i];
                 *slot[i] = static_cast<const float *>(d);
             }
+            if ((rc = plan_flush(dp.get()))) return rc; // the row transform's tables are used by the kernels below
             hpfw::launch_bz_pack_stages(bz, d_tw_n1, const_cast<float *>(bz.apack1), const_cast<float *>(bz.apack3), nullptr);
             hpfw::launch_bz_pack_coefficients(p.n1, bz.k1lo, bz.k1n, d_tw_n1, bz.n_tiles2, const_cast<float *>(bz.apack2), nullptr);
         }
@@ -356,8 +475,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
                                     reinterpret_cast<const void **>(&bz.bhat), reinterpret_cast<const void **>(&bz.wk)};
             for (int i = 0; i < 4; ++i) {
                 void *d = nullptr;
-                HIP_TRY(hipMalloc(&d, bytes[i]));
-                dp->owned.push_back(d);
+                if ((rc = plan_alloc(dp.get(), bytes[i], &d))) return rc;
                 g_uploaded += bytes[i];
                 *slot[i] = d;
             }
@@ -381,11 +499,11 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         ca.mt = p.cols_mt;
         ca.ks = p.cols_ks;
         const int8_t *img = nullptr;
-        if ((rc = upload(p.cols_image, &img, dp->owned))) return rc;
+        if ((rc = upload(p.cols_image, &img, dp.get()))) return rc;
         ca.image = img;
-        if ((rc = upload(p.cols_corr, &ca.corr, dp->owned))) return rc;
-        if ((rc = upload(p.ts_seed, reinterpret_cast<const hpfw::HostCf **>(&dp->rows_out.seed), dp->owned))) return rc;
-        if ((rc = upload(p.ts_step, reinterpret_cast<const hpfw::HostCf **>(&dp->rows_out.step), dp->owned))) return rc;
+        if ((rc = upload(p.cols_corr, &ca.corr, dp.get()))) return rc;
+        if ((rc = upload(p.ts_seed, reinterpret_cast<const hpfw::HostCf **>(&dp->rows_out.seed), dp.get()))) return rc;
+        if ((rc = upload(p.ts_step, reinterpret_cast<const hpfw::HostCf **>(&dp->rows_out.step), dp.get()))) return rc;
     }
     hpfw::CqPlanDev &c = dp->cq;
     c.kmin = p.kmin;
@@ -405,10 +523,10 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         c.xmagic = ((1ull << 40) + (unsigned long long)p.n1 - 1) / (unsigned long long)p.n1;
     }
     std::vector<int> start(p.start, p.start + 121), lg(p.lg, p.lg + 121);
-    if ((rc = upload(start, &c.start, dp->owned))) return rc;
-    if ((rc = upload(lg, &c.lg, dp->owned))) return rc;
-    if ((rc = upload(p.g_off, &c.g_off, dp->owned))) return rc;
-    if ((rc = upload(p.g, reinterpret_cast<const hpfw::HostCf **>(&c.g), dp->owned))) return rc;
+    if ((rc = upload(start, &c.start, dp.get()))) return rc;
+    if ((rc = upload(lg, &c.lg, dp.get()))) return rc;
+    if ((rc = upload(p.g_off, &c.g_off, dp.get()))) return rc;
+    if ((rc = upload(p.g, reinterpret_cast<const hpfw::HostCf **>(&c.g), dp.get()))) return rc;
     c.g2 = nullptr;
     c.g2_off = nullptr;
     c.q2a = c.nq2 = nullptr;
@@ -433,23 +551,23 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
                     const int64_t i = q1 + (int64_t)p.n1 * (q2a[j] + tq) - p.start[j];
                     if (i >= 0 && i < p.lg[j]) g2[(size_t)(g2_off[j] + (int64_t)q1 * nq2[j] + tq)] = p.g[(size_t)(p.g_off[j] + i)];
                 }
-        if ((rc = upload(g2, reinterpret_cast<const hpfw::HostCf **>(&c.g2), dp->owned))) return rc;
-        if ((rc = upload(g2_off, &c.g2_off, dp->owned))) return rc;
-        if ((rc = upload(q2a, &c.q2a, dp->owned))) return rc;
-        if ((rc = upload(nq2, &c.nq2, dp->owned))) return rc;
-        if ((rc = upload(magic, &c.nq2_magic, dp->owned))) return rc;
+        if ((rc = upload(g2, reinterpret_cast<const hpfw::HostCf **>(&c.g2), dp.get()))) return rc;
+        if ((rc = upload(g2_off, &c.g2_off, dp.get()))) return rc;
+        if ((rc = upload(q2a, &c.q2a, dp.get()))) return rc;
+        if ((rc = upload(nq2, &c.nq2, dp.get()))) return rc;
+        if ((rc = upload(magic, &c.nq2_magic, dp.get()))) return rc;
     }
     for (const hpfw::BluesteinClass &bc : p.classes) {
         hpfw::CqClassDev cd;
         cd.p = bc.p;
         cd.n_bands = (int)bc.bands.size();
         cd.radix = to_radix(bc.radix);
-        if ((rc = upload(bc.tw, reinterpret_cast<const hpfw::HostCf **>(&cd.tw), dp->owned))) return rc;
-        if ((rc = upload(bc.gtw, reinterpret_cast<const hpfw::HostCf **>(&cd.gtw.tab), dp->owned))) return rc;
+        if ((rc = upload(bc.tw, reinterpret_cast<const hpfw::HostCf **>(&cd.tw), dp.get()))) return rc;
+        if ((rc = upload(bc.gtw, reinterpret_cast<const hpfw::HostCf **>(&cd.gtw.tab), dp.get()))) return rc;
         for (int g = 0; g < 4; ++g) cd.gtw.off[g] = bc.goff[g];
         cd.gtw.mid_off = bc.mid_off;
-        if ((rc = upload(bc.vrev, reinterpret_cast<const hpfw::HostCf **>(&cd.vrev), dp->owned))) return rc;
-        if ((rc = upload(bc.bands, &cd.band, dp->owned))) return rc;
+        if ((rc = upload(bc.vrev, reinterpret_cast<const hpfw::HostCf **>(&cd.vrev), dp.get()))) return rc;
+        if ((rc = upload(bc.bands, &cd.band, dp.get()))) return rc;
         cd.len0 = bc.len0;
         cd.outer = bc.outer;
         dp->cls.push_back(cd);
@@ -492,6 +610,8 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
             h->plans.erase(lru);
         }
     }
+    if ((rc = plan_flush(dp.get()))) return rc;
+    std::vector<char>().swap(dp->stage);
     h->plan_bytes += dp->bytes;
     *out = dp.get();
     h->plans[n] = std::move(dp);
@@ -700,6 +820,8 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     (void)hipDeviceSynchronize();
     h->plans.clear();
     h->plan_bytes = 0;
+    for (auto &kv : h->dev_pool) (void)hipFree(kv.second);
+    h->dev_pool.clear();
     for (void *p : h->ws)
         if (p) (void)hipFree(p);
     if (h->d_fpack) (void)hipFree(h->d_fpack);
