@@ -215,7 +215,7 @@ def main():
         ops_per_clip = 2.0 * 9 * macs_per_clip
         achieved = ops_per_clip * clips_per_launch / pj_s / 1e12 if pj_launches else 0.0
         algorithmic = 2.0 * macs_per_clip * clips_per_launch / pj_s / 1e12 if pj_launches else 0.0
-        roof_pj = {"kernel": "hashprint_q_kernel (v_mfma_i32_32x32x32_i8, nine digit products of 24-bit fixed-point factors)",
+        roof_pj = {"kernel": "hashprint_q_kernel (v_mfma_i32_16x16x64_i8, nine digit products of 24-bit fixed-point factors)",
                    "bound": "mfma", "achieved": round(achieved, 1), "peak": round(MFMA_I8_PEAK_TOPS, 1), "unit": "TFLOP/s",
                    "unit_note": "integer work: tera int8 operations (2 per multiply-add) per second, TOP/s; 'achieved' counts the "
                                 "nine digit products the fixed-point decomposition performs per reference multiply-add",
@@ -262,8 +262,8 @@ def main():
                          "(a quarter of its time at the probe's rate); the twiddle digits (147 KB per 128 columns) come from L2")
     roof_rows = hbm_roof("fwd_rows", "fwd_rows2_kernel (per row: inter-stage twiddles, FFT_n2 in LDS, pruned stores)", rows_bytes,
                          "fwd_rows_hbm_bytes_per_clip",
-                         "bound by the per-butterfly twiddle tables it streams from L2 (144 KB per transform against 50 KB of "
-                         "data), not by HBM")
+                         "not HBM-bound: three fused LDS passes per row with a barrier each, 61 % of wave-cycles parked "
+                         "(profiles/r03_sq.json); three workgroups per CU")
     ranked = sorted([roof_pj, roof_cols, roof_rows], key=lambda r: -r["avg_launch_ms"])
     roofline, roofline_second, roofline_third = ranked
 
