@@ -528,6 +528,14 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
     }
     // G_j[i] = hann_Lg[i] e^{+i pi 3 i^2 / M} / (M P)
     p.g.resize((size_t)goff);
+    // the chirp factor of index i is the same in every band: evaluated once per i (a quarter of a million sincos less per
+    // length -- a corpus of tracks brings a new length with every file, and this table was most of a length's host cost)
+    int64_t lg_max = 0;
+    for (int j = 0; j < kBins; ++j) lg_max = std::max<int64_t>(lg_max, p.lg[j]);
+    std::vector<double> chirp_c((size_t)lg_max), chirp_s((size_t)lg_max);
+    parallel_rows((lg_max + 1023) / 1024, [&](int64_t blk) {
+        for (int64_t i = 1024 * blk; i < std::min<int64_t>(lg_max, 1024 * (blk + 1)); ++i) chirp_d(i, big_m, chirp_c[(size_t)i], chirp_s[(size_t)i]);
+    });
     parallel_rows(kBins, [&](int64_t j) {
         const int64_t lg = p.lg[j];
         const double scale = 1.0 / (((conv & kConvNoIfftScale) ? 1.0 : (double)big_m) * (double)p.psize[j]);
@@ -535,9 +543,7 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
         HostCf *gj = p.g.data() + p.g_off[(size_t)j];
         for (int64_t i = 0; i < lg; ++i) {
             const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / hann_den);
-            double cc, ss;
-            chirp_d(i, big_m, cc, ss);
-            gj[i] = {(float)(w * cc * scale), (float)(w * ss * scale)};
+            gj[i] = {(float)(w * chirp_c[(size_t)i] * scale), (float)(w * chirp_s[(size_t)i] * scale)};
         }
     });
     return true;
