@@ -13,6 +13,9 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 namespace hpfw {
@@ -36,9 +39,36 @@ HostCf twiddle_f(int64_t m, int64_t n)
     return {(float)c, (float)s};
 }
 
+// twiddle_d(m, n) for m = 0 .. n - 1 as (re, im) pairs, computed once per n and process (the values are a function of
+// (m, n) alone).  The transforms of a corpus share a handful of lengths -- the row length 6300, the chirp-z sizes 2^a and
+// 3 * 2^a and their thirds -- while every file brings a new clip length: without this a length's host tables cost some
+// 160 000 sincos, three quarters of them for twiddles computed for the previous file already.  Sizes above 2^16 (the
+// clip-length-sized tables of the 7-smooth path) are not kept.
+const std::vector<double> *twiddle_d_table(int64_t n)
+{
+    if (n > (1 << 16)) return nullptr;
+    static std::mutex mtx;
+    static std::map<int64_t, std::unique_ptr<std::vector<double>>> tables;
+    {
+        std::scoped_lock lock(mtx);
+        auto it = tables.find(n);
+        if (it != tables.end()) return it->second.get();
+    }
+    auto t = std::make_unique<std::vector<double>>((size_t)(2 * n));
+    for (int64_t m = 0; m < n; ++m) twiddle_d(m, n, (*t)[(size_t)(2 * m)], (*t)[(size_t)(2 * m + 1)]);
+    std::scoped_lock lock(mtx);
+    auto &slot = tables[n];
+    if (!slot) slot = std::move(t); // (another thread may have been faster: its table holds the same values)
+    return slot.get();
+}
+
 std::vector<HostCf> twiddle_table(int64_t n)
 {
     std::vector<HostCf> t((size_t)n);
+    if (const std::vector<double> *d = twiddle_d_table(n)) {
+        for (int64_t m = 0; m < n; ++m) t[(size_t)m] = {(float)(*d)[(size_t)(2 * m)], (float)(*d)[(size_t)(2 * m + 1)]};
+        return t;
+    }
     for (int64_t m = 0; m < n; ++m) t[(size_t)m] = twiddle_f(m, n);
     return t;
 }
@@ -66,11 +96,17 @@ void fft_r2_double(std::vector<double> &re, std::vector<double> &im)
             std::swap(im[i], im[j]);
         }
     }
+    const std::vector<double> *tab = twiddle_d_table(n);
     for (int64_t len = 2; len <= n; len <<= 1) {
         const int64_t half = len >> 1, ts = n / len;
         for (int64_t j = 0; j < half; ++j) {
             double wr, wi;
-            twiddle_d(ts * j, n, wr, wi);
+            if (tab) {
+                wr = (*tab)[(size_t)(2 * ts * j)];
+                wi = (*tab)[(size_t)(2 * ts * j + 1)];
+            } else {
+                twiddle_d(ts * j, n, wr, wi);
+            }
             for (int64_t base = 0; base < n; base += len) {
                 const int64_t ia = base + j, ib = ia + half;
                 const double tr = wr * re[ib] - wi * im[ib];
@@ -104,11 +140,20 @@ void dft_double(std::vector<double> &re, std::vector<double> &im)
         }
         fft_r2_double(fr[r], fi[r]);
     }
+    const std::vector<double> *tab = twiddle_d_table(n);
     for (int64_t k = 0; k < n; ++k) {
         const size_t km = (size_t)(k % m);
         double w1r, w1i, w2r, w2i;
-        twiddle_d(k, n, w1r, w1i);
-        twiddle_d((2 * k) % n, n, w2r, w2i);
+        if (tab) {
+            const size_t k2 = (size_t)((2 * k) % n);
+            w1r = (*tab)[(size_t)(2 * k)];
+            w1i = (*tab)[(size_t)(2 * k + 1)];
+            w2r = (*tab)[2 * k2];
+            w2i = (*tab)[2 * k2 + 1];
+        } else {
+            twiddle_d(k, n, w1r, w1i);
+            twiddle_d((2 * k) % n, n, w2r, w2i);
+        }
         const double ar = fr[0][km] + (w1r * fr[1][km] - w1i * fi[1][km]);
         const double ai = fi[0][km] + (w1r * fi[1][km] + w1i * fr[1][km]);
         re[(size_t)k] = ar + (w2r * fr[2][km] - w2i * fi[2][km]);

@@ -76,3 +76,7 @@ for P in (3072,6144,12288,4096,8192):
                     best.append((tot,s,m,(t or 0),n,round(grow,3)))
     best.sort()
     print(P, 'ideal', idl, best[:5])
+print("xor swizzles (no spare slots)")
+sw={'xor5':lambda i:i^((i>>4)&31),'xor4':lambda i:i^((i>>4)&15),'xor5b':lambda i:i^((i>>5)&31),'xor54':lambda i:i^(((i>>4)^(i>>9))&31)}
+for P in (3072,4096,6144,8192,12288):
+    print(P,{k:sim(P,f) for k,f in sw.items()})
