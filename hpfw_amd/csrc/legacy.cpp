@@ -187,6 +187,9 @@ struct hpfw_legacy_collector {
     // hundreds of MB of device memory per window stalls the reader threads, who share the address space)
     void *spare_db = nullptr;
     size_t spare_db_cap = 0;
+    // hashprints of a whole window when nothing is learned or cached (calc_hashprints): device buffer and pinned host copy
+    void *d_hp_win = nullptr, *h_hp_win = nullptr;
+    size_t hp_win_cap = 0;
     void *arena[2] = {nullptr, nullptr}, *d_arena = nullptr;
     size_t arena_cap[2] = {0, 0}, d_arena_cap = 0;
     ~hpfw_legacy_collector()
@@ -195,6 +198,8 @@ struct hpfw_legacy_collector {
             if (a) (void)hipHostFree(a);
         if (d_arena) (void)hipFree(d_arena);
         if (spare_db) (void)hipFree(spare_db);
+        if (d_hp_win) (void)hipFree(d_hp_win);
+        if (h_hp_win) (void)hipHostFree(h_hp_win);
     }
 };
 
@@ -716,8 +721,61 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                 if (!run.empty()) by_len[kv.first].push_back(run);
             }
         }
+        // Nothing learned, nothing cached (calc_hashprints): every group goes straight from its PCM to hashprints in one
+        // buffer for the window -- the groups are only enqueued, one copy and one synchronisation per window
+        const bool direct = !(first && job.learn) && !(first && job.cache_spectros);
+        if (direct) {
+            struct Part {
+                const std::vector<int> *pos;
+                hpfw_geometry g;
+                size_t off; // hashprints before this group in the window's buffer
+            };
+            std::vector<Part> parts;
+            size_t total = 0;
+            for (auto &kv : by_len)
+                for (const std::vector<int> &pos : kv.second) {
+                    hpfw_geometry g;
+                    if (hpfw_gpu_geometry(c->gpu, kv.first, &g) != 0 || g.n_frames < 2 || g.n_hp <= 0) continue; // skipped
+                    parts.push_back(Part{&pos, g, total});
+                    total += pos.size() * (size_t)g.n_hp;
+                }
+            bool ok = true;
+            if (total * 8 > c->hp_win_cap) {
+                if (c->d_hp_win) (void)hipFree(c->d_hp_win);
+                if (c->h_hp_win) (void)hipHostFree(c->h_hp_win);
+                c->d_hp_win = c->h_hp_win = nullptr;
+                c->hp_win_cap = 0;
+                const size_t want = std::max(total * 8 + total * 2, (size_t)8 << 20);
+                ok = hipMalloc(&c->d_hp_win, want) == hipSuccess && hipHostMalloc(&c->h_hp_win, want, hipHostMallocDefault) == hipSuccess;
+                if (ok) c->hp_win_cap = want;
+                else hpfw_internal_set_error("prepare: out of memory for the window's hashprints");
+            }
+            std::vector<char> done(parts.size(), 0);
+            for (size_t k = 0; ok && k < parts.size(); ++k) {
+                const Part &pt = parts[k];
+                const int16_t *d_pcm = reinterpret_cast<const int16_t *>(static_cast<const char *>(c->d_arena) + clips[(size_t)(*pt.pos)[0]].arena_off);
+                done[k] = hpfw_gpu_extract_pcm16(c->gpu, d_pcm, clips[(size_t)(*pt.pos)[0]].n, (int64_t)pt.pos->size(),
+                                                 static_cast<uint64_t *>(c->d_hp_win) + pt.off, nullptr) == 0; // a failed group is skipped
+            }
+            if (ok && total > 0 && hipMemcpy(c->h_hp_win, c->d_hp_win, total * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                hpfw_internal_set_error("prepare: D2H copy failed");
+                ok = false;
+            }
+            for (size_t k = 0; ok && k < parts.size(); ++k) {
+                if (!done[k]) continue;
+                const Part &pt = parts[k];
+                for (size_t q = 0; q < pt.pos->size(); ++q) {
+                    const int id = files[at + (size_t)(*pt.pos)[q]];
+                    uint64_t *out = new uint64_t[(size_t)pt.g.n_hp];
+                    std::memcpy(out, static_cast<const uint64_t *>(c->h_hp_win) + pt.off + q * (size_t)pt.g.n_hp, (size_t)pt.g.n_hp * 8);
+                    job.hp[(size_t)id] = out;
+                    job.hp_size[(size_t)id] = (int)pt.g.n_hp;
+                }
+            }
+        }
         for (auto &kv : by_len)
           for (const std::vector<int> &pos : kv.second) {
+            if (direct) break;
             const int64_t len = kv.first;
             hpfw_geometry g;
             if (hpfw_gpu_geometry(c->gpu, len, &g) != 0 || g.n_frames < 2) continue; // skipped
