@@ -69,8 +69,10 @@ HPFW_DEVICE cf c_unpair(v2f v) { return cf{v.x, v.y}; }
         asm(ins : "=v"(o) : "v"(c_pair(a)), "v"(c_pair(b)));                              \
         return c_unpair(o);                                                               \
     }
-HPFW_PK_BINARY(c_add, "v_pk_add_f32 %0, %1, %2")
-HPFW_PK_BINARY(c_sub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")
+// (plain sums and differences as vector arithmetic: the compiler emits the same packed instruction and knows what it is --
+// around an asm statement it pads for hazards the instruction does not have)
+HPFW_DEVICE cf c_add(cf a, cf b) { return c_unpair(c_pair(a) + c_pair(b)); }
+HPFW_DEVICE cf c_sub(cf a, cf b) { return c_unpair(c_pair(a) - c_pair(b)); }
 // a + (-i) d = (a.r + d.i, a.i - d.r) and a - (-i) d = (a.r - d.i, a.i + d.r)
 HPFW_PK_BINARY(c_add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
 HPFW_PK_BINARY(c_sub_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
