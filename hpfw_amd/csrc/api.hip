@@ -444,14 +444,28 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         }
         // coefficient images of the column transforms (the first one's two stages; the second one's rows that hold
         // consumed bins), packed on the device
+        // temporaries of this block (T_n1, the generation scratch) come from the handle's pool and go back to it: hipFree
+        // waits for every stream of the device, which would stop a caller that extracts on a stream of its own from
+        // preparing the next length while the previous file's kernels run
         const cf *d_tw_n1 = nullptr;
-        std::vector<void *> tmp_owned;
-        if ((rc = upload(p.tw_n1, reinterpret_cast<const hpfw::HostCf **>(&d_tw_n1), tmp_owned))) return rc;
-        g_uploaded -= p.tw_n1.size() * sizeof(cf);
-        struct FreeTmp {
-            std::vector<void *> &v;
-            ~FreeTmp() { for (void *q : v) (void)hipFree(q); }
-        } free_tmp{tmp_owned};
+        struct PoolTmp {
+            hpfw_gpu *h;
+            std::vector<std::pair<void *, size_t>> v;
+            ~PoolTmp() { for (auto &b : v) pool_give(h, b.first, b.second); }
+            void *take(size_t bytes)
+            {
+                const size_t size = (bytes + 65535) / 65536 * 65536;
+                void *q = pool_take(h, size);
+                if (q) v.emplace_back(q, size);
+                return q;
+            }
+        } tmp{h, {}};
+        {
+            void *d = tmp.take(p.tw_n1.size() * sizeof(cf));
+            if (!d) return fail(HPFW_E_HIP, "out of device memory for the tables of a clip length");
+            HIP_TRY(hipMemcpy(d, p.tw_n1.data(), p.tw_n1.size() * sizeof(cf), hipMemcpyHostToDevice));
+            d_tw_n1 = static_cast<const cf *>(d);
+        }
         {
             const size_t bytes[3] = {(size_t)bz.a * bz.n_tiles1 * 64 * sizeof(float), (size_t)bz.a * 16 * 64 * sizeof(float),
                                      (size_t)p.n1 * bz.n_tiles2 * 64 * sizeof(float)};
@@ -480,9 +494,8 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
                 *slot[i] = d;
             }
         }
-        void *scratch = nullptr;
-        HIP_TRY(hipMalloc(&scratch, big_l * 8 + plane));
-        tmp_owned.push_back(scratch); // freed with T_n1 when this block ends, after the synchronisation below
+        void *scratch = tmp.take(big_l * 8 + plane); // back to the pool with T_n1 when this block ends, after the synchronisation below
+        if (!scratch) return fail(HPFW_E_HIP, "out of device memory for the tables of a clip length");
         hpfw::launch_bz_make_tables(ra, bz, n, static_cast<float *>(scratch), static_cast<float *>(scratch) + 2 * big_l, nullptr);
         const hipError_t launched = hipGetLastError(), done = hipStreamSynchronize(nullptr);
         if (launched != hipSuccess || done != hipSuccess)

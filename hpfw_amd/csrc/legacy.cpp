@@ -190,6 +190,9 @@ struct hpfw_legacy_collector {
     // hashprints of a whole window when nothing is learned or cached (calc_hashprints): device buffer and pinned host copy
     void *d_hp_win = nullptr, *h_hp_win = nullptr;
     size_t hp_win_cap = 0;
+    // ... on a stream of the collector's own (non-blocking): the tables of the next file's length are generated and
+    // uploaded through the default stream while the kernels of the previous file run
+    hipStream_t win_stream = nullptr;
     void *arena[2] = {nullptr, nullptr}, *d_arena = nullptr;
     size_t arena_cap[2] = {0, 0}, d_arena_cap = 0;
     ~hpfw_legacy_collector()
@@ -198,6 +201,7 @@ struct hpfw_legacy_collector {
             if (a) (void)hipHostFree(a);
         if (d_arena) (void)hipFree(d_arena);
         if (spare_db) (void)hipFree(spare_db);
+        if (win_stream) (void)hipStreamDestroy(win_stream);
         if (d_hp_win) (void)hipFree(d_hp_win);
         if (h_hp_win) (void)hipHostFree(h_hp_win);
     }
@@ -750,17 +754,24 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                 if (ok) c->hp_win_cap = want;
                 else hpfw_internal_set_error("prepare: out of memory for the window's hashprints");
             }
+            if (ok && !c->win_stream && hipStreamCreateWithFlags(&c->win_stream, hipStreamNonBlocking) != hipSuccess) {
+                c->win_stream = nullptr;
+                hpfw_internal_set_error("prepare: no stream");
+                ok = false;
+            }
             std::vector<char> done(parts.size(), 0);
             for (size_t k = 0; ok && k < parts.size(); ++k) {
                 const Part &pt = parts[k];
                 const int16_t *d_pcm = reinterpret_cast<const int16_t *>(static_cast<const char *>(c->d_arena) + clips[(size_t)(*pt.pos)[0]].arena_off);
                 done[k] = hpfw_gpu_extract_pcm16(c->gpu, d_pcm, clips[(size_t)(*pt.pos)[0]].n, (int64_t)pt.pos->size(),
-                                                 static_cast<uint64_t *>(c->d_hp_win) + pt.off, nullptr) == 0; // a failed group is skipped
+                                                 static_cast<uint64_t *>(c->d_hp_win) + pt.off, c->win_stream) == 0; // a failed group is skipped
             }
-            if (ok && total > 0 && hipMemcpy(c->h_hp_win, c->d_hp_win, total * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (ok && total > 0 && (hipMemcpyAsync(c->h_hp_win, c->d_hp_win, total * 8, hipMemcpyDeviceToHost, c->win_stream) != hipSuccess ||
+                                    hipStreamSynchronize(c->win_stream) != hipSuccess)) {
                 hpfw_internal_set_error("prepare: D2H copy failed");
                 ok = false;
             }
+            if (c->win_stream) (void)hipStreamSynchronize(c->win_stream); // (also after a failure: the arena is about to be reused)
             for (size_t k = 0; ok && k < parts.size(); ++k) {
                 if (!done[k]) continue;
                 const Part &pt = parts[k];
