@@ -266,6 +266,10 @@ struct hpfw_gpu {
     hipEvent_t order_ev = nullptr;
     hipStream_t order_stream = nullptr;
     bool order_valid = false;
+    // the tables a new length generates on the device (default stream) are awaited by the stream that first uses them
+    // (Ordered), not by the host: a caller on a stream of its own keeps preparing lengths while earlier files run
+    hipEvent_t plan_ev = nullptr;
+    bool plan_ev_pending = false;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned timing_mask = 0;
@@ -331,6 +335,10 @@ struct Ordered {
     Ordered(hpfw_gpu *h_, hipStream_t s_) : h(h_), s(s_)
     {
         if (h->order_valid && h->order_stream != s) (void)hipStreamWaitEvent(s, h->order_ev, 0);
+        if (h->plan_ev_pending) {
+            (void)hipStreamWaitEvent(s, h->plan_ev, 0);
+            h->plan_ev_pending = false; // (later calls on other streams are ordered after this one)
+        }
     }
     ~Ordered()
     {
@@ -497,9 +505,12 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         void *scratch = tmp.take(big_l * 8 + plane); // back to the pool with T_n1 when this block ends, after the synchronisation below
         if (!scratch) return fail(HPFW_E_HIP, "out of device memory for the tables of a clip length");
         hpfw::launch_bz_make_tables(ra, bz, n, static_cast<float *>(scratch), static_cast<float *>(scratch) + 2 * big_l, nullptr);
-        const hipError_t launched = hipGetLastError(), done = hipStreamSynchronize(nullptr);
+        // (no host wait: the temporaries go back to the pool, whose next user is ordered after these kernels on the default
+        // stream like every table generation and upload; the stream that extracts waits for the event)
+        const hipError_t launched = hipGetLastError(), done = hipEventRecord(h->plan_ev, nullptr);
         if (launched != hipSuccess || done != hipSuccess)
             return fail(HPFW_E_HIP, std::string("chirp-z tables: ") + hipGetErrorString(launched != hipSuccess ? launched : done));
+        h->plan_ev_pending = true;
     }
     // S6 (7-smooth lengths): the column stage's twiddle digits, digit-offset correction and inter-stage twiddles
     hpfw::ColsQArgs &ca = dp->cols;
@@ -816,7 +827,8 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     if (const char *e = std::getenv("HPFW_PROJECTION")) // "f32": handles start with the f32 fma chain (hpfw_gpu_set_projection(h, 0))
         h->projection = std::strcmp(e, "f32") == 0 ? 0 : 1;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->plan_ev, hipEventDisableTiming) != hipSuccess) {
         delete h;
         return fail(HPFW_E_HIP, "hipEventCreate failed");
     }
@@ -882,6 +894,7 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (h->plan_ev) (void)hipEventDestroy(h->plan_ev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
