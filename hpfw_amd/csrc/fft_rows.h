@@ -27,11 +27,10 @@ struct RowGroups {
 struct RowsArgs {
     int n1, n2, h;            // N = n1 * n2, h = n2 / 2 + 1
     int hpad;                 // row stride (floats) of the planar output, a multiple of 32
-    int pair_stride;          // distance between consecutive time steps of a pair stream, in pairs:
-                              // 1 after the pcm_pairs pre-pass, n1 / 2 when read in place (n1 even)
+    int pair_stride;          // (the Mel front-end's frame pairs: 1)
     RowGroups groups;
     const cf *gtw;            // per-butterfly twiddles of every group (see group_twiddle_count)
-    const cf *tw_big;         // T_N[a * k2]  [n1][h]
+    const cf *tw_big;         // the table the split spectra are multiplied by (Mel front-end: rows of ones)
     const int *pos_n2;        // digit-reversed position of output k2
     const int *kb_last;       // output k2 = kb_last[b] + (n2 / len) f of the last group's block b (see rows_last_*)
 };
