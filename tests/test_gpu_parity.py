@@ -443,9 +443,13 @@ def test_plan_cache_eviction(torch_cuda, oracle, filters, monkeypatch):
     g = hpfw_amd.Gpu(0)
     g.set_filters(filters)
     clips = {sec: synth.gen_clip(77 + i, sec) for i, sec in enumerate((2.0, 3.0, 4.0))}
+    # two lengths with a prime factor above 7 as well: their tables are generated on the device, in memory that comes from
+    # the handle's pool and goes back to it at every eviction
+    clips["3 s - 1"] = synth.gen_clip(81, 3.0)[:-1]
+    clips["2 s + 5"] = np.concatenate([synth.gen_clip(82, 2.0), synth.gen_clip(83, 2.0)[:5]])
     want = {sec: oracle.Plan(c.size).extract(filters, c) for sec, c in clips.items()}
-    for sec in (2.0, 3.0, 2.0, 4.0, 3.0, 2.0):
-        assert np.array_equal(g.extract(clips[sec])[0], want[sec])
+    for sec in (2.0, "3 s - 1", 3.0, 2.0, "2 s + 5", 4.0, "3 s - 1", 3.0, "2 s + 5", 2.0):
+        assert np.array_equal(g.extract(clips[sec])[0], want[sec]), sec
     g.close()
 
 
