@@ -69,6 +69,28 @@ def test_legacy_ffi_through_python_twin(wav_set, oracle, filters):
     assert raw[:8] == np.array([64, 2420], np.int32).tobytes() and raw[8:] == np.asarray(filters, np.float32).tobytes()
 
 
+def test_calc_hashprints_a_new_length_with_every_file(wav_set, oracle, filters, tmp_path):
+    """a directory of tracks brings a new length with every file (parallel_collector.h:82-137 reads whatever the files
+    hold): one batched call over seven files of seven lengths -- 7-smooth and not -- returns the oracle's hashprints in
+    input order; the tables of each length are prepared by the reader threads and generated on the device while the
+    previous file's kernels run"""
+    d, clips, _, _ = wav_set
+    pc = hpfw_amd.ParallelCollector()
+    pc.load(str(d / "cache") + "/")
+    paths, pcms = [], []
+    for i in range(7):
+        pcm = synth.gen_clip(900 + i, 3.0)[: 3 * 44100 - 11 * i]   # 132300, 132289, ... samples
+        p = str(tmp_path / f"odd{i}.wav")
+        synth.write_wav(p, pcm)
+        paths.append(p)
+        pcms.append(pcm)
+    for rounds in range(2):                                        # the second call finds the tables cached
+        got = pc.calc_hashprints(paths)
+        assert [n for _, n in got] == [f"odd{i}" for i in range(7)]
+        for (hp, _), pcm in zip(got, pcms):
+            assert np.array_equal(hp, oracle.Plan(pcm.size).extract(filters, pcm))
+
+
 def test_stereo_and_unsupported_wav(wav_set, filters, tmp_path):
     d, clips, _, _ = wav_set
     pc = hpfw_amd.ParallelCollector()
