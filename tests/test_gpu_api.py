@@ -300,6 +300,33 @@ def test_python_liveid_and_notebook_example(wav_set, oracle, filters, tmp_path):
     assert [n for _, n in got] == [f"track{i:02d}" for i in range(4)] and all(np.array_equal(a, b) for (a, _), b in zip(got, db))
 
 
+def test_constant_q_classes_side_by_side_or_in_turn(torch_cuda, oracle, filters, monkeypatch):
+    """the size classes of the constant-Q stage are launched on forked streams that join the caller's before the next stage
+    (api.hip run_front); HPFW_CQ_SERIAL=1 launches them one after the other: the same hashprints either way, on the null
+    stream and on a side stream, with another call enqueued right behind on a third stream"""
+    torch = torch_cuda
+    clips = np.stack([synth.gen_clip(640 + i, 12.0) for i in range(3)])
+    plan = oracle.Plan(clips.shape[1])
+    want = plan.extract_batch(filters, clips, n_threads=3)
+    d = torch.from_numpy(clips).cuda()
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("HPFW_CQ_SERIAL", "1")
+        g = hpfw_amd.Gpu(0)                                   # the switch is read when a handle is created
+        g.set_filters(filters)
+        side, other = torch.cuda.Stream(), torch.cuda.Stream()
+        for stream in (0, side.cuda_stream):
+            hp = torch.zeros((3, plan.n_hp), dtype=torch.int64, device="cuda")
+            hp2 = torch.zeros_like(hp)
+            torch.cuda.synchronize()
+            g.extract_dev(d.data_ptr(), clips.shape[1], 3, hp.data_ptr(), stream)
+            g.extract_dev(d.data_ptr(), clips.shape[1], 3, hp2.data_ptr(), other.cuda_stream)   # shares the workspaces: ordered by the handle
+            torch.cuda.synchronize()
+            assert np.array_equal(hp.cpu().numpy().view(np.uint64), want), (serial, stream)
+            assert np.array_equal(hp2.cpu().numpy().view(np.uint64), want), (serial, stream)
+        g.close()
+
+
 def test_streams_mixed_without_sync(torch_cuda, oracle, filters):
     """One handle, three streams, no synchronisation by the caller: a device call on a non-blocking side
     stream, the host entry point (its own private streams), a device call on the null stream and an index
