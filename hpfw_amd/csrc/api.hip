@@ -975,12 +975,28 @@ int hpfw_gpu_stage_delta_q(hpfw_gpu *h, const float *d_db, int64_t n_clips, int6
 int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out)
 {
     if (!h || !out) return fail(HPFW_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    DevPlan *dp;
-    int rc = get_plan(h, n_samples, &dp);
-    if (rc) return rc;
-    const hpfw::HostPlan &p = dp->hp;
-    *out = {p.n, p.n1, p.n2, p.kmin, p.kmax, p.m, p.c, p.n_frames, p.n_hp};
+    // The sizes alone: from the cached plan or from the host half a reader thread prepared, else by the geometry part of
+    // the plan (microseconds).  No device table is built for the question -- a caller that asks for the geometry of every
+    // file of a window before extracting the first would otherwise build all their tables with the GPU idle.
+    auto fill = [&](const hpfw::HostPlan &p) { *out = {p.n, p.n1, p.n2, p.kmin, p.kmax, p.m, p.c, p.n_frames, p.n_hp}; };
+    auto it = h->plans.find(n_samples);
+    if (it != h->plans.end()) {
+        fill(it->second->hp);
+        return 0;
+    }
+    {
+        std::scoped_lock lock(h->host_mtx);
+        auto ready = h->host_ready.find(n_samples);
+        if (ready != h->host_ready.end() && ready->second && ready->second->n == n_samples) {
+            fill(*ready->second);
+            return 0;
+        }
+    }
+    hpfw::HostPlan hp;
+    std::string why;
+    if (!hpfw::build_plan(n_samples, hp, why, true, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions))
+        return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n_samples) + ": " + why);
+    fill(hp);
     return 0;
 }
 
