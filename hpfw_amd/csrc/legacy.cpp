@@ -193,13 +193,17 @@ struct hpfw_legacy_collector {
     // ... on a stream of the collector's own (non-blocking): the tables of the next file's length are generated and
     // uploaded through the default stream while the kernels of the previous file run
     hipStream_t win_stream = nullptr;
-    void *arena[2] = {nullptr, nullptr}, *d_arena = nullptr;
-    size_t arena_cap[2] = {0, 0}, d_arena_cap = 0;
+    void *arena[2] = {nullptr, nullptr};
+    size_t arena_cap[2] = {0, 0};
+    // ... and two device copies in turn: window w + 1 is uploaded while the kernels of window w read theirs
+    void *d_arena_buf[2] = {nullptr, nullptr}, *d_arena = nullptr; // d_arena: the copy of the window in hand
+    size_t d_arena_cap[2] = {0, 0};
     ~hpfw_legacy_collector()
     {
         for (void *a : arena)
             if (a) (void)hipHostFree(a);
-        if (d_arena) (void)hipFree(d_arena);
+        for (void *a : d_arena_buf)
+            if (a) (void)hipFree(a);
         if (spare_db) (void)hipFree(spare_db);
         if (win_stream) (void)hipStreamDestroy(win_stream);
         if (d_hp_win) (void)hipFree(d_hp_win);
@@ -542,18 +546,19 @@ struct DevMem {
 // the window's clips on the device: one copy of the arena (its layout is kept)
 bool upload_window(hpfw_legacy_collector *c, int slot, size_t bytes)
 {
-    if (bytes > c->d_arena_cap) {
-        if (c->d_arena) (void)hipFree(c->d_arena);
-        c->d_arena = nullptr;
-        c->d_arena_cap = 0;
+    if (bytes > c->d_arena_cap[slot]) {
+        if (c->d_arena_buf[slot]) (void)hipFree(c->d_arena_buf[slot]);
+        c->d_arena_buf[slot] = nullptr;
+        c->d_arena_cap[slot] = 0;
         const size_t want = std::max(bytes + bytes / 4, (size_t)64 << 20);
-        if (hipMalloc(&c->d_arena, want) != hipSuccess) {
-            c->d_arena = nullptr;
+        if (hipMalloc(&c->d_arena_buf[slot], want) != hipSuccess) {
+            c->d_arena_buf[slot] = nullptr;
             hpfw_internal_set_error("prepare: out of device memory");
             return false;
         }
-        c->d_arena_cap = want;
+        c->d_arena_cap[slot] = want;
     }
+    c->d_arena = c->d_arena_buf[slot];
     return bytes == 0 || hipMemcpy(c->d_arena, c->arena[slot], bytes, hipMemcpyHostToDevice) == hipSuccess;
 }
 
@@ -689,6 +694,38 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
         });
     };
     const bool timing = std::getenv("HPFW_FFI_TIMING") != nullptr; // where a window's time goes, on stderr
+    // calc_hashprints (nothing learned or cached): the extraction of window w is enqueued on the collector's stream and its
+    // hashprints are fetched only after window w + 1 has been uploaded -- the upload runs under the kernels
+    struct Part {
+        std::vector<int> pos; // positions of the group's clips in the window
+        hpfw_geometry g;
+        size_t off;           // hashprints before this group in the window's buffer
+        bool done;
+    };
+    struct Pending {
+        bool active = false, ok = true;
+        std::vector<Part> parts;
+        size_t total = 0, at = 0;
+    } pend;
+    auto finish = [&]() { // the results of the window whose kernels are in flight
+        if (!pend.active) return;
+        pend.active = false;
+        if (c->win_stream && hipStreamSynchronize(c->win_stream) != hipSuccess) {
+            hpfw_internal_set_error("prepare: the window's kernels failed");
+            pend.ok = false;
+        }
+        for (size_t k = 0; pend.ok && k < pend.parts.size(); ++k) {
+            const Part &pt = pend.parts[k];
+            if (!pt.done) continue;
+            for (size_t q = 0; q < pt.pos.size(); ++q) {
+                const int id = files[pend.at + (size_t)pt.pos[q]];
+                uint64_t *out = new uint64_t[(size_t)pt.g.n_hp];
+                std::memcpy(out, static_cast<const uint64_t *>(c->h_hp_win) + pt.off + q * (size_t)pt.g.n_hp, (size_t)pt.g.n_hp * 8);
+                job.hp[(size_t)id] = out;
+                job.hp_size[(size_t)id] = (int)pt.g.n_hp;
+            }
+        }
+    };
     std::future<Read> ahead;
     if (!windows.empty()) ahead = start_read(0);
     for (size_t w = 0; w < windows.size(); ++w) {
@@ -704,6 +741,7 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
             if (ahead.valid()) (void)ahead.get(); // the task works on this function's state: it ends before we return
             break;
         }
+        finish(); // (the previous window's kernels ran under this upload)
         const auto t_2 = std::chrono::steady_clock::now();
         // length -> positions in the window, in input order.  A group whose files were all read lies side by side in the
         // arena; one with a failed read in its middle is cut into its contiguous runs
@@ -729,20 +767,18 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
         // buffer for the window -- the groups are only enqueued, one copy and one synchronisation per window
         const bool direct = !(first && job.learn) && !(first && job.cache_spectros);
         if (direct) {
-            struct Part {
-                const std::vector<int> *pos;
-                hpfw_geometry g;
-                size_t off; // hashprints before this group in the window's buffer
-            };
-            std::vector<Part> parts;
-            size_t total = 0;
+            pend.parts.clear();
+            pend.total = 0;
+            pend.at = at;
+            pend.ok = true;
             for (auto &kv : by_len)
                 for (const std::vector<int> &pos : kv.second) {
                     hpfw_geometry g;
                     if (hpfw_gpu_geometry(c->gpu, kv.first, &g) != 0 || g.n_frames < 2 || g.n_hp <= 0) continue; // skipped
-                    parts.push_back(Part{&pos, g, total});
-                    total += pos.size() * (size_t)g.n_hp;
+                    pend.parts.push_back(Part{pos, g, pend.total, false});
+                    pend.total += pos.size() * (size_t)g.n_hp;
                 }
+            const size_t total = pend.total;
             bool ok = true;
             if (total * 8 > c->hp_win_cap) {
                 if (c->d_hp_win) (void)hipFree(c->d_hp_win);
@@ -759,30 +795,18 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                 hpfw_internal_set_error("prepare: no stream");
                 ok = false;
             }
-            std::vector<char> done(parts.size(), 0);
-            for (size_t k = 0; ok && k < parts.size(); ++k) {
-                const Part &pt = parts[k];
-                const int16_t *d_pcm = reinterpret_cast<const int16_t *>(static_cast<const char *>(c->d_arena) + clips[(size_t)(*pt.pos)[0]].arena_off);
-                done[k] = hpfw_gpu_extract_pcm16(c->gpu, d_pcm, clips[(size_t)(*pt.pos)[0]].n, (int64_t)pt.pos->size(),
+            for (size_t k = 0; ok && k < pend.parts.size(); ++k) {
+                Part &pt = pend.parts[k];
+                const int16_t *d_pcm = reinterpret_cast<const int16_t *>(static_cast<const char *>(c->d_arena) + clips[(size_t)pt.pos[0]].arena_off);
+                pt.done = hpfw_gpu_extract_pcm16(c->gpu, d_pcm, clips[(size_t)pt.pos[0]].n, (int64_t)pt.pos.size(),
                                                  static_cast<uint64_t *>(c->d_hp_win) + pt.off, c->win_stream) == 0; // a failed group is skipped
             }
-            if (ok && total > 0 && (hipMemcpyAsync(c->h_hp_win, c->d_hp_win, total * 8, hipMemcpyDeviceToHost, c->win_stream) != hipSuccess ||
-                                    hipStreamSynchronize(c->win_stream) != hipSuccess)) {
+            if (ok && total > 0 && hipMemcpyAsync(c->h_hp_win, c->d_hp_win, total * 8, hipMemcpyDeviceToHost, c->win_stream) != hipSuccess) {
                 hpfw_internal_set_error("prepare: D2H copy failed");
                 ok = false;
             }
-            if (c->win_stream) (void)hipStreamSynchronize(c->win_stream); // (also after a failure: the arena is about to be reused)
-            for (size_t k = 0; ok && k < parts.size(); ++k) {
-                if (!done[k]) continue;
-                const Part &pt = parts[k];
-                for (size_t q = 0; q < pt.pos->size(); ++q) {
-                    const int id = files[at + (size_t)(*pt.pos)[q]];
-                    uint64_t *out = new uint64_t[(size_t)pt.g.n_hp];
-                    std::memcpy(out, static_cast<const uint64_t *>(c->h_hp_win) + pt.off + q * (size_t)pt.g.n_hp, (size_t)pt.g.n_hp * 8);
-                    job.hp[(size_t)id] = out;
-                    job.hp_size[(size_t)id] = (int)pt.g.n_hp;
-                }
-            }
+            pend.ok = ok;
+            pend.active = true; // fetched by finish(): after the next window's upload, or after the last window
         }
         for (auto &kv : by_len)
           for (const std::vector<int> &pos : kv.second) {
@@ -832,6 +856,7 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                          end - at, used / 1e6, got.ms, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3));
         }
     }
+    finish();
 }
 
 static void prepare_accumulate(hpfw_legacy_collector *c, const char **filenames, int n, hpfw_prepare_job &job)
