@@ -193,6 +193,9 @@ struct hpfw_legacy_collector {
     // ... on a stream of the collector's own (non-blocking): the tables of the next file's length are generated and
     // uploaded through the default stream while the kernels of the previous file run
     hipStream_t win_stream = nullptr;
+    // pinned host copy of a group's spectrograms on their way to cache/spectros/ (grow-only)
+    void *h_spec = nullptr;
+    size_t h_spec_cap = 0;
     void *arena[2] = {nullptr, nullptr};
     size_t arena_cap[2] = {0, 0};
     // ... and two device copies in turn: window w + 1 is uploaded while the kernels of window w read theirs
@@ -206,6 +209,7 @@ struct hpfw_legacy_collector {
             if (a) (void)hipFree(a);
         if (spare_db) (void)hipFree(spare_db);
         if (win_stream) (void)hipStreamDestroy(win_stream);
+        if (h_spec) (void)hipHostFree(h_spec);
         if (d_hp_win) (void)hipFree(d_hp_win);
         if (h_hp_win) (void)hipHostFree(h_hp_win);
     }
@@ -823,11 +827,18 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
             if (first && job.cache_spectros) {
                 // cache.set_spectro(filename, spectro) (parallel_collector.h:98-100): "it will also be needed
                 // when adding new tracks" -- a later prepare() recomputes every cached track's hashprints
-                std::vector<float> host(sz / 4);
-                if (hipMemcpy(host.data(), d_db, sz, hipMemcpyDeviceToHost) == hipSuccess)
+                if (sz > c->h_spec_cap) { // (pinned: the copy runs at the link's rate, not through the driver's staging)
+                    if (c->h_spec) (void)hipHostFree(c->h_spec);
+                    c->h_spec = nullptr;
+                    c->h_spec_cap = 0;
+                    if (hipHostMalloc(&c->h_spec, sz + sz / 4, hipHostMallocDefault) == hipSuccess) c->h_spec_cap = sz + sz / 4;
+                    else c->h_spec = nullptr;
+                }
+                const float *host = static_cast<const float *>(c->h_spec);
+                if (host && hipMemcpy(c->h_spec, d_db, sz, hipMemcpyDeviceToHost) == hipSuccess)
                     host_team((int)ids.size(), [&](int k) {
                         const std::string stem = std::filesystem::path(filenames[ids[(size_t)k]]).stem().string();
-                        (void)save_spectro_cereal(spectro_dir + stem, host.data() + (size_t)k * 121 * g.c, (int32_t)g.c);
+                        (void)save_spectro_cereal(spectro_dir + stem, host + (size_t)k * 121 * g.c, (int32_t)g.c);
                     });
             }
             if (first && job.learn) {
