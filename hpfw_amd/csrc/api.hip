@@ -621,7 +621,10 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     if (const char *e = std::getenv("HPFW_PLAN_CACHE_GB")) budget = (size_t)(std::max(0.0, std::atof(e)) * 1073741824.0);
     if (h->plan_bytes + dp->bytes > budget && !h->plans.empty()) {
         (void)hipDeviceSynchronize();
-        while (h->plan_bytes + dp->bytes > budget && !h->plans.empty()) {
+        // room for a quarter of the budget at once: every round of evictions costs this synchronisation, and a corpus of
+        // distinct lengths larger than the cache would otherwise pay it with every file
+        const size_t target = budget - budget / 4;
+        while (h->plan_bytes + dp->bytes > target && !h->plans.empty()) {
             auto lru = h->plans.begin();
             for (auto q = h->plans.begin(); q != h->plans.end(); ++q)
                 if (q->second->last_use < lru->second->last_use) lru = q;

@@ -799,6 +799,7 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                 hpfw_internal_set_error("prepare: no stream");
                 ok = false;
             }
+            const auto t_enq = std::chrono::steady_clock::now();
             for (size_t k = 0; ok && k < pend.parts.size(); ++k) {
                 Part &pt = pend.parts[k];
                 const int16_t *d_pcm = reinterpret_cast<const int16_t *>(static_cast<const char *>(c->d_arena) + clips[(size_t)pt.pos[0]].arena_off);
@@ -809,6 +810,9 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                 hpfw_internal_set_error("prepare: D2H copy failed");
                 ok = false;
             }
+            if (timing)
+                std::fprintf(stderr, "[hpfw ffi]   %zu groups enqueued in %.1f ms (tables of new lengths included)\n", pend.parts.size(),
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq).count());
             pend.ok = ok;
             pend.active = true; // fetched by finish(): after the next window's upload, or after the last window
         }
