@@ -740,7 +740,8 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
         Timed t(h, K_CQ, s);
         int n_lds = 0;
         for (const hpfw::CqClassDev &cd : dp->cls) n_lds += cd.outer ? 0 : 1;
-        const bool fork = h->cq_concurrent && n_lds > 1;
+        // (a handful of clips: the five launches are tens of microseconds each, and forking costs the host a dozen calls)
+        const bool fork = h->cq_concurrent && n_lds > 1 && nb >= 4;
         if (fork && !h->cq_fork) {
             bool ok = hipEventCreateWithFlags(&h->cq_fork, hipEventDisableTiming) == hipSuccess;
             for (int k = 0; k < hpfw_gpu::kCqSide && ok; ++k)

@@ -305,9 +305,9 @@ def test_constant_q_classes_side_by_side_or_in_turn(torch_cuda, oracle, filters,
     (api.hip run_front); HPFW_CQ_SERIAL=1 launches them one after the other: the same hashprints either way, on the null
     stream and on a side stream, with another call enqueued right behind on a third stream"""
     torch = torch_cuda
-    clips = np.stack([synth.gen_clip(640 + i, 12.0) for i in range(3)])
+    clips = np.stack([synth.gen_clip(640 + i, 12.0) for i in range(5)])   # (fewer than four clips are never forked)
     plan = oracle.Plan(clips.shape[1])
-    want = plan.extract_batch(filters, clips, n_threads=3)
+    want = plan.extract_batch(filters, clips, n_threads=5)
     d = torch.from_numpy(clips).cuda()
     for serial in (False, True):
         if serial:
@@ -316,11 +316,11 @@ def test_constant_q_classes_side_by_side_or_in_turn(torch_cuda, oracle, filters,
         g.set_filters(filters)
         side, other = torch.cuda.Stream(), torch.cuda.Stream()
         for stream in (0, side.cuda_stream):
-            hp = torch.zeros((3, plan.n_hp), dtype=torch.int64, device="cuda")
+            hp = torch.zeros((5, plan.n_hp), dtype=torch.int64, device="cuda")
             hp2 = torch.zeros_like(hp)
             torch.cuda.synchronize()
-            g.extract_dev(d.data_ptr(), clips.shape[1], 3, hp.data_ptr(), stream)
-            g.extract_dev(d.data_ptr(), clips.shape[1], 3, hp2.data_ptr(), other.cuda_stream)   # shares the workspaces: ordered by the handle
+            g.extract_dev(d.data_ptr(), clips.shape[1], 5, hp.data_ptr(), stream)
+            g.extract_dev(d.data_ptr(), clips.shape[1], 5, hp2.data_ptr(), other.cuda_stream)   # shares the workspaces: ordered by the handle
             torch.cuda.synchronize()
             assert np.array_equal(hp.cpu().numpy().view(np.uint64), want), (serial, stream)
             assert np.array_equal(hp2.cpu().numpy().view(np.uint64), want), (serial, stream)
