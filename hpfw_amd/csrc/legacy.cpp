@@ -585,7 +585,8 @@ float *group_spectrograms(hpfw_legacy_collector *c, size_t first_off, size_t n, 
         *cap = need;
     }
     const int16_t *d_pcm = reinterpret_cast<const int16_t *>(static_cast<const char *>(c->d_arena) + first_off);
-    if (hpfw_gpu_stage_spectrogram(c->gpu, d_pcm, len, (int64_t)n, d_db, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
+    // (no synchronisation: what follows runs on the default stream too, and the copies to the host wait for it)
+    if (hpfw_gpu_stage_spectrogram(c->gpu, d_pcm, len, (int64_t)n, d_db, nullptr) != 0) {
         (void)hipFree(d_db);
         return nullptr;
     }
@@ -605,22 +606,36 @@ void release_spectrograms(hpfw_legacy_collector *c, float *d_db, size_t cap)
 }
 
 // hashprints of n clips from their dB spectrograms: out[k] = new uint64_t[g.n_hp]
-bool group_hashprints(hpfw_gpu *gpu, const float *d_db, size_t n, const hpfw_geometry &g, uint64_t **out)
+// the collector's hashprint buffers (device, and pinned on the host) hold at least `bytes`
+bool ensure_hp_buffers(hpfw_legacy_collector *c, size_t bytes)
 {
-    DevMem hp;
-    if (!hp.alloc(n * (size_t)g.n_hp * 8)) {
-        hpfw_internal_set_error("prepare: out of device memory");
+    if (bytes <= c->hp_win_cap) return true;
+    if (c->d_hp_win) (void)hipFree(c->d_hp_win);
+    if (c->h_hp_win) (void)hipHostFree(c->h_hp_win);
+    c->d_hp_win = c->h_hp_win = nullptr;
+    c->hp_win_cap = 0;
+    const size_t want = std::max(bytes + bytes / 4, (size_t)8 << 20);
+    if (hipMalloc(&c->d_hp_win, want) != hipSuccess || hipHostMalloc(&c->h_hp_win, want, hipHostMallocDefault) != hipSuccess) {
+        hpfw_internal_set_error("prepare: out of memory for the hashprints");
         return false;
     }
-    if (hpfw_gpu_hashprints_from_db(gpu, d_db, (int64_t)n, g.c, (uint64_t *)hp.p, nullptr) != 0) return false;
-    std::vector<uint64_t> host(n * (size_t)g.n_hp);
-    if (hipMemcpy(host.data(), hp.p, host.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+    c->hp_win_cap = want;
+    return true;
+}
+
+// hashprints of n clips from their dB spectrograms: out[k] = new uint64_t[g.n_hp]
+bool group_hashprints(hpfw_legacy_collector *c, const float *d_db, size_t n, const hpfw_geometry &g, uint64_t **out)
+{
+    const size_t bytes = n * (size_t)g.n_hp * 8;
+    if (!ensure_hp_buffers(c, bytes)) return false;
+    if (hpfw_gpu_hashprints_from_db(c->gpu, d_db, (int64_t)n, g.c, (uint64_t *)c->d_hp_win, nullptr) != 0) return false;
+    if (hipMemcpy(c->h_hp_win, c->d_hp_win, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
         hpfw_internal_set_error("prepare: D2H copy failed");
         return false;
     }
     for (size_t k = 0; k < n; ++k) {
         out[k] = new uint64_t[(size_t)g.n_hp];
-        std::memcpy(out[k], host.data() + k * (size_t)g.n_hp, (size_t)g.n_hp * 8);
+        std::memcpy(out[k], static_cast<const uint64_t *>(c->h_hp_win) + k * (size_t)g.n_hp, (size_t)g.n_hp * 8);
     }
     return true;
 }
@@ -784,16 +799,7 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                 }
             const size_t total = pend.total;
             bool ok = true;
-            if (total * 8 > c->hp_win_cap) {
-                if (c->d_hp_win) (void)hipFree(c->d_hp_win);
-                if (c->h_hp_win) (void)hipHostFree(c->h_hp_win);
-                c->d_hp_win = c->h_hp_win = nullptr;
-                c->hp_win_cap = 0;
-                const size_t want = std::max(total * 8 + total * 2, (size_t)8 << 20);
-                ok = hipMalloc(&c->d_hp_win, want) == hipSuccess && hipHostMalloc(&c->h_hp_win, want, hipHostMallocDefault) == hipSuccess;
-                if (ok) c->hp_win_cap = want;
-                else hpfw_internal_set_error("prepare: out of memory for the window's hashprints");
-            }
+            if (!ensure_hp_buffers(c, total * 8)) ok = false;
             if (ok && !c->win_stream && hipStreamCreateWithFlags(&c->win_stream, hipStreamNonBlocking) != hipSuccess) {
                 c->win_stream = nullptr;
                 hpfw_internal_set_error("prepare: no stream");
@@ -816,6 +822,31 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
             pend.ok = ok;
             pend.active = true; // fetched by finish(): after the next window's upload, or after the last window
         }
+        // the window's spectrograms on their way to cache/spectros/: one pinned buffer for all of them, written to the cache
+        // by the team of host threads when the window's groups are through (a window of files of different lengths is as
+        // many groups of one file: written group by group, one thread would do all the writing)
+        struct SpecWrite {
+            std::string path;
+            size_t off; // floats into the pinned buffer
+            int32_t c;
+        };
+        std::vector<SpecWrite> spec_writes;
+        size_t spec_used = 0;
+        if (!direct && first && job.cache_spectros) {
+            size_t total = 0;
+            for (auto &kv : by_len)
+                for (const std::vector<int> &pos : kv.second) {
+                    hpfw_geometry g;
+                    if (hpfw_gpu_geometry(c->gpu, kv.first, &g) == 0 && g.n_frames >= 2) total += pos.size() * (size_t)121 * g.c * 4;
+                }
+            if (total > c->h_spec_cap) { // (pinned: the copies run at the link's rate, not through the driver's staging)
+                if (c->h_spec) (void)hipHostFree(c->h_spec);
+                c->h_spec = nullptr;
+                c->h_spec_cap = 0;
+                if (hipHostMalloc(&c->h_spec, total + total / 8, hipHostMallocDefault) == hipSuccess) c->h_spec_cap = total + total / 8;
+                else c->h_spec = nullptr;
+            }
+        }
         for (auto &kv : by_len)
           for (const std::vector<int> &pos : kv.second) {
             if (direct) break;
@@ -831,19 +862,13 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
             if (first && job.cache_spectros) {
                 // cache.set_spectro(filename, spectro) (parallel_collector.h:98-100): "it will also be needed
                 // when adding new tracks" -- a later prepare() recomputes every cached track's hashprints
-                if (sz > c->h_spec_cap) { // (pinned: the copy runs at the link's rate, not through the driver's staging)
-                    if (c->h_spec) (void)hipHostFree(c->h_spec);
-                    c->h_spec = nullptr;
-                    c->h_spec_cap = 0;
-                    if (hipHostMalloc(&c->h_spec, sz + sz / 4, hipHostMallocDefault) == hipSuccess) c->h_spec_cap = sz + sz / 4;
-                    else c->h_spec = nullptr;
+                if (c->h_spec && spec_used + sz <= c->h_spec_cap &&
+                    hipMemcpy(static_cast<char *>(c->h_spec) + spec_used, d_db, sz, hipMemcpyDeviceToHost) == hipSuccess) {
+                    for (size_t k = 0; k < ids.size(); ++k)
+                        spec_writes.push_back(SpecWrite{spectro_dir + std::filesystem::path(filenames[ids[k]]).stem().string(),
+                                                        spec_used / 4 + k * (size_t)121 * g.c, (int32_t)g.c});
+                    spec_used += sz;
                 }
-                const float *host = static_cast<const float *>(c->h_spec);
-                if (host && hipMemcpy(c->h_spec, d_db, sz, hipMemcpyDeviceToHost) == hipSuccess)
-                    host_team((int)ids.size(), [&](int k) {
-                        const std::string stem = std::filesystem::path(filenames[ids[(size_t)k]]).stem().string();
-                        (void)save_spectro_cereal(spectro_dir + stem, host + (size_t)k * 121 * g.c, (int32_t)g.c);
-                    });
             }
             if (first && job.learn) {
                 if (hpfw_gpu_cov_accumulate_db(c->gpu, d_db, (int64_t)pos.size(), g.c, nullptr) == 0) job.used += (int64_t)pos.size();
@@ -855,14 +880,19 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
                 if (g.n_hp > 0) job.again.insert(job.again.end(), ids.begin(), ids.end());
             } else if (g.n_hp > 0) {
                 std::vector<uint64_t *> out(pos.size(), nullptr);
-                if (group_hashprints(c->gpu, d_db, pos.size(), g, out.data()))
+                if (group_hashprints(c, d_db, pos.size(), g, out.data()))
                     for (size_t k = 0; k < ids.size(); ++k) {
                         job.hp[(size_t)ids[k]] = out[k];
                         job.hp_size[(size_t)ids[k]] = (int)g.n_hp;
                     }
             }
-            (void)hipDeviceSynchronize();
-            release_spectrograms(c, d_db, db_cap);
+            release_spectrograms(c, d_db, db_cap); // (its next user is ordered after this group on the default stream; hipFree waits)
+        }
+        if (!spec_writes.empty()) {
+            const float *host = static_cast<const float *>(c->h_spec);
+            host_team((int)spec_writes.size(), [&](int k) {
+                (void)save_spectro_cereal(spec_writes[(size_t)k].path, host + spec_writes[(size_t)k].off, spec_writes[(size_t)k].c);
+            });
         }
         if (timing) {
             const auto t_3 = std::chrono::steady_clock::now();
@@ -894,7 +924,7 @@ static void prepare_finish(hpfw_legacy_collector *c, const char **filenames, hpf
     (void)hipSetDevice(hpfw_gpu_device(c->gpu));
     for (KeptGroup &k : job.kept) {
         std::vector<uint64_t *> out(k.files.size(), nullptr);
-        if (ok && group_hashprints(c->gpu, k.d_db, k.files.size(), k.g, out.data()))
+        if (ok && group_hashprints(c, k.d_db, k.files.size(), k.g, out.data()))
             for (size_t q = 0; q < k.files.size(); ++q) {
                 job.hp[(size_t)k.files[q]] = out[q];
                 job.hp_size[(size_t)k.files[q]] = (int)k.g.n_hp;
@@ -983,7 +1013,7 @@ static void collect_cached(hpfw_legacy_collector *c, const std::vector<std::stri
             DevMem d_db;
             std::vector<uint64_t *> out(pos.size(), nullptr);
             if (!d_db.alloc(bm.size() * 4) || hipMemcpy(d_db.p, bm.data(), bm.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-                !group_hashprints(c->gpu, (const float *)d_db.p, pos.size(), g, out.data()))
+                !group_hashprints(c, (const float *)d_db.p, pos.size(), g, out.data()))
                 continue;
             for (size_t k = 0; k < pos.size(); ++k) {
                 win_hp[(size_t)pos[k]] = out[k];
