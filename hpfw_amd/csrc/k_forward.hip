@@ -297,6 +297,235 @@ __global__ __launch_bounds__(kCqThreads, 2) void fwd_cols_q_kernel(ColsQArgs a, 
 #endif
 }
 
+// ---- column stage, three workgroups per CU ---------------------------------------------------------------------
+// The same contraction with the sample digits held in REGISTERS: a wave's 32 columns x 224 samples k1 are 56 registers
+// per lane (7 steps x 2 planes x 16 bytes), read once per workgroup through a 2 KB scratch of the wave's own (the
+// transposition with byte permutes as above, 32 rows at a time; no workgroup barrier: a wave's LDS traffic is in
+// order).  What is left in LDS are the twiddle digits of a row tile, fetched by global_load_lds (no registers) into
+// one of two buffers while the results of the previous tile are converted and stored: 43 KB + 8 KB per workgroup
+// and at most 168 registers, so three workgroups = twelve waves share a CU, one barrier per tile.
+constexpr int kCq3ScratchBytes = 2 * 2 * 32 * 16;                         // per wave: [plane][unit][slot][16 bytes]
+constexpr int kCq3LdsBytes = 2 * kCqABytes + 4 * kCq3ScratchBytes;       // 51 200
+
+__device__ __forceinline__ int cq3_w_addr(int c, int rq) { return (rq >> 2) * 512 + cq_slot(c) * 16 + 4 * (rq & 3); }
+
+__device__ __forceinline__ void cq3_store_pair(unsigned char *sc, int c, int rq, unsigned r0, unsigned r1, unsigned r2, unsigned r3)
+{
+    const unsigned x01 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), x23 = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+    const unsigned y01 = __builtin_amdgcn_perm(r1, r0, 0x07030602u), y23 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+    const int a0 = cq3_w_addr(c, rq), a1 = cq3_w_addr(c + 1, rq);
+    *reinterpret_cast<unsigned *>(sc + a0) = __builtin_amdgcn_perm(x23, x01, 0x05040100u);        // lo plane
+    *reinterpret_cast<unsigned *>(sc + 1024 + a0) = __builtin_amdgcn_perm(x23, x01, 0x07060302u); // hi plane
+    *reinterpret_cast<unsigned *>(sc + a1) = __builtin_amdgcn_perm(y23, y01, 0x05040100u);
+    *reinterpret_cast<unsigned *>(sc + 1024 + a1) = __builtin_amdgcn_perm(y23, y01, 0x07060302u);
+}
+
+// the samples of the wave's 32 columns (from column cw0; n1 <= 224) into x[step][plane]: a lane loads 4 columns x 4 consecutive k1 per
+// step (the 64 lanes of a load instruction: 8 rows x 64 contiguous bytes), every load issued before the first is used
+template <int LOADW>
+__device__ __forceinline__ void cq3_load_samples(const ColsQArgs &a, const int16_t *__restrict__ clip_pcm, int cw0,
+                                                 unsigned char *sc, int lane, v4i (&x)[kCqKSteps][2])
+{
+    const int cg = lane & 7, quad = lane >> 3;
+    const int row_last = a.n1 - 1, last = a.n2 - 1;
+    const int gc = cw0 + 4 * cg;
+    // byte offsets inside the clip in 32 bits (a clip is below 2^31 samples): one register per address, the clip's base
+    // in scalar registers
+    const char *base = reinterpret_cast<const char *>(clip_pcm);
+    const unsigned pitch = 2u * (unsigned)a.n2;
+    unsigned cb[4];
+    if (LOADW == 4) {
+        cb[0] = 2u * (unsigned)(gc + 3 <= last ? gc : last - 3);
+    } else if (LOADW == 2) {
+        cb[0] = 2u * (unsigned)(gc + 1 <= last ? gc : last - 1);
+        cb[1] = 2u * (unsigned)(gc + 3 <= last ? gc + 2 : last - 1);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cb[e] = 2u * (unsigned)(gc + e <= last ? gc + e : last);
+    }
+    // LOADW = 4: every load of the chunk is issued before the first value is used (one memory latency instead of seven);
+    // the narrower loads of odd shapes go step by step, or their addresses and values would not fit the registers
+    constexpr int kBatch = LOADW == 4 ? kCqKSteps : 1;
+    const int h = lane >> 5, nl = lane & 31;
+    const int rd = h * 512 + cq_slot(nl) * 16;
+#pragma unroll
+    for (int s0 = 0; s0 < kCqKSteps; s0 += kBatch) {
+    unsigned r[kBatch][4][2];
+#pragma unroll
+    for (int sb = 0; sb < kBatch; ++sb) {
+        const int s = s0 + sb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = 32 * s + 4 * quad + i;
+            if (row > row_last) row = row_last;      // samples past n1 meet zero twiddle digits: any valid address
+            const unsigned ro = (unsigned)row * pitch;
+            if (LOADW == 4) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(base + (ro + cb[0]));
+                r[sb][i][0] = v.x;
+                r[sb][i][1] = v.y;
+            } else if (LOADW == 2) {
+                r[sb][i][0] = *reinterpret_cast<const unsigned *>(base + (ro + cb[0]));
+                r[sb][i][1] = *reinterpret_cast<const unsigned *>(base + (ro + cb[1]));
+            } else {
+                r[sb][i][0] = (unsigned)*reinterpret_cast<const unsigned short *>(base + (ro + cb[0])) |
+                              ((unsigned)*reinterpret_cast<const unsigned short *>(base + (ro + cb[1])) << 16);
+                r[sb][i][1] = (unsigned)*reinterpret_cast<const unsigned short *>(base + (ro + cb[2])) |
+                              ((unsigned)*reinterpret_cast<const unsigned short *>(base + (ro + cb[3])) << 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int sb = 0; sb < kBatch; ++sb) {
+        const int s = s0 + sb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[sb][i][0] ^= 0x00800080u;              // lo = (x & 255) - 128: the low bytes' top bits flipped
+            r[sb][i][1] ^= 0x00800080u;
+        }
+        cq3_store_pair(sc, 4 * cg, quad, r[sb][0][0], r[sb][1][0], r[sb][2][0], r[sb][3][0]);
+        cq3_store_pair(sc, 4 * cg + 2, quad, r[sb][0][1], r[sb][1][1], r[sb][2][1], r[sb][3][1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own writes, in order before its reads
+        x[s][0] = *reinterpret_cast<const v4i *>(sc + rd);
+        x[s][1] = *reinterpret_cast<const v4i *>(sc + 1024 + rd);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read before the next step's writes land
+    }
+    }
+}
+
+template <int LOADW>
+__global__ __launch_bounds__(kCqThreads, 3) void fwd_cols_q3_kernel(ColsQArgs a, const int16_t *__restrict__ pcm, int64_t clip_samples,
+                                                                    float *__restrict__ z)
+{
+    unsigned char *abytes = smem_raw;                                       // [2 buffers][7 steps][3 digits][64 lanes][16 bytes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char *sc = smem_raw + 2 * kCqABytes + wave * kCq3ScratchBytes;
+    const int h = lane >> 5, nl = lane & 31;
+    // Workgroups go to the eight XCDs in turn (id mod 8), each with an L2 of its own: an XCD takes a contiguous run of
+    // (clip, column block) pairs with the column block fastest, so that the 128-byte lines of a PCM row that two
+    // neighbouring column blocks share (a row is 12 600 bytes: no block starts on a line) are fetched from HBM once.
+    const int ncb = (a.n2 + kCqCols - 1) / kCqCols;
+    const unsigned per_xcd = (gridDim.x + 7) / 8;
+    const unsigned t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= (unsigned)(a.n_clips * ncb)) return;
+    const int cb = t % ncb, clip = t / ncb;
+    const int col0 = cb * kCqCols;
+    const int16_t *clip_pcm = pcm + (int64_t)clip * clip_samples;
+    const v4i *image = static_cast<const v4i *>(a.image);
+    const int steps = a.ks, pieces = 3 * steps;      // <= 7 steps: every sample of the columns is in registers
+    // the twiddle digits of row tile mt into buffer `buf`: 21 pieces of 1 KB, every wave its share
+    auto issue_a = [&](int mt, int buf) {
+        const v4i *src = image + (int64_t)mt * a.ks * 3 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < (kCqKSteps * 3 + 3) / 4; ++e) {
+            const int p = wave + 4 * e;
+            if (p < pieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
+                                                 (__attribute__((address_space(3))) void *)(abytes + buf * kCqABytes + p * 1024),
+                                                 16, 0, 0);
+        }
+    };
+#ifdef HPFW_COLS_STAMPS
+    long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int k) {
+        const long long t = __builtin_amdgcn_s_memtime();
+        st[k] += t - tprev;
+        tprev = t;
+    };
+#endif
+    issue_a(0, 0);
+    v4i x[kCqKSteps][2];
+    cq3_load_samples<LOADW>(a, clip_pcm, col0 + wave * 32, sc, lane, x);
+    CQ_STAMP(0);
+    const int cbase = col0 + wave * 32 + 4 * h;      // D: registers 4 g .. 4 g + 3 are columns cbase + 8 g + (0..3), tile column = lane & 31
+    const bool vec4 = (a.n2 & 3) == 0;
+    // all of the wave's columns inside the row and 16-byte stores: then a tile ends with exactly four store
+    // instructions, and the wait at the top of the next one can leave them in flight
+    const bool four_stores = vec4 && col0 + wave * 32 + 32 <= a.n2;
+    auto corr_of = [&](int mt) {
+        const int row = 32 * mt + nl, q1 = row >> 1;
+        return a.corr[2 * (q1 < a.hq ? q1 : a.hq - 1) + (row & 1)];
+    };
+    double corr = corr_of(0);
+    for (int mt = 0; mt < a.mt; ++mt) {
+        const int row = 32 * mt + nl, q1 = row >> 1;
+        const bool live = q1 < a.hq;
+        // this wave's pieces of the tile's digits have landed (they are older than the previous tile's stores, and
+        // memory operations retire in order); after the barrier everybody's have, and everybody is done with the
+        // other buffer
+        if (four_stores)
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        CQ_STAMP(1);
+        double corr_next = 0.0;
+        if (mt + 1 < a.mt) corr_next = corr_of(mt + 1);   // here long before the next tile asks for it
+        const v4i *wb = reinterpret_cast<const v4i *>(abytes + (mt & 1) * kCqABytes) + lane;
+        v16i acc[4];
+        const v16i zero = v16i{0};
+        auto step = [&](int s) {
+            // sample digit i (0 lo, 1 hi) times twiddle digit j goes to accumulator i + j; the first products of a tile
+            // start from the instruction's zero operand instead of a cleared register
+            const v4i w0 = wb[(s * 3 + 0) * 64], w1 = wb[(s * 3 + 1) * 64], w2 = wb[(s * 3 + 2) * 64];
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][0], w0, s == 0 ? zero : acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][0], w1, s == 0 ? zero : acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][0], w2, s == 0 ? zero : acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][1], w2, s == 0 ? zero : acc[3], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][1], w0, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][1], w1, acc[2], 0, 0, 0);
+        };
+        if (steps == kCqKSteps) {                // the usual case, straight through: the operand reads run ahead of the products
+#pragma unroll
+            for (int s = 0; s < kCqKSteps; ++s) step(s);
+        } else {
+#pragma unroll
+            for (int s = 0; s < kCqKSteps; ++s)
+                if (s < steps) step(s);
+        }
+        CQ_STAMP(2);
+        // the next tile's digits, on their way under the conversion and the stores below (corr_next is here by now: no
+        // wait for an ordinary load may follow while they are in flight, the compiler would make it a wait for everything)
+        asm volatile("" : "+v"(corr_next) : : "memory");
+        CQ_STAMP(3);
+        if (mt + 1 < a.mt) issue_a(mt + 1, (mt + 1) & 1);
+        asm volatile("" ::: "memory");           // the stores below stay below: they are the youngest at the next wait
+        CQ_STAMP(4);
+        // D[tile row = column][tile column = output row]: this lane holds output row `row`, register r = column
+        // cbase + 8 (r >> 2) + (r & 3).  G = sum_c acc_c 2^(8c) + corr: n1 <= 224, so the digit-product sums pair up
+        // in int32 (|.| < 2^31) and the rest is exact in double; rounded once.
+        float gm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lo = acc[0][r] + (acc[1][r] << 8), hi = acc[2][r] + (acc[3][r] << 8);
+            gm[r] = (float)(__builtin_fma((double)hi, 65536.0, (double)lo) + corr);
+        }
+        CQ_STAMP(5);
+        if (live) {
+            float *zrow = z + (((int64_t)clip * a.hq + q1) * 2 + (row & 1)) * a.n2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cbase + 8 * g;
+                if (vec4 && c + 3 < a.n2) {
+                    *reinterpret_cast<float4 *>(zrow + c) = float4{gm[4 * g], gm[4 * g + 1], gm[4 * g + 2], gm[4 * g + 3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < a.n2) zrow[c + e] = gm[4 * g + e];
+                }
+            }
+        }
+        CQ_STAMP(6);
+        corr = corr_next;
+    }
+#ifdef HPFW_COLS_STAMPS
+    if (a.stamps && tid == 0) {
+        long long *o = a.stamps + (int64_t)blockIdx.x * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = st[k];
+    }
+#endif
+}
+
 #ifdef HPFW_COLS_STAMPS
 long long *g_cols_stamps = nullptr;
 extern "C" long long *hpfw_debug_cols_stamps() { return g_cols_stamps; }
@@ -326,13 +555,19 @@ __global__ __launch_bounds__(256) void gather_bins_kernel(CqPlanDev cp, const cf
 }
 
 template <int LOADW>
-static void launch_cols_q_t(const ColsQArgs &a, const int16_t *d_pcm, int64_t clip_samples, dim3 grid, float *d_z, hipStream_t s)
+static void launch_cols_q_t(ColsQArgs a, const int16_t *d_pcm, int64_t clip_samples, dim3 grid, float *d_z, hipStream_t s)
 {
     static PerDeviceOnce attr_set;
     if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_cols_q_kernel<LOADW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kCqLdsBytes);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_cols_q_kernel<LOADW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kCqLdsBytes);
         attr_set.mark();
+    }
+    if (a.ks <= kCqKSteps) {                      // n1 <= 224: the register-resident kernel, a one-dimensional grid
+        a.n_clips = grid.x;
+        hipLaunchKernelGGL((fwd_cols_q3_kernel<LOADW>), dim3(8 * ((grid.x * grid.y + 7) / 8)), dim3(kCqThreads), kCq3LdsBytes, s, a, d_pcm,
+                           clip_samples, d_z);
+        return;
     }
     if (a.n1 <= 255)
         hipLaunchKernelGGL((fwd_cols_q_kernel<LOADW, true>), grid, dim3(kCqThreads), kCqLdsBytes, s, a, d_pcm, clip_samples, d_z);

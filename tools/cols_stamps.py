@@ -20,7 +20,7 @@ import ctypes.util
 hip = ctypes.CDLL("libamdhip64.so")
 hip.hipMemcpy(buf, ctypes.c_void_p(ptr), nwg * 64, 2)
 a = np.frombuffer(buf, dtype=np.int64).reshape(nwg, 8)
-names = ["staging+A0 issue", "tile prologue (table loads issue)", "barrier 1", "store A", "barrier 2", "A prefetch + K loop", "conversion+dpp", "cmul+stores"]
+names = ["digits issue + samples into registers", "wait + barrier", "matrix loop", "wait for corr", "next digits issue", "conversion", "stores issue", "-"]
 tot = a.sum(axis=1)
 print("per WG cycles (wave 0, 100 MHz*? memtime ticks): median total", np.median(tot))
 for k, nm in enumerate(names):
