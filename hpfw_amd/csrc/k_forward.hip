@@ -26,6 +26,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 // ---- column stage ---------------------------------------------------------------------------------------------
+// Two kernels: n1 <= 224 (clips up to 32 s at n2 = 6300: all k1 of a column fit the registers of a lane) runs
+// fwd_cols_q3_kernel further down; longer clips run the kernel of this section, which stages the samples in LDS chunk
+// by chunk of 224 k1.  Digits, accumulators, image layout and epilogue are common.
+//
 // One workgroup = 4 waves = 128 columns k2 of one clip x up to 7 row tiles (224 rows (Re, Im interleaved) = 112 q1);
 // a wave owns 32 columns.  K = k1 in chunks of 224 samples (7 matrix-instruction steps): the samples of the chunk sit
 // in LDS as two byte planes [16 k1][column][16 bytes] -- the transposition the matrix instruction's operand layout asks for (a lane
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(kCqThreads, 2) void fwd_cols_q_kernel(ColsQArgs a, 
 #endif
 }
 
-// ---- column stage, three workgroups per CU ---------------------------------------------------------------------
+// ---- column stage, n1 <= 224: three workgroups per CU ----------------------------------------------------------
 // The same contraction with the sample digits held in REGISTERS: a wave's 32 columns x 224 samples k1 are 56 registers
 // per lane (7 steps x 2 planes x 16 bytes), read once per workgroup through a 2 KB scratch of the wave's own (the
 // transposition with byte permutes as above, 32 rows at a time; no workgroup barrier: a wave's LDS traffic is in
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(kCqThreads, 2) void fwd_cols_q_kernel(ColsQArgs a, 
 // one of two buffers while the results of the previous tile are converted and stored: 43 KB + 8 KB per workgroup
 // and at most 168 registers, so three workgroups = twelve waves share a CU, one barrier per tile.
 constexpr int kCq3ScratchBytes = 2 * 2 * 32 * 16;                         // per wave: [plane][unit][slot][16 bytes]
-constexpr int kCq3LdsBytes = 2 * kCqABytes + 4 * kCq3ScratchBytes;       // 51 200
+constexpr int cq3_lds_bytes(int waves) { return 2 * kCqABytes + waves * kCq3ScratchBytes; }
 
 __device__ __forceinline__ int cq3_w_addr(int c, int rq) { return (rq >> 2) * 512 + cq_slot(c) * 16 + 4 * (rq & 3); }
 
@@ -322,9 +326,9 @@ __device__ __forceinline__ void cq3_store_pair(unsigned char *sc, int c, int rq,
 
 // the samples of the wave's 32 columns (from column cw0; n1 <= 224) into x[step][plane]: a lane loads 4 columns x 4 consecutive k1 per
 // step (the 64 lanes of a load instruction: 8 rows x 64 contiguous bytes), every load issued before the first is used
-template <int LOADW>
+template <int LOADW, class F>
 __device__ __forceinline__ void cq3_load_samples(const ColsQArgs &a, const int16_t *__restrict__ clip_pcm, int cw0,
-                                                 unsigned char *sc, int lane, v4i (&x)[kCqKSteps][2])
+                                                 unsigned char *sc, int lane, v4i (&x)[kCqKSteps][2], F issued)
 {
     const int cg = lane & 7, quad = lane >> 3;
     const int row_last = a.n1 - 1, last = a.n2 - 1;
@@ -374,6 +378,7 @@ __device__ __forceinline__ void cq3_load_samples(const ColsQArgs &a, const int16
             }
         }
     }
+    if (s0 == 0) issued();                         // what the caller wants in flight behind the first loads
 #pragma unroll
     for (int sb = 0; sb < kBatch; ++sb) {
         const int s = s0 + sb;
@@ -392,10 +397,11 @@ __device__ __forceinline__ void cq3_load_samples(const ColsQArgs &a, const int16
     }
 }
 
-template <int LOADW>
-__global__ __launch_bounds__(kCqThreads, 3) void fwd_cols_q3_kernel(ColsQArgs a, const int16_t *__restrict__ pcm, int64_t clip_samples,
+template <int LOADW, int kCq3Waves>                  // a wave = 32 columns
+__global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArgs a, const int16_t *__restrict__ pcm, int64_t clip_samples,
                                                                     float *__restrict__ z)
 {
+    constexpr int kCq3Cols = 32 * kCq3Waves;
     unsigned char *abytes = smem_raw;                                       // [2 buffers][7 steps][3 digits][64 lanes][16 bytes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char *sc = smem_raw + 2 * kCqABytes + wave * kCq3ScratchBytes;
@@ -403,12 +409,12 @@ __global__ __launch_bounds__(kCqThreads, 3) void fwd_cols_q3_kernel(ColsQArgs a,
     // Workgroups go to the eight XCDs in turn (id mod 8), each with an L2 of its own: an XCD takes a contiguous run of
     // (clip, column block) pairs with the column block fastest, so that the 128-byte lines of a PCM row that two
     // neighbouring column blocks share (a row is 12 600 bytes: no block starts on a line) are fetched from HBM once.
-    const int ncb = (a.n2 + kCqCols - 1) / kCqCols;
+    const int ncb = (a.n2 + kCq3Cols - 1) / kCq3Cols;
     const unsigned per_xcd = (gridDim.x + 7) / 8;
     const unsigned t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= (unsigned)(a.n_clips * ncb)) return;
     const int cb = t % ncb, clip = t / ncb;
-    const int col0 = cb * kCqCols;
+    const int col0 = cb * kCq3Cols;
     const int16_t *clip_pcm = pcm + (int64_t)clip * clip_samples;
     const v4i *image = static_cast<const v4i *>(a.image);
     const int steps = a.ks, pieces = 3 * steps;      // <= 7 steps: every sample of the columns is in registers
@@ -416,8 +422,8 @@ __global__ __launch_bounds__(kCqThreads, 3) void fwd_cols_q3_kernel(ColsQArgs a,
     auto issue_a = [&](int mt, int buf) {
         const v4i *src = image + (int64_t)mt * a.ks * 3 * 64 + lane;
 #pragma unroll
-        for (int e = 0; e < (kCqKSteps * 3 + 3) / 4; ++e) {
-            const int p = wave + 4 * e;
+        for (int e = 0; e < (kCqKSteps * 3 + kCq3Waves - 1) / kCq3Waves; ++e) {
+            const int p = wave + kCq3Waves * e;
             if (p < pieces)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
                                                  (__attribute__((address_space(3))) void *)(abytes + buf * kCqABytes + p * 1024),
@@ -433,9 +439,9 @@ __global__ __launch_bounds__(kCqThreads, 3) void fwd_cols_q3_kernel(ColsQArgs a,
         tprev = t;
     };
 #endif
-    issue_a(0, 0);
     v4i x[kCqKSteps][2];
-    cq3_load_samples<LOADW>(a, clip_pcm, col0 + wave * 32, sc, lane, x);
+    // the samples first (they come from HBM), the first tile's digits (from L2) behind them
+    cq3_load_samples<LOADW>(a, clip_pcm, col0 + wave * 32, sc, lane, x, [&] { issue_a(0, 0); });
     CQ_STAMP(0);
     const int cbase = col0 + wave * 32 + 4 * h;      // D: registers 4 g .. 4 g + 3 are columns cbase + 8 g + (0..3), tile column = lane & 31
     const bool vec4 = (a.n2 & 3) == 0;
@@ -565,8 +571,12 @@ static void launch_cols_q_t(ColsQArgs a, const int16_t *d_pcm, int64_t clip_samp
     }
     if (a.ks <= kCqKSteps) {                      // n1 <= 224: the register-resident kernel, a one-dimensional grid
         a.n_clips = grid.x;
-        hipLaunchKernelGGL((fwd_cols_q3_kernel<LOADW>), dim3(8 * ((grid.x * grid.y + 7) / 8)), dim3(kCqThreads), kCq3LdsBytes, s, a, d_pcm,
-                           clip_samples, d_z);
+        // (workgroups of six waves = 192 columns, two per CU: a third less of the digit traffic per column, the kernel
+        // itself 2.63 -> 2.9 ms, the step within 0.6 %: DESIGN.md section 9)
+        constexpr int kWaves = 4;
+        const int ncb = (a.n2 + 32 * kWaves - 1) / (32 * kWaves);
+        hipLaunchKernelGGL((fwd_cols_q3_kernel<LOADW, kWaves>), dim3(8 * ((grid.x * ncb + 7) / 8)), dim3(64 * kWaves), cq3_lds_bytes(kWaves), s,
+                           a, d_pcm, clip_samples, d_z);
         return;
     }
     if (a.n1 <= 255)
