@@ -256,10 +256,13 @@ def main():
 
     cols_bytes = geo.n1 * geo.n2 * 2 + hq * geo.n2 * 8
     rows_bytes = hq * geo.n2 * 8 + hq * ((geo.n2 + 3) // 4) * 8 + geo.n1 * q2w * 8
-    roof_cols = hbm_roof("fwd_cols", "fwd_cols_q_kernel (column DFT of the sample matrix as six int8 digit products on "
-                         "v_mfma_i32_32x32x32_i8, exact; one rounding)", cols_bytes, "fwd_cols_hbm_bytes_per_clip",
+    roof_cols = hbm_roof("fwd_cols", "fwd_cols_q3_kernel (column DFT of the sample matrix as six int8 digit products on "
+                         "v_mfma_i32_32x32x32_i8, exact; one rounding; sample digits in registers, twiddle digits by "
+                         "global_load_lds)", cols_bytes, "fwd_cols_hbm_bytes_per_clip",
                          f"also {6 * 2 * 2 * hq * geo.n1 * geo.n2 / 1e9:.2f} G int8 operations per clip on the matrix pipe "
-                         "(a quarter of its time at the probe's rate); the twiddle digits (147 KB per 128 columns) come from L2")
+                         "(38 % of its cycles busy: profiles/r03_sq.json); the twiddle digits (147 KB per 128 columns) come "
+                         "from L2; the kernels of a step share one power budget -- a slower, cooler variant of this kernel "
+                         "(2.9 ms) left the step time unchanged within 0.6 % (DESIGN.md section 9)")
     roof_rows = hbm_roof("fwd_rows", "fwd_rows2_kernel (per row: inter-stage twiddles, FFT_n2 in LDS, pruned stores)", rows_bytes,
                          "fwd_rows_hbm_bytes_per_clip",
                          "not HBM-bound: three fused LDS passes per row with a barrier each, 61 % of wave-cycles parked "

@@ -77,7 +77,7 @@ def main():
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / clips, launches of the largest grid"}
         for key, prefixes in (("project_mfma_hbm_bytes_per_clip", ("project_kernel<true", "project_kernel")),
                               ("project_q_hbm_bytes_per_clip", ("hashprint_q_kernel<true", "hashprint_q_kernel", "project_q_kernel")),
-                              ("fwd_cols_hbm_bytes_per_clip", ("fwd_cols_q_kernel",)),
+                              ("fwd_cols_hbm_bytes_per_clip", ("fwd_cols_q3_kernel", "fwd_cols_q_kernel")),
                               ("fwd_rows_hbm_bytes_per_clip", ("fwd_rows2_kernel", "fwd_rows_kernel"))):
             pk = next((v for k, v in sorted(pmc.items()) if any(k.startswith(px) for px in prefixes)), {})
             if "hbm_bytes_per_launch" in pk:
