@@ -168,6 +168,7 @@ def main():
     torch.cuda.synchronize()
     # the two largest kernels (the row transforms and the projection): one HIP event pair per launch, on the launch stream
     gpu.set_kernel_timing((1 << hpfw_amd.KERNEL_KINDS.index("project_mfma")) | (1 << hpfw_amd.KERNEL_KINDS.index("fwd_rows")) |
+                          (1 << hpfw_amd.KERNEL_KINDS.index("fwd_span")) |
                           (1 << hpfw_amd.KERNEL_KINDS.index("fwd_cols")))
     barrier()
     torch.cuda.synchronize()
@@ -267,6 +268,30 @@ def main():
                          "fwd_rows_hbm_bytes_per_clip",
                          "not HBM-bound: three fused LDS passes per row with a barrier each, 61 % of wave-cycles parked "
                          "(profiles/r03_sq.json); three workgroups per CU")
+    # the two stages of the forward transform run in chunks of a few clips on two streams (the
+    # column stage's output stays in the Infinity Cache), so their launches overlap and the stage is timed as ONE span on
+    # the caller's stream, like the chirp-z classes; the per-launch figures above are durations of launches that share the chip
+    span_ms, span_n = kt.get("fwd_span", (0.0, 0))
+    chunked = kt["fwd_cols"][1] > span_n > 0
+    roof_fwd = None
+    if span_n:
+        clips = n_clips * args.steps / span_n
+        gbs = (cols_bytes + rows_bytes) * clips / (span_ms / span_n * 1e-3) / 1e9
+        tr = [traffic_json.get("fwd_cols_hbm_bytes_per_clip"), traffic_json.get("fwd_rows_hbm_bytes_per_clip")]
+        roof_fwd = {"kernel": "forward transform as a span: fwd_cols_q3_kernel + fwd_rows2_kernel" +
+                              (f", {kt['fwd_cols'][1] // span_n} chunks per pass in turn on two streams" if chunked else ""),
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": (sum(tr) * clips if None not in tr else None),
+                    "avg_span_ms": round(span_ms / span_n, 4), "spans": span_n,
+                    "bytes_per_clip": cols_bytes + rows_bytes, "clips_per_span": clips,
+                    "note": "algorithmic bytes of both stages over the span's duration (one HIP event pair on the caller's "
+                            "stream around fork and join); traffic: the two kernels' counters from whole-batch launches "
+                            "(HPFW_FWD_CHUNK=0), an upper bound for the chunked run, whose 5.3 MB per clip of column-stage "
+                            "output need not reach HBM"}
+        if chunked:
+            for r in (roof_cols, roof_rows):
+                r["note"] = "launches of one chunk, overlapping with the other stream's: " + r["note"]
     ranked = sorted([roof_pj, roof_cols, roof_rows], key=lambda r: -r["avg_launch_ms"])
     roofline, roofline_second, roofline_third = ranked
 
@@ -421,6 +446,7 @@ def main():
                              "note": "weak scaling: what every rank does per step is what the N = 1 run does"},
             "kernel_ms_one_pass": split,
             "roofline": roofline, "roofline_second_kernel": roofline_second, "roofline_third_kernel": roofline_third,
+            "roofline_forward_span": roof_fwd,
             "cpu_baseline": cpu_baseline, "parity": parity,
             "projection_f32_chain": f32_chain,
             "pcie_inclusive": pcie, "ffi": ffi, "any_length": any_len, "search": search,

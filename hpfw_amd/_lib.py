@@ -15,7 +15,7 @@ HIT_DTYPE = np.dtype([("dist", "<u4"), ("clip", "<u4"), ("offset", "<i4"), ("pad
 VOTE_DTYPE = np.dtype([("clip", "<u4"), ("pad", "<u4"), ("offset", "<i8"), ("cnt", "<f4"), ("pad2", "<f4")])
 
 KERNEL_KINDS = ("fwd_rows", "fwd_cols", "cq_chirpz", "db", "project_mfma", "delta_pack",
-                "hamming_scan", "topk", "pcm_pairs")
+                "hamming_scan", "topk", "pcm_pairs", "fwd_span")
 
 # every symbol include/hpfw_gpu.h declares (tests check that the library exports all of them)
 EXPORTS = (

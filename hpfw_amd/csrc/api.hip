@@ -166,9 +166,9 @@ int upload(const std::vector<T> &v, const T **out, DevPlan *dp)
     return 0;
 }
 
-enum KernelKind { K_ROWS = 0, K_COLS, K_CQ, K_DB, K_PROJECT, K_PACK, K_SCAN, K_TOPK, K_PAIRS, K_COUNT };
+enum KernelKind { K_ROWS = 0, K_COLS, K_CQ, K_DB, K_PROJECT, K_PACK, K_SCAN, K_TOPK, K_PAIRS, K_FWD, K_COUNT };
 const char *const kKernelNames[K_COUNT] = {"fwd_rows", "fwd_cols", "cq_chirpz", "db",
-                                           "project_mfma", "delta_pack", "hamming_scan", "topk", "pcm_pairs"};
+                                           "project_mfma", "delta_pack", "hamming_scan", "topk", "pcm_pairs", "fwd_span"};
 
 struct TimedLaunch {
     int kind;
@@ -222,6 +222,11 @@ struct hpfw_gpu {
     hipStream_t cq_side[kCqSide] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t cq_fork = nullptr, cq_join[kCqSide] = {nullptr, nullptr, nullptr, nullptr};
     int cq_concurrent = 1; // HPFW_CQ_SERIAL=1 in the environment at creation: one class after the other on the caller's stream
+    // the forward transform of a large batch in chunks of fwd_chunk clips taken in turn by fwd_streams streams (the
+    // caller's and side streams): column stage and row stage of a chunk back to back, so that the column stage's output
+    // (5.3 MB per clip) is read back out of the Infinity Cache instead of HBM.  HPFW_FWD_CHUNK (0: one launch per stage
+    // for the whole batch), HPFW_FWD_STREAMS (1..5) in the environment at creation
+    int fwd_chunk = 16, fwd_streams = 2;
     void *d_topk_scratch = nullptr;
     size_t topk_scratch_cap = 0;
     // Mel front-end: tables (owned by mel_owned), workspaces
@@ -685,6 +690,17 @@ int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
     return ensure((void **)&h->d_clipmax, &h->clipmax_cap, (size_t)ns * 4);
 }
 
+// the side streams and their events (chirp-z classes side by side, chunks of the forward transform in turn)
+int ensure_side_streams(hpfw_gpu *h)
+{
+    if (h->cq_fork) return HPFW_OK;
+    bool ok = hipEventCreateWithFlags(&h->cq_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < hpfw_gpu::kCqSide && ok; ++k)
+        ok = hipStreamCreateWithFlags(&h->cq_side[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&h->cq_join[k], hipEventDisableTiming) == hipSuccess;
+    return ok ? HPFW_OK : fail(HPFW_E_HIP, "side streams");
+}
+
 // a1 + the forward transform for nb clips: PCM -> bins [kmin, kmax) in x
 int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf *x, hipStream_t s)
 {
@@ -708,6 +724,37 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
             hpfw::launch_bz_cols_last(dp->bz, other, nb, x, s);
         }
         return check_launch("bz_cols");
+    }
+    Timed span(h, K_FWD, s);                     // the whole forward transform as one span (its chunks overlap)
+    if (h->fwd_chunk > 0 && nb >= 6 * h->fwd_chunk) {
+        const int lanes = h->fwd_streams;
+        if ((rc = ensure_side_streams(h))) return rc;
+        if (lanes > 1) {
+            HIP_TRY(hipEventRecord(h->cq_fork, s));
+            for (int k = 0; k + 1 < lanes; ++k) HIP_TRY(hipStreamWaitEvent(h->cq_side[k], h->cq_fork, 0));
+        }
+        // a stream's chunks follow each other in order, so every stream has one region of z of its own
+        const int64_t region = (int64_t)h->fwd_chunk * dp->rows_out.hq * 2 * p.n2;
+        int i = 0;
+        for (int c0 = 0; c0 < nb; c0 += h->fwd_chunk, ++i) {
+            const int nc = std::min(nb - c0, h->fwd_chunk);
+            const int lane = i % lanes;
+            hipStream_t st = lane ? h->cq_side[lane - 1] : s;
+            float *zr = (float *)h->ws[0] + lane * region;
+            {
+                Timed t(h, K_COLS, st);
+                hpfw::launch_fwd_cols_q(dp->cols, d_pcm + (int64_t)c0 * p.n, p.n, nc, zr, st);
+            }
+            {
+                Timed t(h, K_ROWS, st);
+                hpfw::launch_fwd_rows2(dp->rows, dp->rows_out, zr, nc, x + (int64_t)c0 * dp->rows_out.n1 * dp->rows_out.q2w, st);
+            }
+        }
+        for (int k = 0; k + 1 < lanes; ++k) {
+            HIP_TRY(hipEventRecord(h->cq_join[k], h->cq_side[k]));
+            HIP_TRY(hipStreamWaitEvent(s, h->cq_join[k], 0));
+        }
+        return check_launch("fwd_chunks");
     }
     {
         Timed t(h, K_COLS, s);
@@ -742,13 +789,7 @@ int run_front(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, int slot, 
         for (const hpfw::CqClassDev &cd : dp->cls) n_lds += cd.outer ? 0 : 1;
         // (a handful of clips: the five launches are tens of microseconds each, and forking costs the host a dozen calls)
         const bool fork = h->cq_concurrent && n_lds > 1 && nb >= 4;
-        if (fork && !h->cq_fork) {
-            bool ok = hipEventCreateWithFlags(&h->cq_fork, hipEventDisableTiming) == hipSuccess;
-            for (int k = 0; k < hpfw_gpu::kCqSide && ok; ++k)
-                ok = hipStreamCreateWithFlags(&h->cq_side[k], hipStreamNonBlocking) == hipSuccess &&
-                     hipEventCreateWithFlags(&h->cq_join[k], hipEventDisableTiming) == hipSuccess;
-            if (!ok) return fail(HPFW_E_HIP, "streams of the chirp-z classes");
-        }
+        if (fork && (rc = ensure_side_streams(h))) return rc;
         if (fork) {
             HIP_TRY(hipEventRecord(h->cq_fork, s));
             for (int k = 0; k < hpfw_gpu::kCqSide; ++k) HIP_TRY(hipStreamWaitEvent(h->cq_side[k], h->cq_fork, 0));
@@ -828,6 +869,8 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     auto *h = new hpfw_gpu();
     h->device = device;
     if (std::getenv("HPFW_CQ_SERIAL")) h->cq_concurrent = 0;
+    if (const char *e = std::getenv("HPFW_FWD_CHUNK")) h->fwd_chunk = std::max(0, atoi(e));
+    if (const char *e = std::getenv("HPFW_FWD_STREAMS")) h->fwd_streams = std::min(hpfw_gpu::kCqSide + 1, std::max(1, atoi(e)));
     if (const char *e = std::getenv("HPFW_PROJECTION")) // "f32": handles start with the f32 fma chain (hpfw_gpu_set_projection(h, 0))
         h->projection = std::strcmp(e, "f32") == 0 ? 0 : 1;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||

@@ -327,6 +327,41 @@ def test_constant_q_classes_side_by_side_or_in_turn(torch_cuda, oracle, filters,
         g.close()
 
 
+def test_forward_transform_in_chunks_on_streams_in_turn(torch_cuda, oracle, filters, monkeypatch):
+    """a large batch goes through the forward transform in chunks of HPFW_FWD_CHUNK clips (default 16) that HPFW_FWD_STREAMS
+    streams (default 2: the caller's and a side stream) take in turn, column stage and row stage of a chunk back to back
+    (api.hip run_forward: the column stage's output stays in the Infinity Cache); HPFW_FWD_CHUNK=0 runs one launch per
+    stage over the whole batch.  100 clips = six chunks of 16 and a ragged one of 4: the same hashprints whatever the
+    chunking, on the null stream and on a side stream, with another call enqueued right behind on a third stream"""
+    torch = torch_cuda
+    base = np.stack([synth.gen_clip(900 + i, 2.0) for i in range(10)])
+    clips = np.concatenate([np.roll(base, 37 * r, axis=1) for r in range(10)])        # 100 different clips
+    clips[5::10] = -clips[5::10]
+    n = clips.shape[1]
+    plan = oracle.Plan(n)
+    want = plan.extract_batch(filters, clips, n_threads=8)
+    d = torch.from_numpy(clips).cuda()
+    for chunk, streams in ((None, None), ("7", "3"), ("16", "1"), ("0", None), ("9", "5")):
+        for key, val in (("HPFW_FWD_CHUNK", chunk), ("HPFW_FWD_STREAMS", streams)):
+            if val is None:
+                monkeypatch.delenv(key, raising=False)
+            else:
+                monkeypatch.setenv(key, val)
+        g = hpfw_amd.Gpu(0)                                   # the switches are read when a handle is created
+        g.set_filters(filters)
+        side, other = torch.cuda.Stream(), torch.cuda.Stream()
+        for stream in (0, side.cuda_stream):
+            hp = torch.zeros((len(clips), plan.n_hp), dtype=torch.int64, device="cuda")
+            hp2 = torch.zeros_like(hp)
+            torch.cuda.synchronize()
+            g.extract_dev(d.data_ptr(), n, len(clips), hp.data_ptr(), stream)
+            g.extract_dev(d.data_ptr(), n, len(clips), hp2.data_ptr(), other.cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(hp.cpu().numpy().view(np.uint64), want), (chunk, streams, stream)
+            assert np.array_equal(hp2.cpu().numpy().view(np.uint64), want), (chunk, streams, stream)
+        g.close()
+
+
 def test_streams_mixed_without_sync(torch_cuda, oracle, filters):
     """One handle, three streams, no synchronisation by the caller: a device call on a non-blocking side
     stream, the host entry point (its own private streams), a device call on the null stream and an index
