@@ -16,6 +16,9 @@ mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace -o p --output-format csv -- python3 bench.py > gpurun_out/prof/bench_trace.log 2> gpurun_out/prof/bench_trace.err || { echo "trace run failed"; tail -5 gpurun_out/prof/bench_trace.err; exit 1; }
 echo "trace done"
 LIGHT="--no-parity --no-cpu-baseline --no-pcie --no-any-length --no-learn --steps 2 --warmup 1"
+# the counter passes launch the two stages of the forward transform over the whole batch (per-clip figures = per launch /
+# 1000 clips); the trace above ran them as shipped, in chunks of 16 clips on two streams
+export HPFW_FWD_CHUNK=0
 for c in fetch:FETCH_SIZE write:WRITE_SIZE \
          "sq1:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
          "sq2:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
@@ -26,6 +29,7 @@ for c in fetch:FETCH_SIZE write:WRITE_SIZE \
   rocprofv3 --kernel-trace --pmc $n -d gpurun_out/prof/$d -o p --output-format csv -- python3 bench.py $LIGHT > gpurun_out/prof/bench_$d.log 2> gpurun_out/prof/bench_$d.err || { echo "$d run failed"; tail -5 gpurun_out/prof/bench_$d.err; }
   echo "$d done"
 done
+unset HPFW_FWD_CHUNK
 for c in calib_fetch:FETCH_SIZE calib_write:WRITE_SIZE; do
   d=${c%%:*}; n=${c#*:}
   rocprofv3 --kernel-trace --pmc $n -d gpurun_out/prof/$d -o p --output-format csv -- tools/fetch_calib.bin > gpurun_out/prof/$d.log 2>&1 || echo "$d failed"
