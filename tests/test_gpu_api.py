@@ -360,6 +360,21 @@ def test_forward_transform_in_chunks_on_streams_in_turn(torch_cuda, oracle, filt
             assert np.array_equal(hp.cpu().numpy().view(np.uint64), want), (chunk, streams, stream)
             assert np.array_equal(hp2.cpu().numpy().view(np.uint64), want), (chunk, streams, stream)
         g.close()
+    # the chirp-z forward transform (a length with a prime factor above 7) has the same switch, HPFW_BZ_CHUNK (default 32)
+    odd = np.ascontiguousarray(clips[:20, :n - 1199])
+    plan = oracle.Plan(odd.shape[1])
+    want = plan.extract_batch(filters, odd, n_threads=8)
+    d = torch.from_numpy(odd).cuda()
+    for chunk, streams in (("3", "2"), ("3", "4"), ("0", "2")):
+        monkeypatch.setenv("HPFW_BZ_CHUNK", chunk)
+        monkeypatch.setenv("HPFW_FWD_STREAMS", streams)
+        g = hpfw_amd.Gpu(0)
+        g.set_filters(filters)
+        hp = torch.zeros((len(odd), plan.n_hp), dtype=torch.int64, device="cuda")
+        g.extract_dev(d.data_ptr(), odd.shape[1], len(odd), hp.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(hp.cpu().numpy().view(np.uint64), want), (chunk, streams)
+        g.close()
 
 
 def test_streams_mixed_without_sync(torch_cuda, oracle, filters):
