@@ -104,7 +104,7 @@ int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
 /* host buffers; copies in, runs, copies out, synchronises */
 int hpfw_gpu_extract_pcm16_host(hpfw_gpu *h, const int16_t *pcm, int64_t n_samples, int64_t n_clips,
                                 uint64_t *hp);
-/* clips processed per internal pass (workspace = ~9.5 MB per clip at 30 s); 0 = default (1024) */
+/* clips processed per internal pass at most (workspace = ~9.5 MB per clip at 30 s; a call splits into passes of equal size); 0 = default (256) */
 int hpfw_gpu_set_batch(hpfw_gpu *h, int clips_per_pass);
 
 /* The smallest supported clip length >= n_samples, or -1 beyond the longest supported clip.  Host-only.
