@@ -15,9 +15,9 @@ rm -rf gpurun_out/prof
 mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace -o p --output-format csv -- python3 bench.py > gpurun_out/prof/bench_trace.log 2> gpurun_out/prof/bench_trace.err || { echo "trace run failed"; tail -5 gpurun_out/prof/bench_trace.err; exit 1; }
 echo "trace done"
-LIGHT="--no-parity --no-cpu-baseline --no-pcie --no-any-length --no-learn --steps 2 --warmup 1"
+LIGHT="--no-parity --no-cpu-baseline --no-pcie --no-any-length --no-learn --steps 2 --warmup 1 --batch 1000"
 # the counter passes launch the two stages of the forward transform over the whole batch (per-clip figures = per launch /
-# 1000 clips); the trace above ran them as shipped, in chunks of 16 clips on two streams
+# 1000 clips: one pass, --batch 1000); the trace above ran them as shipped, four passes, chunks of 16 clips on two streams
 export HPFW_FWD_CHUNK=0
 for c in fetch:FETCH_SIZE write:WRITE_SIZE \
          "sq1:SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
