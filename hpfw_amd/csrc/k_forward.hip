@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kCqThreads, 2) void fwd_cols_q_kernel(ColsQArgs a, 
 // transposition with byte permutes as above, 32 rows at a time; no workgroup barrier: a wave's LDS traffic is in
 // order).  What is left in LDS are the twiddle digits of a row tile, fetched by global_load_lds (no registers) into
 // one of two buffers while the results of the previous tile are converted and stored: 43 KB + 8 KB per workgroup
-// and at most 168 registers, so three workgroups = twelve waves share a CU, one barrier per tile.
+// and at most 168 registers, so three workgroups = twelve waves share a CU, one barrier (behind a full vmcnt(0)) per tile.
 constexpr int kCq3ScratchBytes = 2 * 2 * 32 * 16;                         // per wave: [plane][unit][slot][16 bytes]
 constexpr int cq3_lds_bytes(int waves) { return 2 * kCqABytes + waves * kCq3ScratchBytes; }
 
@@ -445,9 +445,6 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
     CQ_STAMP(0);
     const int cbase = col0 + wave * 32 + 4 * h;      // D: registers 4 g .. 4 g + 3 are columns cbase + 8 g + (0..3), tile column = lane & 31
     const bool vec4 = (a.n2 & 3) == 0;
-    // all of the wave's columns inside the row and 16-byte stores: then a tile ends with exactly four store
-    // instructions, and the wait at the top of the next one can leave them in flight
-    const bool four_stores = vec4 && col0 + wave * 32 + 32 <= a.n2;
     auto corr_of = [&](int mt) {
         const int row = 32 * mt + nl, q1 = row >> 1;
         return a.corr[2 * (q1 < a.hq ? q1 : a.hq - 1) + (row & 1)];
@@ -456,13 +453,11 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
     for (int mt = 0; mt < a.mt; ++mt) {
         const int row = 32 * mt + nl, q1 = row >> 1;
         const bool live = q1 < a.hq;
-        // this wave's pieces of the tile's digits have landed (they are older than the previous tile's stores, and
-        // memory operations retire in order); after the barrier everybody's have, and everybody is done with the
-        // other buffer
-        if (four_stores)
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // this wave's pieces of the tile's digits have landed; after the barrier everybody's have, and everybody is done
+        // with the other buffer.  (A counted wait that leaves the previous tile's four stores in flight is NOT safe:
+        // reads and writes retire out of order with respect to each other, so "at most four outstanding" does not mean
+        // that the older global_load_lds are done -- it passed every test on an idle GPU and failed with two processes on it.)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         CQ_STAMP(1);
         double corr_next = 0.0;
         if (mt + 1 < a.mt) corr_next = corr_of(mt + 1);   // here long before the next tile asks for it
@@ -494,7 +489,7 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
         asm volatile("" : "+v"(corr_next) : : "memory");
         CQ_STAMP(3);
         if (mt + 1 < a.mt) issue_a(mt + 1, (mt + 1) & 1);
-        asm volatile("" ::: "memory");           // the stores below stay below: they are the youngest at the next wait
+        asm volatile("" ::: "memory");
         CQ_STAMP(4);
         // D[tile row = column][tile column = output row]: this lane holds output row `row`, register r = column
         // cbase + 8 (r >> 2) + (r & 3).  G = sum_c acc_c 2^(8c) + corr: n1 <= 224, so the digit-product sums pair up
