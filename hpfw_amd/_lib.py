@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhpfw_gpu.so")
+# (HPFW_GPU_LIB: another build of the same library, for diagnosis -- tools/interfere.py)
+LIB_PATH = os.environ.get("HPFW_GPU_LIB") or os.path.join(_HERE, "lib", "libhpfw_gpu.so")
 
 HIT_DTYPE = np.dtype([("dist", "<u4"), ("clip", "<u4"), ("offset", "<i4"), ("pad", "<u4")])
 VOTE_DTYPE = np.dtype([("clip", "<u4"), ("pad", "<u4"), ("offset", "<i8"), ("cnt", "<f4"), ("pad2", "<f4")])
@@ -36,7 +37,7 @@ EXPORTS = (
     "hpfw_gpu_cfg_set_filters", "hpfw_gpu_cfg_hashprints", "hpfw_gpu_mel_hashprints_pcm16_host",
     "hpfw_gpu_cfg_cov_reset", "hpfw_gpu_cfg_cov_accumulate", "hpfw_gpu_cfg_cov_get", "hpfw_gpu_cfg_learn_filters",
     "hpfw_gpu_set_kernel_timing", "hpfw_gpu_get_kernel_timing", "hpfw_gpu_plan_checksum",
-    "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions", "hpfw_gpu_chirpz_table", "hpfw_gpu_prepare_length", "hpfw_gpu_set_projection", "hpfw_gpu_get_projection",
+    "hpfw_gpu_plan_checksum_ex", "hpfw_gpu_set_conventions", "hpfw_gpu_chirpz_table", "hpfw_gpu_debug_workspace", "hpfw_gpu_prepare_length", "hpfw_gpu_set_projection", "hpfw_gpu_get_projection",
     "hpfw_gpu_hashprints_from_db", "hpfw_gpu_stage_delta_q",
     "par_collector_new", "par_collector_del", "par_collector_prepare",
     "par_collector_calc_hashprint", "par_collector_calc_hashprints", "par_collector_save", "par_collector_load",
@@ -138,6 +139,7 @@ def lib():
     L.hpfw_gpu_plan_checksum.argtypes = [i64, vp]
     L.hpfw_gpu_plan_checksum_ex.argtypes = [i64, i32, u32, vp]
     L.hpfw_gpu_chirpz_table.argtypes = [vp, i64, i32, vp, i64, vp]
+    L.hpfw_gpu_debug_workspace.argtypes = [vp, i32, vp, vp]
     L.hpfw_gpu_prepare_length.argtypes = [vp, i64]
     L.hpfw_gpu_set_projection.argtypes = [vp, i32]
     L.hpfw_gpu_get_projection.argtypes = [vp]
@@ -252,6 +254,12 @@ class Gpu:
     def prepare_length(self, n_samples):
         """build the host half of the tables of a clip length on the calling thread (thread-safe; see hpfw_gpu.h)"""
         check(lib().hpfw_gpu_prepare_length(self._h, int(n_samples)))
+
+    def debug_workspace(self, which):
+        """(device pointer, bytes) of extraction workspace `which` as the last call left it (diagnosis)"""
+        p, b = ctypes.c_void_p(), ctypes.c_size_t()
+        check(lib().hpfw_gpu_debug_workspace(self._h, which, ctypes.byref(p), ctypes.byref(b)))
+        return p.value or 0, b.value
 
     def chirpz_table(self, n_samples, which):
         """device-generated table of the chirp-z forward transform as complex64 (0 w, 1 T_L, 2 Bhat, 3 w[k] / L)"""

@@ -230,6 +230,7 @@ struct hpfw_gpu {
     // (5.3 MB per clip) is read back out of the Infinity Cache instead of HBM.  HPFW_FWD_CHUNK (0: one launch per stage
     // for the whole batch), HPFW_FWD_STREAMS (1..5) in the environment at creation
     int fwd_chunk = 16, fwd_streams = 2;
+    int cols_variant = 0; // HPFW_COLS_VARIANT (diagnosis): kernels.h ColsQArgs::variant
     int bz_chunk = 32;  // the same for the chirp-z forward transform's three kernels (HPFW_BZ_CHUNK; 38.6 -> 39.6 k clips/s at 30 s)
     void *d_topk_scratch = nullptr;
     size_t topk_scratch_cap = 0;
@@ -708,6 +709,10 @@ int ensure_side_streams(hpfw_gpu *h)
     return ok ? HPFW_OK : fail(HPFW_E_HIP, "side streams");
 }
 
+#if defined(HPFW_ROWS_SNAP)
+hpfw::cf *g_rows_snap = nullptr; // diagnosis builds: fft_rows.h HPFW_SNAP
+#endif
+
 // a1 + the forward transform for nb clips: PCM -> bins [kmin, kmax) in x
 int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf *x, hipStream_t s)
 {
@@ -767,6 +772,8 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
         return check_launch("bz_cols");
     }
     Timed span(h, K_FWD, s);                     // the whole forward transform as one span (its chunks overlap)
+    hpfw::ColsQArgs cols = dp->cols;
+    cols.variant = h->cols_variant;
     if (h->fwd_chunk > 0 && nb >= 6 * h->fwd_chunk) {
         const int lanes = h->fwd_streams;
         if ((rc = ensure_side_streams(h))) return rc;
@@ -784,7 +791,7 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
             float *zr = (float *)h->ws[0] + lane * region;
             {
                 Timed t(h, K_COLS, st);
-                hpfw::launch_fwd_cols_q(dp->cols, d_pcm + (int64_t)c0 * p.n, p.n, nc, zr, st);
+                hpfw::launch_fwd_cols_q(cols, d_pcm + (int64_t)c0 * p.n, p.n, nc, zr, st);
             }
             {
                 Timed t(h, K_ROWS, st);
@@ -799,11 +806,14 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
     }
     {
         Timed t(h, K_COLS, s);
-        hpfw::launch_fwd_cols_q(dp->cols, d_pcm, p.n, nb, (float *)h->ws[0], s); // pcm as it lies -> z [hq][Re, Im][n2]
+        hpfw::launch_fwd_cols_q(cols, d_pcm, p.n, nb, (float *)h->ws[0], s); // pcm as it lies -> z [hq][Re, Im][n2]
     }
     if ((rc = check_launch("fwd_cols"))) return rc;
     {
         Timed t(h, K_ROWS, s);
+#if defined(HPFW_ROWS_SNAP)
+        dp->rows.snap = g_rows_snap;
+#endif
         hpfw::launch_fwd_rows2(dp->rows, dp->rows_out, (const float *)h->ws[0], nb, x, s); // -> x [n1][q2w]
     }
     return check_launch("fwd_rows");
@@ -912,6 +922,7 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     if (std::getenv("HPFW_CQ_SERIAL")) h->cq_concurrent = 0;
     if (const char *e = std::getenv("HPFW_FWD_CHUNK")) h->fwd_chunk = std::max(0, atoi(e));
     if (const char *e = std::getenv("HPFW_BZ_CHUNK")) h->bz_chunk = std::max(0, atoi(e));
+    if (const char *e = std::getenv("HPFW_COLS_VARIANT")) h->cols_variant = atoi(e);
     if (const char *e = std::getenv("HPFW_FWD_STREAMS")) h->fwd_streams = std::min(hpfw_gpu::kCqSide + 1, std::max(1, atoi(e)));
     if (const char *e = std::getenv("HPFW_PROJECTION")) // "f32": handles start with the f32 fma chain (hpfw_gpu_set_projection(h, 0))
         h->projection = std::strcmp(e, "f32") == 0 ? 0 : 1;
@@ -1221,6 +1232,22 @@ int hpfw_gpu_prepare_length(hpfw_gpu *h, int64_t n_samples)
     }
     h->host_cv.notify_all();
     return ok ? 0 : fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n_samples) + ": " + why);
+}
+
+#if defined(HPFW_ROWS_SNAP)
+int hpfw_gpu_debug_set_rows_snap(void *d_snap)
+{
+    g_rows_snap = static_cast<hpfw::cf *>(d_snap);
+    return 0;
+}
+#endif
+
+int hpfw_gpu_debug_workspace(hpfw_gpu *h, int which, void **d_ptr, size_t *bytes)
+{
+    if (!h || which < 0 || which >= 7 || !d_ptr || !bytes) return fail(HPFW_E_INVALID, "bad argument");
+    *d_ptr = h->ws[which];
+    *bytes = h->ws_bytes[which];
+    return 0;
 }
 
 // ---- diagnostic: the device-generated tables of the chirp-z forward transform ------------------

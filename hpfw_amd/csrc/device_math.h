@@ -27,13 +27,20 @@ HPFW_DEVICE cf tw_entry(const cf *__restrict__ gt, int e, int nb, int b)
     return (e & 1) ? p.b : p.a;
 }
 
-// The complex helpers.  Each is a fixed sequence of IEEE operations (stated by the scalar form, which is what the host-side
-// emulation of tests/emu compiles); on the GPU the same operations are issued as packed instructions on the (Re, Im) register
-// pair -- v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 round each half exactly as the scalar instruction does, and their
-// operand-select and negate modifiers do the swaps and sign changes of a rotation by +-i or a complex product for free.
-// Left to itself the compiler pairs values across butterflies and pays for it in register moves: about twice the
-// instructions per fused group.
-#if defined(HPFW_SIMT_EMU)
+// The complex helpers.  Each is a fixed sequence of IEEE operations on scalar f32 instructions (the host-side emulation of
+// tests/emu compiles the same text).
+//
+// NO PACKED FP32.  Round 3 issued these operations as v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on the (Re, Im) register
+// pair.  On MI355X those instructions return wrong results in lanes 48..63 of a wave -- one instruction, sixteen lanes at
+// a time -- while a kernel that feeds int8 matrix instructions from LDS (hashprint_q_kernel, the LDS-staged column
+// kernel) runs on the same compute units, from another stream or another process; alone on the GPU they are exact,
+// which is why every single-process test passed.  tools/pk_mfma_repro.hip shows it without this library's transform
+// code (packed against scalar evaluation of the same butterflies in one thread: 0 of 8.2e9 values differ alone, 8.5e5
+// beside hashprint_q_kernel, all of them in lanes 48..63); DESIGN.md section 9 has the measurements.  The library is
+// therefore built with the target feature packed-fp32-ops switched off (csrc/Makefile), so that the compiler cannot form
+// such an instruction from this text or any other either, and the build checks the code object for them.  The scalar
+// form costs nothing: 9.94 against 10.03 ms per 1000 clips (the inline-asm packed form kept the compiler from
+// scheduling around it).
 HPFW_DEVICE cf c_add(cf a, cf b) { return {a.r + b.r, a.i + b.i}; }
 HPFW_DEVICE cf c_sub(cf a, cf b) { return {a.r - b.r, a.i - b.i}; }
 // a + (-i) d and a - (-i) d
@@ -58,55 +65,6 @@ HPFW_DEVICE cf c_fma_s(float s, cf a, cf b)
     return {HPFW_FMAF(s, a.r, b.r), HPFW_FMAF(s, a.i, b.i)};
 }
 HPFW_DEVICE cf c_scale(float s, cf a) { return {s * a.r, s * a.i}; }
-#else
-typedef float v2f __attribute__((ext_vector_type(2)));
-HPFW_DEVICE v2f c_pair(cf a) { return v2f{a.r, a.i}; }
-HPFW_DEVICE cf c_unpair(v2f v) { return cf{v.x, v.y}; }
-#define HPFW_PK_BINARY(name, ins)                                                         \
-    HPFW_DEVICE cf name(cf a, cf b)                                                       \
-    {                                                                                     \
-        v2f o;                                                                            \
-        asm(ins : "=v"(o) : "v"(c_pair(a)), "v"(c_pair(b)));                              \
-        return c_unpair(o);                                                               \
-    }
-// (plain sums and differences as vector arithmetic: the compiler emits the same packed instruction and knows what it is --
-// around an asm statement it pads for hazards the instruction does not have)
-HPFW_DEVICE cf c_add(cf a, cf b) { return c_unpair(c_pair(a) + c_pair(b)); }
-HPFW_DEVICE cf c_sub(cf a, cf b) { return c_unpair(c_pair(a) - c_pair(b)); }
-// a + (-i) d = (a.r + d.i, a.i - d.r) and a - (-i) d = (a.r - d.i, a.i + d.r)
-HPFW_PK_BINARY(c_add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")
-HPFW_PK_BINARY(c_sub_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")
-#undef HPFW_PK_BINARY
-// a * w: (p, q) = (a.i w.i, a.i w.r); (fma(a.r, w.r, -p), fma(a.r, w.i, q))
-HPFW_DEVICE cf c_mul(cf a, cf w)
-{
-    v2f t, o;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(c_pair(a)), "v"(c_pair(w)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(o) : "v"(c_pair(a)), "v"(c_pair(w)), "v"(t));
-    return c_unpair(o);
-}
-// a * conj(w): (p, q) = (a.i w.i, a.r w.i); (fma(a.r, w.r, p), fma(a.i, w.r, -q))
-HPFW_DEVICE cf c_mulc(cf a, cf w)
-{
-    v2f t, o;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t) : "v"(c_pair(a)), "v"(c_pair(w)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_hi:[0,0,1]" : "=v"(o) : "v"(c_pair(a)), "v"(c_pair(w)), "v"(t));
-    return c_unpair(o);
-}
-// s real (a compile-time constant at every call: it sits in a scalar register pair, both halves read from the low word)
-HPFW_DEVICE cf c_fma_s(float s, cf a, cf b)
-{
-    v2f o;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(o) : "s"(v2f{s, s}), "v"(c_pair(a)), "v"(c_pair(b)));
-    return c_unpair(o);
-}
-HPFW_DEVICE cf c_scale(float s, cf a)
-{
-    v2f o;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(o) : "s"(v2f{s, s}), "v"(c_pair(a)));
-    return c_unpair(o);
-}
-#endif
 
 // ---- forward DFT butterflies (sign -), in place on u[0..R) -------------------------------
 template <int R>

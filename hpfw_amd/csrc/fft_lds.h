@@ -126,7 +126,7 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
 }
 
 // inverse butterfly of the specification: swap, forward codelet, swap.  For radix 2, 3 and 4 the same operations on the
-// same values, written without the swaps (which cost register moves between the packed operations): multiplying by +i
+// same values, written without the swaps (which cost register moves): multiplying by +i
 // instead of -i, x - (-y) for x + y and x + (-y) for x - y, which round identically.
 template <int R>
 struct Idft {

@@ -24,7 +24,25 @@ struct RowGroups {
     int tw_off[kRowsMaxGroups]; // offset of the group's twiddle table in gtw (complex elements)
 };
 
+// diagnosis builds (-DHPFW_ROWS_SNAP, tools/rows_snapshots.py): the LDS image of every workgroup after the load and after
+// each fused group goes to RowsArgs::snap [workgroup][4][n2]
+#if defined(HPFW_ROWS_SNAP) && !defined(HPFW_SIMT_EMU)
+#define HPFW_SNAP(lds, a, slot, n2v)                                                                                   \
+    do {                                                                                                               \
+        if ((a).snap) {                                                                                                \
+            cf *dst_ = (a).snap + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (slot)) * (int64_t)(n2v);       \
+            for (int i_ = threadIdx.x; i_ < (n2v); i_ += blockDim.x) dst_[i_] = (lds)[i_];                              \
+            __syncthreads(); /* the next group writes in place */                                                      \
+        }                                                                                                              \
+    } while (0)
+#else
+#define HPFW_SNAP(lds, a, slot, n2v) ((void)0)
+#endif
+
 struct RowsArgs {
+#if defined(HPFW_ROWS_SNAP)
+    cf *snap;
+#endif
     int n1, n2, h;            // N = n1 * n2, h = n2 / 2 + 1
     int hpad;                 // row stride (floats) of the planar output, a multiple of 32
     int pair_stride;          // (the Mel front-end's frame pairs: 1)
@@ -288,16 +306,19 @@ struct StaticGroups<R1, R2, Rest...> {
             HPFW_BARRIER();
             HPFW_FOR_THREADS(tid, nthreads) { rows_last_store<R1, R2, N2>(lds, a, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
+            HPFW_SNAP(lds, a, g + 1, N2);
         } else if constexpr (sizeof...(Rest) == 2) {
             HPFW_CARRY(cf, outv, R1 * R2, nthreads);
             HPFW_FOR_THREADS(tid, nthreads) { rows_pre_compute<R1, R2, N2, LEN>(lds, a, gt, LEN, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
             HPFW_FOR_THREADS(tid, nthreads) { rows_pre_store<R1, R2, N2, LEN>(lds, a, LEN, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
+            HPFW_SNAP(lds, a, g + 1, N2);
             StaticGroups<Rest...>::template run_from<N2, LEN / (R1 * R2)>(lds, a, nthreads, g + 1);
         } else {
             HPFW_FOR_THREADS(tid, nthreads) { rows_group<R1, R2, N2, LEN>(lds, a, gt, LEN, tid, nthreads); }
             HPFW_BARRIER();
+            HPFW_SNAP(lds, a, g + 1, N2);
             StaticGroups<Rest...>::template run_from<N2, LEN / (R1 * R2)>(lds, a, nthreads, g + 1);
         }
     }
@@ -471,6 +492,7 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
         }
     }
     HPFW_BARRIER();
+    HPFW_SNAP(lds, a, 0, n2);
     Groups::run(lds, a, nthreads);
     const int *__restrict__ pos = a.pos_n2;
     constexpr bool kNat = Groups::kNatural;

@@ -313,6 +313,12 @@ int hpfw_gpu_prepare_length(hpfw_gpu *h, int64_t n_samples);
  * ask for the count only.  HPFW_E_INVALID for a 7-smooth length (unless HPFW_FORCE_BLUESTEIN is set). */
 int hpfw_gpu_chirpz_table(hpfw_gpu *h, int64_t n_samples, int which, float *out, int64_t capacity, int64_t *count);
 
+/* ---- diagnostic: the handle's extraction workspaces as the last call left them (device pointers; valid until the next
+ * call that grows them).  which: 0 = z, the column stage's output (chunked forward transform: one region per stream),
+ * 1 = forward bins in the rows layout, 2 = dB terms / spectrograms, 4 = wave maxima.  Used by tools/ and tests to name
+ * the first stage that differs; not part of the reference's interface. */
+int hpfw_gpu_debug_workspace(hpfw_gpu *h, int which, void **d_ptr, size_t *bytes);
+
 /* ---- legacy FFI: modules/python/parallel_collector_wrapper.hpp:12-38, same shapes --------- */
 typedef struct {
     char *filename;

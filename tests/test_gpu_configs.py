@@ -1,5 +1,9 @@
-"""BASELINE.json configs[2], [3] and [4] at their full index sizes on one MI355X, against the oracle.
+"""BASELINE.json configs[1] as the bench runs it, and configs[2], [3], [4] at their full index sizes, on one MI355X, against
+the oracle.
 
+configs[1]: 30 s clips in the numbers that take the bench's path through the library (at least 96: the forward
+            transform in chunks of 16 on two streams, all seven row tiles of the column kernel, the five chirp-z classes
+            forked) -- 128 clips on the null stream and on a side stream, every hashprint against the oracle;
 configs[2]: 10 000-clip index x 2320 hashprints, queries of 305 in groups of 32 (one group ragged), top-10,
             through all three scan kernels;
 configs[3]: the 100 000-clip index as 8 contiguous shards of 12 500 clips -- every shard scanned on this GPU
@@ -145,3 +149,30 @@ def test_config4_shard_streaming_windows(gpu, oracle, filters):
     hop = 1323000 / 7255 * 3
     for i, (_, song, start) in enumerate(windows):
         assert want[i, 0]["clip"] == where[song] and abs(want[i, 0]["offset"] - start / hop) <= 2
+
+
+def test_bench_configuration_thirty_second_clips(torch_cuda, oracle, filters):
+    """configs[1] as bench.py extracts it: 128 x 30 s clips (n1 = 210; chunks of 16 clips taken in turn by two streams,
+    parallel_collector.h:115-137 for every clip) -- on the null stream and on a side stream, twice each so that the second
+    call meets the first one's events; every hashprint equals the oracle's"""
+    torch = torch_cuda
+    n_clips = 128
+    base = np.stack([synth.gen_clip(7000 + i, 30.0) for i in range(8)])
+    clips = np.concatenate([np.roll(base, 97 * r + 1, axis=1) for r in range(n_clips // 8)])
+    n = clips.shape[1]
+    plan = oracle.Plan(n)
+    assert (plan.n1, plan.n_hp) == (210, N_HP)
+    want = plan.extract_batch(filters, clips, n_threads=THREADS)
+    g = hpfw_amd.Gpu(0)
+    g.set_filters(filters)
+    d = torch.from_numpy(clips).cuda()
+    side = torch.cuda.Stream()
+    for stream in (0, side.cuda_stream, 0, side.cuda_stream):
+        hp = torch.zeros((n_clips, plan.n_hp), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        g.extract_dev(d.data_ptr(), n, n_clips, hp.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = hp.cpu().numpy().view(np.uint64)
+        ne = got != want
+        assert not ne.any(), f"stream {stream}: {int(ne.sum())} hashprints differ, clips {np.nonzero(ne.any(axis=1))[0].tolist()[:10]}"
+    g.close()

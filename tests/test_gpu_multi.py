@@ -241,45 +241,3 @@ def test_group_prepare_learns_over_shards(torch_cuda, oracle, tmp_path, devices)
     assert np.abs(cov2 - rawc2).max() <= 2e-5 * np.abs(cov2).max()
     one.close()
     g2.close()
-
-
-_SHARED_GPU_WORKER = r"""
-import sys
-import numpy as np
-import torch
-sys.path.insert(0, sys.argv[1])
-import hpfw_amd
-from hpfw_amd import synth
-from oracle import oracle
-seed, reps = int(sys.argv[2]), int(sys.argv[3])
-filt = synth.make_filters()
-base = np.stack([synth.gen_clip(seed + i, 5.0) for i in range(12)])
-clips = np.concatenate([np.roll(base, 53 * r, axis=1) for r in range(10)])     # 120 clips: the chunked forward transform
-plan = oracle.Plan(clips.shape[1])
-want = plan.extract_batch(filt, clips, n_threads=4)
-g = hpfw_amd.Gpu(0)
-g.set_filters(filt)
-d = torch.from_numpy(clips).cuda()
-hp = torch.zeros((len(clips), plan.n_hp), dtype=torch.int64, device="cuda")
-bad = 0
-for _ in range(reps):
-    hp.zero_()
-    g.extract_dev(d.data_ptr(), clips.shape[1], len(clips), hp.data_ptr())
-    torch.cuda.synchronize()
-    bad += int((hp.cpu().numpy().view(np.uint64) != want).sum())
-print("differing", bad)
-"""
-
-
-def test_two_processes_share_the_gpu():
-    """Two processes extract on the SAME GPU at the same time (what the one-GPU rehearsal of the N = 2 bench does): the
-    kernels of one run between and beside the other's, so loads and stores complete in other orders than on a GPU of
-    one's own -- a counted `s_waitcnt vmcnt(4)` in the column kernel passed every single-process test and failed here.
-    Every hashprint of every repetition equals the oracle's in both processes."""
-    import sys
-    procs = [subprocess.Popen([sys.executable, "-c", _SHARED_GPU_WORKER, ROOT, str(4000 + 100 * i), "25"],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(2)]
-    outs = [p.communicate(timeout=600) for p in procs]
-    for p, (out, err) in zip(procs, outs):
-        assert p.returncode == 0, err[-2000:]
-        assert out.strip().splitlines()[-1] == "differing 0", (out, err[-500:])

@@ -1,0 +1,127 @@
+"""The GPU shared with other work: kernels of other streams and of other PROCESSES beside the extraction's.
+
+Round 3 failed here (6915 wrong hashprints with two processes on one GPU).  The cause, found in round 4 (DESIGN.md
+section 9, tools/pk_mfma_repro.hip): packed FP32 instructions (v_pk_add/mul/fma_f32), which the row transform and the
+chirp-z kernels used for their complex arithmetic, return wrong results in lanes 48..63 of a wave while a kernel that
+feeds int8 matrix instructions from LDS (hashprint_q_kernel of the same library, on another stream or in another
+process) runs on the same compute units.  The library is built without packed FP32 since; these tests put exactly that
+neighbour beside every stage, deterministically (two streams of one process) and as the round-3 scenario (two
+processes), and name the first stage that differs when something does."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import hpfw_amd  # noqa: E402
+from hpfw_amd import synth  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_packed_fp32_in_the_code_object():
+    """the build's own check, repeated on the library the tests load: no v_pk_*_f32 in the device code"""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    import tempfile
+    import shutil
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(hpfw_amd._lib.LIB_PATH, os.path.join(d, "lib.so"))
+        subprocess.run([objdump, "--offloading", "lib.so"], cwd=d, check=True, capture_output=True)
+        objs = [os.path.join(d, f) for f in os.listdir(d) if "amdgcn" in f]
+        assert objs
+        text = subprocess.run([objdump, "-d"] + objs, capture_output=True, text=True, check=True).stdout
+    assert "s_endpgm" in text
+    assert text.count("v_pk_add_f32") + text.count("v_pk_mul_f32") + text.count("v_pk_fma_f32") == 0
+
+
+@pytest.mark.parametrize("seconds, n_clips", [(5.0, 48), (30.0, 32)])
+def test_every_stage_beside_the_int8_matrix_kernels(torch_cuda, oracle, filters, seconds, n_clips):
+    """Two streams of one process: the forward transform, the chirp-z stage and the whole extraction on one, while the
+    other runs hashprint_q_kernel (and the LDS-staged column kernel) without pause.  With round 3's packed arithmetic
+    9-12 of 12 rounds of the first two stages came out wrong here; every round must equal the oracle / the quiet run."""
+    torch = torch_cuda
+    base = np.stack([synth.gen_clip(4000 + i, seconds) for i in range(4)])
+    clips = np.concatenate([np.roll(base, 53 * r, axis=1) for r in range(n_clips // 4)])
+    n = clips.shape[1]
+    plan = oracle.Plan(n)
+    nk = plan.kmax - plan.kmin
+    want_hp = plan.extract_batch(filters, clips, n_threads=8)
+    want_x = np.stack([plan.spectrum(c) for c in clips[:4]])
+    d = torch.from_numpy(clips).cuda()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    os.environ["HPFW_COLS_VARIANT"] = "1"                      # the neighbour's forward transform: the LDS-staged column kernel
+    nb_cols = hpfw_amd.Gpu(0)
+    del os.environ["HPFW_COLS_VARIANT"]
+    vic, nb = hpfw_amd.Gpu(0), hpfw_amd.Gpu(0)
+    for g in (vic, nb, nb_cols):
+        g.set_filters(filters)
+    x_ref = torch.zeros((n_clips, nk, 2), dtype=torch.float32, device="cuda")
+    vic.stage_spectrum_dev(d.data_ptr(), n, n_clips, x_ref.data_ptr())
+    mag_ref = torch.zeros((n_clips, 121, plan.c), dtype=torch.float32, device="cuda")
+    vic.stage_cqmag_dev(x_ref.data_ptr(), n, n_clips, mag_ref.data_ptr())
+    db = torch.zeros_like(mag_ref)
+    vic.stage_db_dev(mag_ref.data_ptr(), n_clips, plan.c, db.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(x_ref[:4].cpu().numpy().view(np.uint32), want_x.view(np.uint32))      # the quiet run is the oracle's
+    x, mag = torch.zeros_like(x_ref), torch.zeros_like(mag_ref)
+    hp = torch.zeros((n_clips, plan.n_hp), dtype=torch.int64, device="cuda")
+    hp_nb, x_nb = torch.zeros_like(hp), torch.zeros_like(x_ref)
+
+    def neighbour(k):
+        if k % 2:
+            nb_cols.stage_spectrum_dev(d.data_ptr(), n, n_clips, x_nb.data_ptr(), sb.cuda_stream)
+        nb.hashprints_from_db_dev(db.data_ptr(), n_clips, plan.c, hp_nb.data_ptr(), sb.cuda_stream)
+
+    bad = {"spectrum": [], "cqmag": [], "hashprints": []}
+    for rnd in range(10):
+        neighbour(rnd)
+        vic.stage_spectrum_dev(d.data_ptr(), n, n_clips, x.data_ptr(), sa.cuda_stream)
+        neighbour(rnd)
+        vic.stage_cqmag_dev(x_ref.data_ptr(), n, n_clips, mag.data_ptr(), sa.cuda_stream)
+        neighbour(rnd)
+        vic.extract_dev(d.data_ptr(), n, n_clips, hp.data_ptr(), sa.cuda_stream)
+        neighbour(rnd)
+        torch.cuda.synchronize()
+        for name, got, ref in (("spectrum", x, x_ref), ("cqmag", mag, mag_ref)):
+            ne = (got.view(torch.int32) != ref.view(torch.int32)).reshape(n_clips, -1).any(dim=1)
+            if bool(ne.any()):
+                bad[name].append((rnd, torch.nonzero(ne).flatten().tolist()[:8]))
+        ne = hp.cpu().numpy().view(np.uint64) != want_hp
+        if ne.any():
+            bad["hashprints"].append((rnd, np.nonzero(ne.any(axis=1))[0].tolist()[:8]))
+    for g in (vic, nb, nb_cols):
+        g.close()
+    assert bad == {"spectrum": [], "cqmag": [], "hashprints": []}, f"(round, clips) that differ, by stage: {bad}"
+
+
+def _run_pair(seconds, n_clips, reps, tmp_path):
+    start = str(tmp_path / "start")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "shared_gpu_diag.py"), str(4000 + 100 * i), str(reps), str(seconds),
+                               str(n_clips), start, "default"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    res = []
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+        res.append(json.loads(out.strip().splitlines()[-1]))
+    return res
+
+
+@pytest.mark.parametrize("seconds, n_clips, reps", [(5.0, 120, 60), (30.0, 128, 12)])
+def test_two_processes_share_the_gpu(tmp_path, seconds, n_clips, reps):
+    """Two processes extract on the SAME GPU at the same time (what a one-GPU rehearsal of the N = 2 bench does), started
+    together: in every repetition the forward transform alone, the front end alone and the whole extraction equal the
+    oracle in both processes -- 120 five-second clips (n1 = 35: two row tiles of the column kernel) and 128 thirty-second
+    clips (n1 = 210: seven tiles, chunks of 16 on two streams).  A failure prints, per process, how many values of which
+    stage differ and the first events (repetition, clip, rows / bands / words)."""
+    res = _run_pair(seconds, n_clips, reps, tmp_path)
+    report = [{"seed": r["seed"], "elapsed_s": r["elapsed_s"], "totals": r["totals"], "first_events": r["events"][:6]} for r in res]
+    for r in res:
+        assert all(v == 0 for t in r["totals"].values() for v in t.values()), json.dumps(report, indent=1)
+    # (the two did run side by side: each took a few seconds of repetitions after a common start)
+    assert min(r["elapsed_s"] for r in res) > 0.5, report
