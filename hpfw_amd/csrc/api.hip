@@ -230,7 +230,7 @@ struct hpfw_gpu {
     // (5.3 MB per clip) is read back out of the Infinity Cache instead of HBM.  HPFW_FWD_CHUNK (0: one launch per stage
     // for the whole batch), HPFW_FWD_STREAMS (1..5) in the environment at creation
     int fwd_chunk = 16, fwd_streams = 2;
-    int cols_variant = 0; // HPFW_COLS_VARIANT (diagnosis): kernels.h ColsQArgs::variant
+    int cols_variant = 0; // HPFW_COLS_VARIANT (tests, diagnosis): kernels.h ColsQArgs::variant
     int bz_chunk = 32;  // the same for the chirp-z forward transform's three kernels (HPFW_BZ_CHUNK; 38.6 -> 39.6 k clips/s at 30 s)
     void *d_topk_scratch = nullptr;
     size_t topk_scratch_cap = 0;

@@ -397,9 +397,7 @@ __device__ __forceinline__ void cq3_load_samples(const ColsQArgs &a, const int16
     }
 }
 
-// DMA: the twiddle digits of a row tile go to LDS by global_load_lds; otherwise (HPFW_COLS_DMA=0, diagnosis) through
-// registers: fetched where the DMA would be issued, written to LDS behind the tile's stores
-template <int LOADW, int kCq3Waves, bool DMA>        // a wave = 32 columns
+template <int LOADW, int kCq3Waves>                  // a wave = 32 columns
 __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArgs a, const int16_t *__restrict__ pcm, int64_t clip_samples,
                                                                     float *__restrict__ z)
 {
@@ -421,30 +419,15 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
     const v4i *image = static_cast<const v4i *>(a.image);
     const int steps = a.ks, pieces = 3 * steps;      // <= 7 steps: every sample of the columns is in registers
     // the twiddle digits of row tile mt into buffer `buf`: 21 pieces of 1 KB, every wave its share
-    constexpr int kPer = (kCqKSteps * 3 + kCq3Waves - 1) / kCq3Waves;
-    v4i pre[DMA ? 1 : kPer];
     auto issue_a = [&](int mt, int buf) {
         const v4i *src = image + (int64_t)mt * a.ks * 3 * 64 + lane;
 #pragma unroll
-        for (int e = 0; e < kPer; ++e) {
+        for (int e = 0; e < (kCqKSteps * 3 + kCq3Waves - 1) / kCq3Waves; ++e) {
             const int p = wave + kCq3Waves * e;
-            if (p < pieces) {
-                if constexpr (DMA)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
-                                                     (__attribute__((address_space(3))) void *)(abytes + buf * kCqABytes + p * 1024),
-                                                     16, 0, 0);
-                else
-                    pre[e] = src[p * 64];
-            }
-        }
-    };
-    auto commit_a = [&](int buf) {                   // (registers -> LDS; nothing to do for the DMA)
-        if constexpr (!DMA) {
-#pragma unroll
-            for (int e = 0; e < kPer; ++e) {
-                const int p = wave + kCq3Waves * e;
-                if (p < pieces) *(reinterpret_cast<v4i *>(abytes + buf * kCqABytes + p * 1024) + lane) = pre[e];
-            }
+            if (p < pieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + p * 64),
+                                                 (__attribute__((address_space(3))) void *)(abytes + buf * kCqABytes + p * 1024),
+                                                 16, 0, 0);
         }
     };
 #ifdef HPFW_COLS_STAMPS
@@ -459,7 +442,6 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
     v4i x[kCqKSteps][2];
     // the samples first (they come from HBM), the first tile's digits (from L2) behind them
     cq3_load_samples<LOADW>(a, clip_pcm, col0 + wave * 32, sc, lane, x, [&] { issue_a(0, 0); });
-    commit_a(0);
     CQ_STAMP(0);
     const int cbase = col0 + wave * 32 + 4 * h;      // D: registers 4 g .. 4 g + 3 are columns cbase + 8 g + (0..3), tile column = lane & 31
     const bool vec4 = (a.n2 & 3) == 0;
@@ -472,9 +454,11 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
         const int row = 32 * mt + nl, q1 = row >> 1;
         const bool live = q1 < a.hq;
         // this wave's pieces of the tile's digits have landed; after the barrier everybody's have, and everybody is done
-        // with the other buffer.  (A counted wait that leaves the previous tile's four stores in flight is NOT safe:
-        // reads and writes retire out of order with respect to each other, so "at most four outstanding" does not mean
-        // that the older global_load_lds are done -- it passed every test on an idle GPU and failed with two processes on it.)
+        // with the other buffer.  A full wait: loads and stores share the counter and are not guaranteed to retire in
+        // order with respect to each other, so "at most four outstanding" (the previous tile's stores) would not prove
+        // that the older global_load_lds are done.  (Round 3 blamed a counted wait here for wrong hashprints with two
+        // processes on the GPU; round 4 found that cause elsewhere -- packed FP32 in the row stage, device_math.h -- and
+        // this kernel's output was never wrong in any of the runs that localised it: tools/rows_error_shape.py.)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         CQ_STAMP(1);
         double corr_next = 0.0;
@@ -534,7 +518,6 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
             }
         }
         CQ_STAMP(6);
-        if (mt + 1 < a.mt) commit_a((mt + 1) & 1);  // (that buffer was last read in tile mt - 1: every wave is past this tile's barrier)
         corr = corr_next;
     }
 #ifdef HPFW_COLS_STAMPS
@@ -589,11 +572,8 @@ static void launch_cols_q_t(ColsQArgs a, const int16_t *d_pcm, int64_t clip_samp
         // itself 2.63 -> 2.9 ms, the step within 0.6 %: DESIGN.md section 9)
         constexpr int kWaves = 4;
         const int ncb = (a.n2 + 32 * kWaves - 1) / (32 * kWaves);
-        const dim3 g3(8 * ((grid.x * ncb + 7) / 8));
-        if (a.variant & 2)
-            hipLaunchKernelGGL((fwd_cols_q3_kernel<LOADW, kWaves, false>), g3, dim3(64 * kWaves), cq3_lds_bytes(kWaves), s, a, d_pcm, clip_samples, d_z);
-        else
-            hipLaunchKernelGGL((fwd_cols_q3_kernel<LOADW, kWaves, true>), g3, dim3(64 * kWaves), cq3_lds_bytes(kWaves), s, a, d_pcm, clip_samples, d_z);
+        hipLaunchKernelGGL((fwd_cols_q3_kernel<LOADW, kWaves>), dim3(8 * ((grid.x * ncb + 7) / 8)), dim3(64 * kWaves), cq3_lds_bytes(kWaves), s,
+                           a, d_pcm, clip_samples, d_z);
         return;
     }
     if (a.n1 <= 255)

@@ -61,15 +61,21 @@ __device__ __forceinline__ int q_fixed(float s)
 // rides on the staging loads.  dbg (tests only, NULL in extraction): D as int64 [clip][64][nhp].
 template <bool FROM_T>
 __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__restrict__ fq_image, const float *__restrict__ sdb,
-                                                                   const float *__restrict__ tmax, int c, int nhp,
+                                                                   const float *__restrict__ tmax, int c, int nhp, int n_tiles_x, int n_clips,
                                                                    uint64_t *__restrict__ hp, long long *__restrict__ dbg)
 {
     unsigned char *slab = smem_raw;                                   // [chunk][column (pitch 160)][digit][16]
     unsigned short *parts = reinterpret_cast<unsigned short *>(smem_raw + kQSlabBytes); // [hashprint][wave]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kg = lane >> 4, cl = lane & 15;  // this lane's group of 16 k' inside a step; its column (B) / filter (A) in a tile
-    const int clip = blockIdx.y;
-    const int n0 = blockIdx.x * kQTileN;
+    // Workgroups go to the eight XCDs in turn (id mod 8), each with an L2 of its own: an XCD takes a contiguous run of
+    // (clip, tile) pairs with the tile fastest, so that the 99 columns two neighbouring tiles share, and the columns a
+    // tile reads twice (as c and as c + 80), come from HBM once: 2.34 -> MB per clip by the counters (1.17 algorithmic)
+    const unsigned per_xcd = (gridDim.x + 7) / 8;
+    const unsigned t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= (unsigned)(n_tiles_x * n_clips)) return;
+    const int clip = t / n_tiles_x;
+    const int n0 = (t - clip * n_tiles_x) * kQTileN;
     const float *S = sdb + (int64_t)clip * kBins * c;
     const float ref = FROM_T ? tmax[clip] : 0.0f;
     // the wave's filter digits of the first two steps are on their way while the slab is quantised
@@ -242,13 +248,14 @@ void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float 
     }
     const int nhp = c - (kCtx - 1) - kLag;
     if (nhp <= 0 || n_clips <= 0) return;
-    dim3 grid((nhp + kQTileN - 1) / kQTileN, n_clips);
+    const int tiles = (nhp + kQTileN - 1) / kQTileN;
+    const dim3 grid(8 * (unsigned)(((int64_t)tiles * n_clips + 7) / 8)); // one-dimensional, in XCD-aware order
     if (d_tmax)
         hipLaunchKernelGGL(hashprint_q_kernel<true>, grid, dim3(kQThreads), kQLdsBytes, s, static_cast<const v4i *>(d_fq_image), d_db, d_tmax,
-                           c, nhp, d_hp, d_dbg);
+                           c, nhp, tiles, n_clips, d_hp, d_dbg);
     else
         hipLaunchKernelGGL(hashprint_q_kernel<false>, grid, dim3(kQThreads), kQLdsBytes, s, static_cast<const v4i *>(d_fq_image), d_db, d_tmax,
-                           c, nhp, d_hp, d_dbg);
+                           c, nhp, tiles, n_clips, d_hp, d_dbg);
 }
 
 } // namespace hpfw

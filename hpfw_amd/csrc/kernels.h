@@ -44,7 +44,7 @@ struct ColsQArgs {
     const double *corr;  // [2 hq]: what the samples' +128 digit offset adds to every element of a row
     long long *stamps;   // diagnostic builds (-DHPFW_COLS_STAMPS) only: per workgroup 8 cycle sums
     int n_clips;         // set by the launch of the register-resident kernel: its grid is one-dimensional
-    int variant;         // diagnosis (HPFW_COLS_VARIANT at handle creation): 1 the LDS-staged kernel for every n1, 2 no global_load_lds
+    int variant;         // HPFW_COLS_VARIANT at handle creation (tests, diagnosis): 1 = the LDS-staged kernel for every n1
 };
 
 // Where the forward bins of one clip lie: in natural order from bin q0 on (n1 == 1: the chirp-z forward transform, the

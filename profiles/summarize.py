@@ -79,9 +79,18 @@ def main():
                               ("project_q_hbm_bytes_per_clip", ("hashprint_q_kernel<true", "hashprint_q_kernel", "project_q_kernel")),
                               ("fwd_cols_hbm_bytes_per_clip", ("fwd_cols_q3_kernel", "fwd_cols_q_kernel")),
                               ("fwd_rows_hbm_bytes_per_clip", ("fwd_rows2_kernel", "fwd_rows_kernel"))):
-            pk = next((v for k, v in sorted(pmc.items()) if any(k.startswith(px) for px in prefixes)), {})
+            # prefixes in order of preference; of the kernels one prefix matches, the launch of the largest grid (round 3 took
+            # the first key in sorted order, hashprint_q_kernel<false> -- 256-clip launches of the bench's side sections --
+            # and divided by 1000 clips: 0.60 MB per clip where the 1000-clip launches of <true> read 2.34 MB)
+            pk = {}
+            for px in prefixes:
+                cand = [v for k, v in pmc.items() if k.startswith(px) and "hbm_bytes_per_launch" in v]
+                if cand:
+                    pk = max(cand, key=lambda v: v.get("grid_work_items", 0))
+                    break
             if "hbm_bytes_per_launch" in pk:
                 traffic[key] = pk["hbm_bytes_per_launch"] / clips
+                traffic[key.replace("_hbm_bytes_per_clip", "_grid_work_items")] = pk.get("grid_work_items")
         if len(traffic) > 3:
             json.dump(traffic, open(os.path.join(here, "traffic.json"), "w"), indent=1)
     # ---- calibration of FETCH_SIZE / WRITE_SIZE on known byte counts (tools/fetch_calib.bin streams 1 GiB per kernel)

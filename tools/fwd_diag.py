@@ -72,9 +72,6 @@ CONFIGS = [
     ("v1 lds-staged, chunked 2 streams", {"HPFW_COLS_VARIANT": "1"}),
     ("v1 lds-staged, one launch", {"HPFW_COLS_VARIANT": "1", "HPFW_FWD_CHUNK": "0"}),
     ("v1 lds-staged, chunked 1 stream", {"HPFW_COLS_VARIANT": "1", "HPFW_FWD_STREAMS": "1"}),
-    ("v2 no-dma, chunked 2 streams", {"HPFW_COLS_VARIANT": "2"}),
-    ("v2 no-dma, one launch", {"HPFW_COLS_VARIANT": "2", "HPFW_FWD_CHUNK": "0"}),
-    ("v2 no-dma, chunked 1 stream", {"HPFW_COLS_VARIANT": "2", "HPFW_FWD_STREAMS": "1"}),
     ("default, chunked 1 stream", {"HPFW_FWD_STREAMS": "1"}),
     ("default, chunked 3 streams", {"HPFW_FWD_STREAMS": "3"}),
 ]

@@ -29,7 +29,6 @@ VARIANTS = [
     ("default", {}),
     ("no_side_streams", {"HPFW_FWD_CHUNK": "0", "HPFW_CQ_SERIAL": "1"}),
     ("cols_lds_staged", {"HPFW_COLS_VARIANT": "1"}),
-    ("cols_no_dma", {"HPFW_COLS_VARIANT": "2"}),
 ]
 if which == "default":
     VARIANTS = VARIANTS[:1]
