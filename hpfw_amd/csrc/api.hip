@@ -709,8 +709,8 @@ int ensure_side_streams(hpfw_gpu *h)
     return ok ? HPFW_OK : fail(HPFW_E_HIP, "side streams");
 }
 
-#if defined(HPFW_ROWS_SNAP)
-hpfw::cf *g_rows_snap = nullptr; // diagnosis builds: fft_rows.h HPFW_SNAP
+#if defined(HPFW_ROWS_SNAP) || defined(HPFW_ROWS_STAMPS)
+hpfw::cf *g_rows_snap = nullptr; // diagnosis builds: fft_rows.h HPFW_SNAP / HPFW_STAMP
 #endif
 
 // a1 + the forward transform for nb clips: PCM -> bins [kmin, kmax) in x
@@ -813,6 +813,9 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
         Timed t(h, K_ROWS, s);
 #if defined(HPFW_ROWS_SNAP)
         dp->rows.snap = g_rows_snap;
+#endif
+#if defined(HPFW_ROWS_STAMPS)
+        dp->rows.stamps = reinterpret_cast<long long *>(g_rows_snap);
 #endif
         hpfw::launch_fwd_rows2(dp->rows, dp->rows_out, (const float *)h->ws[0], nb, x, s); // -> x [n1][q2w]
     }
@@ -1234,7 +1237,7 @@ int hpfw_gpu_prepare_length(hpfw_gpu *h, int64_t n_samples)
     return ok ? 0 : fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n_samples) + ": " + why);
 }
 
-#if defined(HPFW_ROWS_SNAP)
+#if defined(HPFW_ROWS_SNAP) || defined(HPFW_ROWS_STAMPS)
 int hpfw_gpu_debug_set_rows_snap(void *d_snap)
 {
     g_rows_snap = static_cast<hpfw::cf *>(d_snap);

@@ -17,6 +17,10 @@ struct i16x2 { // two consecutive residues of one time step
     short x, y;
 };
 
+// entries per butterfly of a fused (R1, R2) group: stage 1 has (R1 - 1) R2, stage 2 has R2 - 1;
+// entry q2 (R1 - 1) + (s - 1) = T_n[ts1 (j0 + q2 m2) s], entry (R1 - 1) R2 + (s2 - 1) = T_n[ts2 j0 s2]
+constexpr int group_twiddle_count(int r1, int r2) { return (r1 - 1) * r2 + (r2 - 1); }
+
 struct RowGroups {
     int n;                    // number of fused groups
     int r1[kRowsMaxGroups];   // first radix of the group
@@ -39,9 +43,24 @@ struct RowGroups {
 #define HPFW_SNAP(lds, a, slot, n2v) ((void)0)
 #endif
 
+// diagnosis builds (-DHPFW_ROWS_STAMPS, tools/rows_stamps.py): s_memtime ticks wave 0 of every workgroup spends up to
+// each barrier of the row transform, RowsArgs::stamps [workgroup][8]
+#if defined(HPFW_ROWS_STAMPS) && !defined(HPFW_SIMT_EMU)
+#define HPFW_STAMP(a, k)                                                                                               \
+    do {                                                                                                               \
+        if ((a).stamps && threadIdx.x == 0)                                                                            \
+            (a).stamps[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memtime();      \
+    } while (0)
+#else
+#define HPFW_STAMP(a, k) ((void)0)
+#endif
+
 struct RowsArgs {
 #if defined(HPFW_ROWS_SNAP)
     cf *snap;
+#endif
+#if defined(HPFW_ROWS_STAMPS)
+    long long *stamps;
 #endif
     int n1, n2, h;            // N = n1 * n2, h = n2 / 2 + 1
     int hpad;                 // row stride (floats) of the planar output, a multiple of 32
@@ -53,15 +72,73 @@ struct RowsArgs {
     const int *kb_last;       // output k2 = kb_last[b] + (n2 / len) f of the last group's block b (see rows_last_*)
 };
 
-// entries per butterfly of a fused (R1, R2) group: stage 1 has (R1 - 1) R2, stage 2 has R2 - 1;
-// entry q2 (R1 - 1) + (s - 1) = T_n[ts1 (j0 + q2 m2) s], entry (R1 - 1) R2 + (s2 - 1) = T_n[ts2 j0 s2]
-constexpr int group_twiddle_count(int r1, int r2) { return (r1 - 1) * r2 + (r2 - 1); }
+// Where a fused group's per-butterfly twiddles come from.  TwAtUse: one load per entry where it is multiplied in -- what
+// the compiler makes of it under the register bound of three workgroups per CU is a load and a full wait per entry, ten
+// L2 round trips in a row for the (7, 3) group (tools/rows_stamps.py: that group took 39 % of a workgroup's time,
+// 3.4 times the (5, 3) group).  TwPairs<R1, R2>: all entry pairs of one butterfly fetched together (16 bytes each),
+// BEFORE the barrier in front of the group, so that they arrive while the workgroup waits there anyway.
+struct TwAtUse {
+    const cf *gt;
+    int nb, b;
+    HPFW_DEVICE_MEMBER cf operator()(int e) const { return tw_entry(gt, e, nb, b); }
+};
+template <int R1, int R2>
+struct TwPairs {
+    static constexpr int kPairs = (group_twiddle_count(R1, R2) + 1) / 2;
+    cf2 p[kPairs];
+    HPFW_DEVICE_MEMBER void fetch(const cf *__restrict__ gt, int nb, int b)
+    {
+#pragma unroll
+        for (int k = 0; k < kPairs; ++k) p[k] = reinterpret_cast<const cf2 *>(gt)[(unsigned)(k * nb + b)];
+    }
+    HPFW_DEVICE_MEMBER cf operator()(int e) const { return (e & 1) ? p[e >> 1].b : p[e >> 1].a; }
+};
 
 // one fused group of the forward DIF at sub-length len: radix R1, then radix R2 (or 1), in place
 // N2C, LENC: the transform length and the sub-length when the group sequence is fixed at compile time (0 = taken
 // from the arguments at run time): every LDS address is then the thread's base plus an immediate offset, no
 // address or 1 / m2 is computed or kept in registers, and the loop over butterflies disappears when the workgroup
 // holds at least one thread per butterfly.
+// the butterfly of one fused group on registers: in place when `out` is null, else to out[s R2 + s2] (the two-phase groups)
+template <int R1, int R2, class Lds, class Tw>
+HPFW_DEVICE void rows_butterfly(Lds &lds, int base, int m1, int m2, const Tw &tw, cf *out)
+{
+    cf e[R1][R2];
+#pragma unroll
+    for (int q2 = 0; q2 < R2; ++q2) {
+        cf u[R1];
+#pragma unroll
+        for (int q = 0; q < R1; ++q) u[q] = lds[base + q2 * m2 + q * m1];
+        Dft<R1>::run(u);
+        e[0][q2] = u[0];
+#pragma unroll
+        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw(q2 * (R1 - 1) + (s - 1)));
+    }
+#pragma unroll
+    for (int s = 0; s < R1; ++s) {
+        if constexpr (R2 > 1) {
+            cf v[R2];
+#pragma unroll
+            for (int q2 = 0; q2 < R2; ++q2) v[q2] = e[s][q2];
+            Dft<R2>::run(v);
+            if (out) {
+                out[s * R2] = v[0];
+#pragma unroll
+                for (int s2 = 1; s2 < R2; ++s2) out[s * R2 + s2] = c_mul(v[s2], tw((R1 - 1) * R2 + (s2 - 1)));
+            } else {
+                lds[base + s * m1] = v[0];
+#pragma unroll
+                for (int s2 = 1; s2 < R2; ++s2) lds[base + s * m1 + s2 * m2] = c_mul(v[s2], tw((R1 - 1) * R2 + (s2 - 1)));
+            }
+        } else {
+            if (out)
+                out[s] = e[s][0];
+            else
+                lds[base + s * m1] = e[s][0];
+        }
+    }
+}
+
 template <int R1, int R2, int N2C = 0, int LENC = 0, class Lds>
 HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ gt, int len_rt, int tid, int nthreads)
 {
@@ -80,35 +157,25 @@ HPFW_DEVICE void rows_group(Lds &lds, const RowsArgs &a, const cf *__restrict__ 
             if ((blk + 1) * m2 <= b) ++blk;
         }
         const int j0 = b - blk * m2;
-        const int base = blk * len + j0;
-        const int TWB = j0, TWN = m2; // the entries depend on j0 only: the table holds the m2 butterflies of one block
-        cf e[R1][R2];
-#pragma unroll
-        for (int q2 = 0; q2 < R2; ++q2) {
-            cf u[R1];
-#pragma unroll
-            for (int q = 0; q < R1; ++q) u[q] = lds[base + q2 * m2 + q * m1];
-            Dft<R1>::run(u);
-            e[0][q2] = u[0];
-#pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), TWN, TWB));
-        }
-#pragma unroll
-        for (int s = 0; s < R1; ++s) {
-            if constexpr (R2 > 1) {
-                cf v[R2];
-#pragma unroll
-                for (int q2 = 0; q2 < R2; ++q2) v[q2] = e[s][q2];
-                Dft<R2>::run(v);
-                lds[base + s * m1] = v[0];
-#pragma unroll
-                for (int s2 = 1; s2 < R2; ++s2)
-                    lds[base + s * m1 + s2 * m2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), TWN, TWB));
-            } else {
-                lds[base + s * m1] = e[s][0];
-            }
-        }
+        // the entries depend on j0 only: the table holds the m2 butterflies of one block
+        rows_butterfly<R1, R2>(lds, blk * len + j0, m1, m2, TwAtUse{gt, m2, j0}, static_cast<cf *>(nullptr));
     }
+}
+
+// butterfly `tid` of a compile-time group (one per thread), its twiddles fetched earlier; in place, or into out
+template <int R1, int R2, int N2, int LEN, class Lds>
+HPFW_DEVICE void rows_group_pre(Lds &lds, int tid, const TwPairs<R1, R2> &tw, cf *out)
+{
+    constexpr int m1 = LEN / R1, m2 = m1 / R2, nb = N2 / (R1 * R2);
+    if (tid >= nb) return;
+    const int blk = tid / m2, j0 = tid - blk * m2;
+    rows_butterfly<R1, R2>(lds, blk * LEN + j0, m1, m2, tw, out);
+}
+template <int R1, int R2, int N2, int LEN>
+HPFW_DEVICE void rows_group_fetch(const cf *__restrict__ gt, int tid, TwPairs<R1, R2> &tw)
+{
+    constexpr int m2 = LEN / (R1 * R2), nb = N2 / (R1 * R2);
+    if (tid < nb) tw.fetch(gt, m2, tid % m2);
 }
 
 // The group before the last, one butterfly per thread, in two halves around a barrier (its stores
@@ -125,33 +192,7 @@ HPFW_DEVICE void rows_pre_compute(Lds &lds, const RowsArgs &a, const cf *__restr
     const int nb = n / (R1 * R2);
     if (tid >= nb) return;
     const int blk = tid / m2, j0 = tid - blk * m2;
-    const int base = blk * len + j0;
-    const int TWB = j0, TWN = m2;
-    cf e[R1][R2];
-#pragma unroll
-    for (int q2 = 0; q2 < R2; ++q2) {
-        cf u[R1];
-#pragma unroll
-        for (int q = 0; q < R1; ++q) u[q] = lds[base + q2 * m2 + q * m1];
-        Dft<R1>::run(u);
-        e[0][q2] = u[0];
-#pragma unroll
-        for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), TWN, TWB));
-    }
-#pragma unroll
-    for (int s = 0; s < R1; ++s) {
-        if constexpr (R2 > 1) {
-            cf v[R2];
-#pragma unroll
-            for (int q2 = 0; q2 < R2; ++q2) v[q2] = e[s][q2];
-            Dft<R2>::run(v);
-            out[s * R2] = v[0];
-#pragma unroll
-            for (int s2 = 1; s2 < R2; ++s2) out[s * R2 + s2] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), TWN, TWB));
-        } else {
-            out[s] = e[s][0];
-        }
-    }
+    rows_butterfly<R1, R2>(lds, blk * len + j0, m1, m2, TwAtUse{gt, m2, j0}, out);
 }
 
 template <int R1, int R2, int N2C = 0, int LENC = 0, class Lds>
@@ -304,24 +345,66 @@ struct StaticGroups<R1, R2, Rest...> {
             HPFW_CARRY(cf, outv, R1 * R2, nthreads);
             HPFW_FOR_THREADS(tid, nthreads) { rows_last_compute<R1, R2, N2>(lds, a, gt, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
+            HPFW_STAMP(a, 5);
             HPFW_FOR_THREADS(tid, nthreads) { rows_last_store<R1, R2, N2>(lds, a, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
+            HPFW_STAMP(a, 6);
             HPFW_SNAP(lds, a, g + 1, N2);
         } else if constexpr (sizeof...(Rest) == 2) {
             HPFW_CARRY(cf, outv, R1 * R2, nthreads);
             HPFW_FOR_THREADS(tid, nthreads) { rows_pre_compute<R1, R2, N2, LEN>(lds, a, gt, LEN, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
+            HPFW_STAMP(a, 3);
             HPFW_FOR_THREADS(tid, nthreads) { rows_pre_store<R1, R2, N2, LEN>(lds, a, LEN, tid, HPFW_CARRY_AT(outv, R1 * R2, tid)); }
             HPFW_BARRIER();
+            HPFW_STAMP(a, 4);
             HPFW_SNAP(lds, a, g + 1, N2);
             StaticGroups<Rest...>::template run_from<N2, LEN / (R1 * R2)>(lds, a, nthreads, g + 1);
         } else {
             HPFW_FOR_THREADS(tid, nthreads) { rows_group<R1, R2, N2, LEN>(lds, a, gt, LEN, tid, nthreads); }
             HPFW_BARRIER();
+            HPFW_STAMP(a, 2);
             HPFW_SNAP(lds, a, g + 1, N2);
             StaticGroups<Rest...>::template run_from<N2, LEN / (R1 * R2)>(lds, a, nthreads, g + 1);
         }
     }
+#if !defined(HPFW_SIMT_EMU)
+    // The same sequence with every group's twiddles fetched before the barrier in front of it (one butterfly per thread
+    // throughout: the launcher checked min_threads).  `mine`: this group's, fetched by the caller.
+    using Pairs = TwPairs<R1, R2>;
+    template <int N2, int LEN>
+    HPFW_DEVICE_STATIC void fetch(const RowsArgs &a, int g, Pairs &mine)
+    {
+        if constexpr (sizeof...(Rest) != 0) rows_group_fetch<R1, R2, N2, LEN>(a.gtw + a.groups.tw_off[g], threadIdx.x, mine);
+    }
+    template <int N2, int LEN, class Lds>
+    HPFW_DEVICE_STATIC void run_fetched(Lds &lds, const RowsArgs &a, int g, const Pairs &mine)
+    {
+        const int tid = threadIdx.x;
+        if constexpr (sizeof...(Rest) == 0) {
+            run_from<N2, LEN>(lds, a, 0, g);          // (the last group's twiddles are the same for every butterfly: scalar loads)
+        } else if constexpr (sizeof...(Rest) == 2) {
+            cf outv[R1 * R2];
+            rows_group_pre<R1, R2, N2, LEN>(lds, tid, mine, outv);
+            HPFW_BARRIER();
+            HPFW_STAMP(a, 3);
+            rows_pre_store<R1, R2, N2, LEN>(lds, a, LEN, tid, outv);
+            HPFW_BARRIER();
+            HPFW_STAMP(a, 4);
+            HPFW_SNAP(lds, a, g + 1, N2);
+            StaticGroups<Rest...>::template run_from<N2, LEN / (R1 * R2)>(lds, a, 0, g + 1);
+        } else {
+            using Next = StaticGroups<Rest...>;
+            rows_group_pre<R1, R2, N2, LEN>(lds, tid, mine, static_cast<cf *>(nullptr));
+            typename Next::Pairs next;
+            Next::template fetch<N2, LEN / (R1 * R2)>(a, g + 1, next);
+            HPFW_BARRIER();
+            HPFW_STAMP(a, 2);
+            HPFW_SNAP(lds, a, g + 1, N2);
+            Next::template run_fetched<N2, LEN / (R1 * R2)>(lds, a, g + 1, next);
+        }
+    }
+#endif
     template <class Lds>
     HPFW_DEVICE_STATIC void run(Lds &lds, const RowsArgs &a, int nthreads)
     {
@@ -455,6 +538,7 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
                             cf *__restrict__ xclip)
 {
     const int n2 = Groups::kProduct ? Groups::kProduct : a.n2;
+    HPFW_STAMP(a, 0);
     HPFW_FOR_THREADS(tid, nthreads)
     {
         constexpr int kLd = 4; // loads in batches so that their latencies overlap
@@ -491,9 +575,23 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
             }
         }
     }
-    HPFW_BARRIER();
-    HPFW_SNAP(lds, a, 0, n2);
-    Groups::run(lds, a, nthreads);
+#if !defined(HPFW_SIMT_EMU)
+    if constexpr (Groups::kProduct != 0) {
+        // the compile-time sequence: the first group's twiddles are on their way while the workgroup meets at the barrier
+        typename Groups::Pairs tw0;
+        Groups::template fetch<Groups::kProduct, Groups::kProduct>(a, 0, tw0);
+        HPFW_BARRIER();
+        HPFW_STAMP(a, 1);
+        HPFW_SNAP(lds, a, 0, n2);
+        Groups::template run_fetched<Groups::kProduct, Groups::kProduct>(lds, a, 0, tw0);
+    } else
+#endif
+    {
+        HPFW_BARRIER();
+        HPFW_STAMP(a, 1);
+        HPFW_SNAP(lds, a, 0, n2);
+        Groups::run(lds, a, nthreads);
+    }
     const int *__restrict__ pos = a.pos_n2;
     constexpr bool kNat = Groups::kNatural;
     const bool mirror_row = q1 >= 1 && o.n1 - q1 >= o.hq; // row n1 - q1 is not computed itself
@@ -510,6 +608,7 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
             xclip[(int64_t)(mir ? o.n1 - q1 : q1) * o.q2w + j] = v;
         }
     }
+    HPFW_STAMP(a, 7);
 }
 
 } // namespace hpfw

@@ -538,6 +538,9 @@ extern "C" long long *hpfw_debug_cols_stamps() { return g_cols_stamps; }
 // one workgroup = one row q1 of one clip; the body (fft_rows.h) is shared with tests/emu.
 // 512 threads x 128 VGPRs and 50 KB of LDS: two workgroups per CU, every pass one butterfly per thread.
 constexpr int kFwdThreads = 512;
+#ifndef HPFW_ROWS_WAVES
+#define HPFW_ROWS_WAVES 6 // waves per SIMD the compile-time sequence is held to (6: three workgroups per CU)
+#endif
 
 template <class Groups, int WAVES>
 __global__ __launch_bounds__(kFwdThreads, WAVES) void fwd_rows2_kernel(RowsArgs a, Rows2Out o, const float *__restrict__ z,
@@ -624,7 +627,7 @@ void launch_fwd_rows2(const RowsArgs &a, const Rows2Out &o, const float *d_z, in
     // (68 registers under the bound of six waves per SIMD: three workgroups share a CU, as the 50 KB of LDS allow --
     // 2.30 -> 2.18 ms per 1000 clips against the 82 registers and two workgroups the compiler settles on by itself)
     if (Groups6300::matches_plan(a) && Groups6300::min_threads(a.n2) <= kFwdThreads)
-        launch_rows2_t<Groups6300, 6>(a, o, d_z, n_clips, d_x, s);
+        launch_rows2_t<Groups6300, HPFW_ROWS_WAVES>(a, o, d_z, n_clips, d_x, s);
     else
         launch_rows2_t<RuntimeGroups, 4>(a, o, d_z, n_clips, d_x, s);
 }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
     const int kg = lane >> 4, cl = lane & 15;  // this lane's group of 16 k' inside a step; its column (B) / filter (A) in a tile
     // Workgroups go to the eight XCDs in turn (id mod 8), each with an L2 of its own: an XCD takes a contiguous run of
     // (clip, tile) pairs with the tile fastest, so that the 99 columns two neighbouring tiles share, and the columns a
-    // tile reads twice (as c and as c + 80), come from HBM once: 2.34 -> MB per clip by the counters (1.17 algorithmic)
+    // tile reads twice (as c and as c + 80), come from HBM once: 2.34 -> 1.19 MB per clip by the counters (1.17 algorithmic; profiles/r04_pmc.json)
     const unsigned per_xcd = (gridDim.x + 7) / 8;
     const unsigned t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= (unsigned)(n_tiles_x * n_clips)) return;
