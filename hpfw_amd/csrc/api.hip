@@ -73,6 +73,7 @@ hpfw::RadixList to_radix(const std::vector<int> &r)
 // cost more than generating the tables).
 void *pool_take(hpfw_gpu *h, size_t bytes);
 void pool_give(hpfw_gpu *h, void *p, size_t bytes);
+void pool_release(hpfw_gpu *h);
 
 struct DevPlan {
     hpfw_gpu *owner = nullptr;
@@ -231,6 +232,12 @@ struct hpfw_gpu {
     // for the whole batch), HPFW_FWD_STREAMS (1..5) in the environment at creation
     int fwd_chunk = 16, fwd_streams = 2;
     int cols_variant = 0; // HPFW_COLS_VARIANT (tests, diagnosis): kernels.h ColsQArgs::variant
+    // HPFW_BACK_OVERLAP=1: the back end (hashprints from dB terms: the int8 matrix pipe) of one pass beside the front end
+    // (transforms: vector ALU, LDS) of the next, on a stream of its own.  Off by default: the kernels slow each other by
+    // what the overlap would gain (9.95-10.03 against 9.70-9.92 ms per 1000 clips on one box)
+    int back_overlap = 0;
+    hipStream_t back_side = nullptr;
+    hipEvent_t back_fork = nullptr, back_join = nullptr;
     int bz_chunk = 32;  // the same for the chirp-z forward transform's three kernels (HPFW_BZ_CHUNK; 38.6 -> 39.6 k clips/s at 30 s)
     void *d_topk_scratch = nullptr;
     size_t topk_scratch_cap = 0;
@@ -291,33 +298,50 @@ struct hpfw_gpu {
 
 namespace {
 
-int ensure(void **p, size_t *cap, size_t need)
+int ensure(void **p, size_t *cap, size_t need, hpfw_gpu *pool_owner = nullptr)
 {
     if (*cap >= need) return 0;
     if (*p) HIP_TRY(hipFree(*p));
     *p = nullptr;
     *cap = 0;
+    if (hipMalloc(p, need) != hipSuccess && pool_owner) { // the handle's pool of table blocks may be holding what is missing
+        (void)hipGetLastError();
+        pool_release(pool_owner);
+    } else if (*p) {
+        *cap = need;
+        return 0;
+    }
     HIP_TRY(hipMalloc(p, need));
     *cap = need;
     return 0;
 }
 
 
+// The pool: blocks of evicted plans and the temporaries of table generation, kept (up to 4 GiB, on top of the plan cache's
+// HPFW_PLAN_CACHE_GB) so that a corpus of distinct lengths does not pay a hipMalloc / hipFree -- a device-wide
+// synchronisation -- per file.  A request takes the smallest block that holds it with at most a quarter to spare (block
+// sizes of distinct lengths rarely recur exactly); whoever fails to allocate -- the pool itself, the workspaces -- gives the
+// whole pool back first.
+void pool_release(hpfw_gpu *h)
+{
+    for (auto &kv : h->dev_pool) (void)hipFree(kv.second);
+    h->dev_pool.clear();
+    h->dev_pool_bytes = 0;
+}
+
 void *pool_take(hpfw_gpu *h, size_t bytes)
 {
-    auto it = h->dev_pool.find(bytes);
-    if (it != h->dev_pool.end()) {
+    auto it = h->dev_pool.lower_bound(bytes);
+    if (it != h->dev_pool.end() && it->first <= bytes + bytes / 4) {
         void *p = it->second;
+        h->dev_pool_bytes -= it->first;      // (it comes back under the size asked for here: the label only ever shrinks)
         h->dev_pool.erase(it);
-        h->dev_pool_bytes -= bytes;
         return p;
     }
     void *d = nullptr;
-    if (hipMalloc(&d, bytes) != hipSuccess) { // the pool may be holding what is missing
-        for (auto &kv : h->dev_pool) (void)hipFree(kv.second);
-        h->dev_pool.clear();
-        h->dev_pool_bytes = 0;
+    if (hipMalloc(&d, bytes) != hipSuccess) {
         (void)hipGetLastError();
+        pool_release(h);
         if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
     }
     return d;
@@ -692,10 +716,10 @@ int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
                             (size_t)ns * 121 * hpfw::kCqMaxWaves * 4,
                             0, planar};
     for (int i = 0; i < 7; ++i) {
-        int rc = ensure(&h->ws[i], &h->ws_bytes[i], need[i]);
+        int rc = ensure(&h->ws[i], &h->ws_bytes[i], need[i], h);
         if (rc) return rc;
     }
-    return ensure((void **)&h->d_clipmax, &h->clipmax_cap, (size_t)ns * 4);
+    return ensure((void **)&h->d_clipmax, &h->clipmax_cap, (size_t)ns * 4, h);
 }
 
 // the side streams and their events (chirp-z classes side by side, chunks of the forward transform in turn)
@@ -926,6 +950,7 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     if (const char *e = std::getenv("HPFW_FWD_CHUNK")) h->fwd_chunk = std::max(0, atoi(e));
     if (const char *e = std::getenv("HPFW_BZ_CHUNK")) h->bz_chunk = std::max(0, atoi(e));
     if (const char *e = std::getenv("HPFW_COLS_VARIANT")) h->cols_variant = atoi(e);
+    if (const char *e = std::getenv("HPFW_BACK_OVERLAP")) h->back_overlap = atoi(e);
     if (const char *e = std::getenv("HPFW_FWD_STREAMS")) h->fwd_streams = std::min(hpfw_gpu::kCqSide + 1, std::max(1, atoi(e)));
     if (const char *e = std::getenv("HPFW_PROJECTION")) // "f32": handles start with the f32 fma chain (hpfw_gpu_set_projection(h, 0))
         h->projection = std::strcmp(e, "f32") == 0 ? 0 : 1;
@@ -975,6 +1000,9 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
         if (h->cq_join[k]) (void)hipEventDestroy(h->cq_join[k]);
     }
     if (h->cq_fork) (void)hipEventDestroy(h->cq_fork);
+    if (h->back_side) (void)hipStreamDestroy(h->back_side);
+    if (h->back_fork) (void)hipEventDestroy(h->back_fork);
+    if (h->back_join) (void)hipEventDestroy(h->back_join);
     if (h->stage_copy) (void)hipStreamDestroy(h->stage_copy);
     if (h->stage_comp) (void)hipStreamDestroy(h->stage_comp);
     if (h->d_cov_tiles) (void)hipFree(h->d_cov_tiles);
@@ -1099,6 +1127,9 @@ int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out)
     std::string why;
     if (!hpfw::build_plan(n_samples, hp, why, true, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions))
         return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n_samples) + ": " + why);
+    // what get_plan would refuse later is refused here (callers size their buffers from this answer)
+    if ((size_t)hp.n2 * sizeof(hpfw::cf) > 150 * 1024)
+        return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n_samples) + ": n2 exceeds the LDS");
     fill(hp);
     return 0;
 }
@@ -1146,15 +1177,37 @@ int hpfw_gpu_extract_pcm16(hpfw_gpu *h, const int16_t *d_pcm, int64_t n_samples,
     const int nbmax = pass_clips(h, dp, n_clips);
     const int nsmax = (int)std::min<int64_t>(std::max(kBackBatch, nbmax), std::max<int64_t>(n_clips, 1));
     if ((rc = ensure_ws(h, dp, nbmax, nsmax))) return rc;
+    // several passes and the fixed-point back end: the hashprints of pass i are computed on a stream of their own while the
+    // front end of pass i + 1 runs on the caller's (different pipes: matrix against vector ALU and LDS)
+    const bool overlap = h->back_overlap && h->projection && n_clips > nbmax;
+    if (overlap && !h->back_side) {
+        if (hipStreamCreateWithFlags(&h->back_side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->back_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->back_join, hipEventDisableTiming) != hipSuccess)
+            return fail(HPFW_E_HIP, "back-end stream");
+    }
     for (int64_t s0 = 0; s0 < n_clips; s0 += nsmax) {
         const int ns = (int)std::min<int64_t>(nsmax, n_clips - s0);
         for (int c0 = 0; c0 < ns; c0 += nbmax) {
             const int nb = std::min(nbmax, ns - c0);
             rc = run_front(h, dp, d_pcm + (s0 + c0) * n_samples, nb, c0, false, s);
             if (rc) return rc;
+            if (overlap) {
+                HIP_TRY(hipEventRecord(h->back_fork, s));
+                HIP_TRY(hipStreamWaitEvent(h->back_side, h->back_fork, 0));
+                Timed t(h, K_PROJECT, h->back_side);
+                hpfw::launch_hashprints_q(h->d_fq_image, (const float *)h->ws[2] + (size_t)c0 * 121 * dp->hp.c, h->d_clipmax + c0, nb, dp->hp.c,
+                                          d_hp + (s0 + c0) * dp->hp.n_hp, nullptr, h->back_side);
+                if ((rc = check_launch("project"))) return rc;
+            }
         }
-        rc = run_back(h, dp, ns, d_hp + s0 * dp->hp.n_hp, s);
-        if (rc) return rc;
+        if (overlap) { // the caller's stream (and the next batch's passes, which write the same slots) behind the last back end
+            HIP_TRY(hipEventRecord(h->back_join, h->back_side));
+            HIP_TRY(hipStreamWaitEvent(s, h->back_join, 0));
+        } else {
+            rc = run_back(h, dp, ns, d_hp + s0 * dp->hp.n_hp, s);
+            if (rc) return rc;
+        }
     }
     return 0;
 }

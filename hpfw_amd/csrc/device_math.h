@@ -27,6 +27,33 @@ HPFW_DEVICE cf tw_entry(const cf *__restrict__ gt, int e, int nb, int b)
     return (e & 1) ? p.b : p.a;
 }
 
+// entries per butterfly of a fused (R1, R2) group: stage 1 has (R1 - 1) R2, stage 2 has R2 - 1;
+// entry q2 (R1 - 1) + (s - 1) = T_n[ts1 (j0 + q2 m2) s], entry (R1 - 1) R2 + (s2 - 1) = T_n[ts2 j0 s2]
+constexpr int group_twiddle_count(int r1, int r2) { return (r1 - 1) * r2 + (r2 - 1); }
+
+
+// Where a fused group's per-butterfly twiddles come from.  TwAtUse: one load per entry where it is multiplied in -- what
+// the compiler makes of it under the register bound of three workgroups per CU is a load and a full wait per entry, ten
+// L2 round trips in a row for the (7, 3) group (tools/rows_stamps.py: that group took 39 % of a workgroup's time,
+// 3.4 times the (5, 3) group).  TwPairs<R1, R2>: all entry pairs of one butterfly fetched together (16 bytes each),
+// BEFORE the barrier in front of the group, so that they arrive while the workgroup waits there anyway.
+struct TwAtUse {
+    const cf *gt;
+    int nb, b;
+    HPFW_DEVICE_MEMBER cf operator()(int e) const { return tw_entry(gt, e, nb, b); }
+};
+template <int R1, int R2>
+struct TwPairs {
+    static constexpr int kPairs = (group_twiddle_count(R1, R2) + 1) / 2;
+    cf2 p[kPairs];
+    HPFW_DEVICE_MEMBER void fetch(const cf *__restrict__ gt, int nb, int b)
+    {
+#pragma unroll
+        for (int k = 0; k < kPairs; ++k) p[k] = reinterpret_cast<const cf2 *>(gt)[(unsigned)(k * nb + b)];
+    }
+    HPFW_DEVICE_MEMBER cf operator()(int e) const { return (e & 1) ? p[e >> 1].b : p[e >> 1].a; }
+};
+
 // The complex helpers.  Each is a fixed sequence of IEEE operations on scalar f32 instructions (the host-side emulation of
 // tests/emu compiles the same text).
 //

@@ -78,13 +78,13 @@ struct CqTwiddles {
 // PRUNE: only inputs with index < nz inside the first quarter can be non-zero (nz <= LEN / R1 and
 // LEN == N): a radix-R1 butterfly whose inputs 1..R1-1 are zero returns its input 0 on every
 // output, so those loads and adds are skipped and the zero padding is never read.
-template <int N, int LEN, int R1, int R2, bool PRUNE, class Lds>
-HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nthreads, int nz)
+// tw(e): entry e of THIS butterfly's twiddles -- TwAtUse (a load where it is used) or TwPairs (fetched before the barrier in
+// front of the group: device_math.h)
+template <int N, int LEN, int R1, int R2, bool PRUNE, class Lds, class Tw>
+HPFW_DEVICE void dif_butterfly(Lds &lds, int b, int nz, const Tw &tw)
 {
-    using P = Size<N>;
     constexpr int M1 = LEN / R1, M2 = M1 / R2;
-    constexpr int NB = P::N / (R1 * R2);
-    for (int b = tid; b < NB; b += nthreads) {
+    {
         const int blk = b / M2, j0 = b % M2;
         const int base = blk * LEN + j0;
         const PadAt<LEN, M1, M2, R2> at(base);
@@ -105,7 +105,7 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
             }
             e[0][q2] = u[0];
 #pragma unroll
-            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw_entry(gt, q2 * (R1 - 1) + (s - 1), M2, j0));
+            for (int s = 1; s < R1; ++s) e[s][q2] = c_mul(u[s], tw(q2 * (R1 - 1) + (s - 1)));
         }
 #pragma unroll
         for (int s = 0; s < R1; ++s) {
@@ -116,13 +116,19 @@ HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nth
                 Dft<R2>::run(v);
                 lds[at(0, s)] = v[0];
 #pragma unroll
-                for (int s2 = 1; s2 < R2; ++s2)
-                    lds[at(s2, s)] = c_mul(v[s2], tw_entry(gt, (R1 - 1) * R2 + (s2 - 1), M2, j0));
+                for (int s2 = 1; s2 < R2; ++s2) lds[at(s2, s)] = c_mul(v[s2], tw((R1 - 1) * R2 + (s2 - 1)));
             } else {
                 lds[at(0, s)] = e[s][0];
             }
         }
     }
+}
+
+template <int N, int LEN, int R1, int R2, bool PRUNE, class Lds>
+HPFW_DEVICE void dif_group(Lds &lds, const cf *__restrict__ gt, int tid, int nthreads, int nz)
+{
+    constexpr int M2 = LEN / (R1 * R2), NB = Size<N>::N / (R1 * R2);
+    for (int b = tid; b < NB; b += nthreads) dif_butterfly<N, LEN, R1, R2, PRUNE>(lds, b, nz, TwAtUse{gt, M2, b % M2});
 }
 
 // inverse butterfly of the specification: swap, forward codelet, swap.  For radix 2, 3 and 4 the same operations on the
@@ -180,13 +186,11 @@ HPFW_DEVICE void idft(cf *u)
 // ---- one fused group of the inverse DIT: radix R2 (or 1) at sub-length LEN / R1, then R1 ----
 // Same table as the forward group (the kernel conjugates).  Outputs with index >= keep are not
 // stored (only the first C samples of the last group are used).
-template <int N, int LEN, int R1, int R2, class Lds>
-HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nthreads, int keep)
+template <int N, int LEN, int R1, int R2, class Lds, class Tw>
+HPFW_DEVICE void idit_butterfly(Lds &lds, int b, int keep, const Tw &tw)
 {
-    using P = Size<N>;
     constexpr int M1 = LEN / R1, M2 = M1 / R2;
-    constexpr int NB = P::N / (R1 * R2);
-    for (int b = tid; b < NB; b += nthreads) {
+    {
         const int blk = b / M2, j0 = b % M2;
         const int base = blk * LEN + j0;
         const PadAt<LEN, M1, M2, R2> at(base);
@@ -197,7 +201,7 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
             v[0] = lds[at(0, q)];
 #pragma unroll
             for (int q2 = 1; q2 < R2; ++q2)
-                v[q2] = c_mulc(lds[at(q2, q)], tw_entry(gt, (R1 - 1) * R2 + (q2 - 1), M2, j0));
+                v[q2] = c_mulc(lds[at(q2, q)], tw((R1 - 1) * R2 + (q2 - 1)));
             if constexpr (R2 > 1) idft<R2>(v);
 #pragma unroll
             for (int s2 = 0; s2 < R2; ++s2) o[q][s2] = v[s2];
@@ -208,7 +212,7 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
             cf u[R1];
             u[0] = o[0][s2];
 #pragma unroll
-            for (int q = 1; q < R1; ++q) u[q] = c_mulc(o[q][s2], tw_entry(gt, s2 * (R1 - 1) + (q - 1), M2, j0));
+            for (int q = 1; q < R1; ++q) u[q] = c_mulc(o[q][s2], tw(s2 * (R1 - 1) + (q - 1)));
             idft<R1>(u);
 #pragma unroll
             for (int s = 0; s < R1; ++s) {
@@ -217,6 +221,13 @@ HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nt
             }
         }
     }
+}
+
+template <int N, int LEN, int R1, int R2, class Lds>
+HPFW_DEVICE void idit_group(Lds &lds, const cf *__restrict__ gt, int tid, int nthreads, int keep)
+{
+    constexpr int M2 = LEN / (R1 * R2), NB = Size<N>::N / (R1 * R2);
+    for (int b = tid; b < NB; b += nthreads) idit_butterfly<N, LEN, R1, R2>(lds, b, keep, TwAtUse{gt, M2, b % M2});
 }
 
 // ---- the innermost group of both transforms in one register pass:
@@ -332,6 +343,64 @@ HPFW_DEVICE void cq_transform(Lds &lds, const CqTwiddles &tw, int nthreads, int 
     }
 }
 
+#if !defined(HPFW_SIMT_EMU)
+// The same sequence with the twiddles of every outer group fetched BEFORE the barrier in front of it (one butterfly per
+// thread in those groups: N / 16 or N / 12 of them for cq_threads(N) threads): they arrive while the workgroup waits at
+// the barrier, where otherwise every group began with an L2 round trip.  `mine`: this level's pairs, fetched by the
+// caller for the way in; `outer`: the level above, whose pairs are fetched again in front of this level's last barrier,
+// for its way out.
+struct CqNoPairs {
+    HPFW_DEVICE_MEMBER void refetch() const {}
+};
+template <int R1, int R2>
+struct CqPairs : TwPairs<R1, R2> {
+    const cf *gt;
+    int nb, b; // b = tid mod nb: a valid butterfly of the table for every thread, so the fetch needs no guard (a guarded
+               // one would keep the old values alive through the inner levels)
+    HPFW_DEVICE_MEMBER void refetch() { this->fetch(gt, nb, b); }
+};
+
+template <int N, int LEN, int G, class Lds, class Mine, class Outer>
+HPFW_DEVICE void cq_transform_fetched(Lds &lds, const CqTwiddles &tw, int nthreads, int nz, int keep, const cf *__restrict__ vrev,
+                                      Mine &mine, Outer &outer)
+{
+    using GO = GroupOf<LEN>;
+    const int tid = threadIdx.x;
+    if constexpr (GO::REST == 1) {
+        mid_group<N, LEN, GO::R1, GO::R2>(lds, tw.tab + tw.mid_off, tid, nthreads, vrev);
+        outer.refetch();
+        HPFW_BARRIER();
+    } else {
+        constexpr int NB = Size<N>::N / (GO::R1 * GO::R2), M2 = LEN / (GO::R1 * GO::R2);
+        if (tid < NB) {
+            if (G == 0 && nz <= LEN / GO::R1)
+                dif_butterfly<N, LEN, GO::R1, GO::R2, true>(lds, tid, nz, mine);
+            else
+                dif_butterfly<N, LEN, GO::R1, GO::R2, false>(lds, tid, nz, mine);
+        }
+        using GN = GroupOf<GO::REST>;
+        if constexpr (GN::REST == 1) {       // the innermost group comes next: its twiddles are scalar loads
+            CqNoPairs none;
+            HPFW_BARRIER();
+            cq_transform_fetched<N, GO::REST, G + 1>(lds, tw, nthreads, nz, keep, vrev, none, mine);
+        } else {
+            constexpr int M2N = GO::REST / (GN::R1 * GN::R2);
+            CqPairs<GN::R1, GN::R2> next;
+            next.gt = tw.tab + tw.off[G + 1];
+            next.nb = M2N;
+            next.b = tid % M2N;
+            next.refetch();
+            HPFW_BARRIER();
+            cq_transform_fetched<N, GO::REST, G + 1>(lds, tw, nthreads, nz, keep, vrev, next, mine);
+        }
+        if (tid < NB) idit_butterfly<N, LEN, GO::R1, GO::R2>(lds, tid, G == 0 ? keep : N, mine);
+        outer.refetch();
+        HPFW_BARRIER();
+        (void)M2;
+    }
+}
+#endif
+
 // ---- the whole band: window*chirp, forward FFT, times V, inverse FFT, magnitudes ----
 // lds: Size<NP>::DATA complex slots; red: one float per thread (the largest value it stored).
 // xs.for_each(tid, nthreads, lg, g, f): f(i, X[start_j + i] g[i]) for every i < lg, in whatever order the layout of the
@@ -363,8 +432,25 @@ HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const Xs &xs, co
         if (!prune)
             for (int i = lg + tid; i < P::N; i += nthreads) lds[pad16(i)] = {0.0f, 0.0f};
     }
-    HPFW_BARRIER();
-    cq_transform<NP, NP, 0>(lds, tw, nthreads, lg, c, vrev);
+#if !defined(HPFW_SIMT_EMU)
+    if constexpr (GroupOf<NP>::REST != 1) {
+        using G0 = GroupOf<NP>;
+        constexpr int NB0 = NP / (G0::R1 * G0::R2), M20 = NP / (G0::R1 * G0::R2);
+        static_assert(NB0 <= 1024, "one butterfly per thread in the outer groups");
+        CqPairs<G0::R1, G0::R2> first;
+        first.gt = tw.tab + tw.off[0];
+        first.nb = M20;
+        first.b = (int)threadIdx.x % M20;
+        first.refetch();
+        CqNoPairs none;
+        HPFW_BARRIER();
+        cq_transform_fetched<NP, NP, 0>(lds, tw, nthreads, lg, c, vrev, first, none);
+    } else
+#endif
+    {
+        HPFW_BARRIER();
+        cq_transform<NP, NP, 0>(lds, tw, nthreads, lg, c, vrev);
+    }
     HPFW_FOR_THREADS(tid, nthreads)
     {
         float mx = fin(0.0f);

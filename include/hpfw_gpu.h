@@ -84,7 +84,9 @@ int hpfw_gpu_device(const hpfw_gpu *h); /* the device ordinal the handle was cre
 /* filters = ParallelCollector::filters (parallel_collector.h:77), host pointer, 64 x 2420 floats */
 int hpfw_gpu_set_filters(hpfw_gpu *h, const float *filters_colmajor);
 /* the sizes of a clip length (columns, frames, hashprints: cqt.h:66-73, hashprint_handle.h:79-93).  Host arithmetic only:
- * no table of the length is built or uploaded for the question */
+ * no table of the length is built or uploaded for the question; a length the extraction would refuse (a factor n2 beyond
+ * the LDS) is refused here with the same status.  Like every entry point but hpfw_gpu_prepare_length it belongs to the one
+ * host thread that drives the handle. */
 int hpfw_gpu_geometry(hpfw_gpu *h, int64_t n_samples, hpfw_geometry *out);
 
 /* essentia's NSGConstantQ is not vendored with hpfw and its version is not pinned (CMakeLists.txt:36), so four of

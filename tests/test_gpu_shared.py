@@ -112,7 +112,7 @@ def _run_pair(seconds, n_clips, reps, tmp_path):
     return res
 
 
-@pytest.mark.parametrize("seconds, n_clips, reps", [(5.0, 120, 60), (30.0, 128, 12)])
+@pytest.mark.parametrize("seconds, n_clips, reps", [(5.0, 120, 60), (30.0, 128, 40)])
 def test_two_processes_share_the_gpu(tmp_path, seconds, n_clips, reps):
     """Two processes extract on the SAME GPU at the same time (what a one-GPU rehearsal of the N = 2 bench does), started
     together: in every repetition the forward transform alone, the front end alone and the whole extraction equal the
@@ -124,4 +124,4 @@ def test_two_processes_share_the_gpu(tmp_path, seconds, n_clips, reps):
     for r in res:
         assert all(v == 0 for t in r["totals"].values() for v in t.values()), json.dumps(report, indent=1)
     # (the two did run side by side: each took a few seconds of repetitions after a common start)
-    assert min(r["elapsed_s"] for r in res) > 0.5, report
+    assert min(r["elapsed_s"] for r in res) > 0.3, report
