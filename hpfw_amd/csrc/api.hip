@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <chrono>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -102,6 +103,24 @@ struct DevPlan {
 
 constexpr size_t kPlanChunk = (size_t)4 << 20;
 
+// HPFW_PLAN_TIMING=1: where the first use of a clip length spends the host's time (printed when the handle goes)
+struct PlanTiming {
+    double host_wait = 0, host_build = 0, upload = 0, device_tables = 0, total = 0;
+    long plans = 0, copies = 0;
+    size_t copied = 0;
+};
+thread_local PlanTiming *g_plan_timing = nullptr;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct PlanTimer {
+    double *acc, t0;
+    explicit PlanTimer(double PlanTiming::*m) : acc(g_plan_timing ? &(g_plan_timing->*m) : nullptr), t0(acc ? now_s() : 0.0) {}
+    ~PlanTimer()
+    {
+        if (acc) *acc += now_s() - t0;
+    }
+};
+hipError_t plan_h2d(hpfw_gpu *h, void *dst, const void *src, size_t bytes); // (below: needs the handle)
+
 int plan_flush(DevPlan *dp)
 {
     size_t i = 0;
@@ -109,7 +128,7 @@ int plan_flush(DevPlan *dp)
         size_t off = dp->staged[i].first, end = off + dp->staged[i].second;
         // (a run = tables in adjacent 256-byte slots; a table the device fills itself, in between, ends the run)
         for (++i; i < dp->staged.size() && dp->staged[i].first == (end + 255) / 256 * 256; ++i) end = dp->staged[i].first + dp->staged[i].second;
-        HIP_TRY(hipMemcpy(dp->chunk_base + off, dp->stage.data() + off, end - off, hipMemcpyHostToDevice));
+        HIP_TRY(plan_h2d(dp->owner, dp->chunk_base + off, dp->stage.data() + off, end - off));
     }
     dp->staged.clear();
     return 0;
@@ -161,7 +180,7 @@ int upload(const std::vector<T> &v, const T **out, DevPlan *dp)
         std::memcpy(dp->stage.data() + off, v.data(), bytes);
         dp->staged.emplace_back(off, bytes);
     } else {
-        HIP_TRY(hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
+        HIP_TRY(plan_h2d(dp->owner, d, v.data(), bytes));
     }
     *out = reinterpret_cast<const T *>(d);
     return 0;
@@ -232,6 +251,14 @@ struct hpfw_gpu {
     // for the whole batch), HPFW_FWD_STREAMS (1..5) in the environment at creation
     int fwd_chunk = 16, fwd_streams = 2;
     int cols_variant = 0; // HPFW_COLS_VARIANT (tests, diagnosis): kernels.h ColsQArgs::variant
+    std::unique_ptr<PlanTiming> plan_timing; // HPFW_PLAN_TIMING
+    // The tables of a new clip length go to the device on a stream of the handle's own, from a pinned ring, without a host
+    // wait (the stream that first uses them waits for plan_ev): synchronous copies on the default stream waited behind
+    // whatever shared its hardware queue -- after bench.py's host-buffer section that was the collector's extraction stream,
+    // and a corpus of distinct lengths lost a fifth of its rate (tools/ffi_interaction.sh)
+    hipStream_t plan_stream = nullptr;
+    char *pin_ring = nullptr;
+    size_t pin_cap = 0, pin_off = 0;
     // HPFW_BACK_OVERLAP=1: the back end (hashprints from dB terms: the int8 matrix pipe) of one pass beside the front end
     // (transforms: vector ALU, LDS) of the next, on a stream of its own.  Off by default: the kernels slow each other by
     // what the overlap would gain (9.95-10.03 against 9.70-9.92 ms per 1000 clips on one box)
@@ -297,6 +324,38 @@ struct hpfw_gpu {
 };
 
 namespace {
+
+constexpr size_t kPinRing = (size_t)48 << 20;
+
+hipError_t plan_h2d(hpfw_gpu *h, void *dst, const void *src, size_t bytes)
+{
+    PlanTimer t(&PlanTiming::upload);
+    if (g_plan_timing) {
+        ++g_plan_timing->copies;
+        g_plan_timing->copied += bytes;
+    }
+    if (!h->pin_ring) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&h->pin_ring), kPinRing, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h->pin_ring = nullptr;
+        } else {
+            h->pin_cap = kPinRing;
+        }
+    }
+    if (!h->pin_ring || bytes > h->pin_cap / 2) { // (a table beyond the ring: the runtime stages it; rare -- clips of many minutes)
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->plan_stream);
+        return e != hipSuccess ? e : hipStreamSynchronize(h->plan_stream);
+    }
+    if (h->pin_off + bytes > h->pin_cap) { // wrap: what was copied out of the ring before has to be gone
+        hipError_t e = hipStreamSynchronize(h->plan_stream);
+        if (e != hipSuccess) return e;
+        h->pin_off = 0;
+    }
+    std::memcpy(h->pin_ring + h->pin_off, src, bytes);
+    hipError_t e = hipMemcpyAsync(dst, h->pin_ring + h->pin_off, bytes, hipMemcpyHostToDevice, h->plan_stream);
+    h->pin_off += (bytes + 255) / 256 * 256;
+    return e;
+}
 
 int ensure(void **p, size_t *cap, size_t need, hpfw_gpu *pool_owner = nullptr)
 {
@@ -426,11 +485,15 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         return 0;
     }
     g_uploaded = 0;
+    g_plan_timing = h->plan_timing.get();
+    PlanTimer whole(&PlanTiming::total);
+    if (g_plan_timing) ++g_plan_timing->plans;
     auto dp = std::make_unique<DevPlan>();
     dp->owner = h;
     std::string why;
     bool have_host = false;
     {
+        PlanTimer t(&PlanTiming::host_wait);
         // the host half may have been prepared (or be in preparation) by a reader thread: take it, or wait for it
         std::unique_lock<std::mutex> lock(h->host_mtx);
         auto ready = h->host_ready.find(n);
@@ -444,8 +507,11 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         h->host_seen.insert(n);
     }
     // HPFW_FORCE_BLUESTEIN=1 (tests): the chirp-z forward transform for 7-smooth lengths too
-    if (!have_host && !hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions))
-        return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n) + ": " + why);
+    if (!have_host) {
+        PlanTimer t(&PlanTiming::host_build);
+        if (!hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions))
+            return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n) + ": " + why);
+    }
     const hpfw::HostPlan &p = dp->hp;
     using hpfw::cf;
     int rc;
@@ -470,6 +536,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     hpfw::BzArgs &bz = dp->bz;
     std::memset(&bz, 0, sizeof(bz));
     if (p.bluestein) {
+        PlanTimer t_dev(&PlanTiming::device_tables);
         bz.n1 = p.n1;
         bz.n2 = p.n2;
         bz.n2pad = (p.n2 + 31) / 32 * 32;
@@ -505,7 +572,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         {
             void *d = tmp.take(p.tw_n1.size() * sizeof(cf));
             if (!d) return fail(HPFW_E_HIP, "out of device memory for the tables of a clip length");
-            HIP_TRY(hipMemcpy(d, p.tw_n1.data(), p.tw_n1.size() * sizeof(cf), hipMemcpyHostToDevice));
+            HIP_TRY(plan_h2d(h, d, p.tw_n1.data(), p.tw_n1.size() * sizeof(cf)));
             d_tw_n1 = static_cast<const cf *>(d);
         }
         {
@@ -519,8 +586,8 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
                 *slot[i] = static_cast<const float *>(d);
             }
             if ((rc = plan_flush(dp.get()))) return rc; // the row transform's tables are used by the kernels below
-            hpfw::launch_bz_pack_stages(bz, d_tw_n1, const_cast<float *>(bz.apack1), const_cast<float *>(bz.apack3), nullptr);
-            hpfw::launch_bz_pack_coefficients(p.n1, bz.k1lo, bz.k1n, d_tw_n1, bz.n_tiles2, const_cast<float *>(bz.apack2), nullptr);
+            hpfw::launch_bz_pack_stages(bz, d_tw_n1, const_cast<float *>(bz.apack1), const_cast<float *>(bz.apack3), h->plan_stream);
+            hpfw::launch_bz_pack_coefficients(p.n1, bz.k1lo, bz.k1n, d_tw_n1, bz.n_tiles2, const_cast<float *>(bz.apack2), h->plan_stream);
         }
         // chirp, T_L, w[k] / L and Bhat are generated on the device (k_bluestein.hip): a corpus of
         // real recordings brings a new length with every file
@@ -538,13 +605,11 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
         }
         void *scratch = tmp.take(big_l * 8 + plane); // back to the pool with T_n1 when this block ends, after the synchronisation below
         if (!scratch) return fail(HPFW_E_HIP, "out of device memory for the tables of a clip length");
-        hpfw::launch_bz_make_tables(ra, bz, n, static_cast<float *>(scratch), static_cast<float *>(scratch) + 2 * big_l, nullptr);
-        // (no host wait: the temporaries go back to the pool, whose next user is ordered after these kernels on the default
-        // stream like every table generation and upload; the stream that extracts waits for the event)
-        const hipError_t launched = hipGetLastError(), done = hipEventRecord(h->plan_ev, nullptr);
-        if (launched != hipSuccess || done != hipSuccess)
-            return fail(HPFW_E_HIP, std::string("chirp-z tables: ") + hipGetErrorString(launched != hipSuccess ? launched : done));
-        h->plan_ev_pending = true;
+        hpfw::launch_bz_make_tables(ra, bz, n, static_cast<float *>(scratch), static_cast<float *>(scratch) + 2 * big_l, h->plan_stream);
+        // (no host wait: the temporaries go back to the pool, whose next user is ordered after these kernels on the handle's
+        // table stream like every table generation and upload; the stream that extracts waits for the event recorded below)
+        const hipError_t launched = hipGetLastError();
+        if (launched != hipSuccess) return fail(HPFW_E_HIP, std::string("chirp-z tables: ") + hipGetErrorString(launched));
     }
     // S6 (7-smooth lengths): the column stage's twiddle digits, digit-offset correction and inter-stage twiddles
     hpfw::ColsQArgs &ca = dp->cols;
@@ -673,6 +738,9 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     }
     if ((rc = plan_flush(dp.get()))) return rc;
     std::vector<char>().swap(dp->stage);
+    // every table of the length is on its way on the table stream: whoever uses them first waits for this (Ordered)
+    HIP_TRY(hipEventRecord(h->plan_ev, h->plan_stream));
+    h->plan_ev_pending = true;
     h->plan_bytes += dp->bytes;
     *out = dp.get();
     h->plans[n] = std::move(dp);
@@ -950,13 +1018,15 @@ int hpfw_gpu_create(int device, hpfw_gpu **out)
     if (const char *e = std::getenv("HPFW_FWD_CHUNK")) h->fwd_chunk = std::max(0, atoi(e));
     if (const char *e = std::getenv("HPFW_BZ_CHUNK")) h->bz_chunk = std::max(0, atoi(e));
     if (const char *e = std::getenv("HPFW_COLS_VARIANT")) h->cols_variant = atoi(e);
+    if (std::getenv("HPFW_PLAN_TIMING")) h->plan_timing = std::make_unique<PlanTiming>();
     if (const char *e = std::getenv("HPFW_BACK_OVERLAP")) h->back_overlap = atoi(e);
     if (const char *e = std::getenv("HPFW_FWD_STREAMS")) h->fwd_streams = std::min(hpfw_gpu::kCqSide + 1, std::max(1, atoi(e)));
     if (const char *e = std::getenv("HPFW_PROJECTION")) // "f32": handles start with the f32 fma chain (hpfw_gpu_set_projection(h, 0))
         h->projection = std::strcmp(e, "f32") == 0 ? 0 : 1;
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->plan_ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->plan_ev, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->plan_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return fail(HPFW_E_HIP, "hipEventCreate failed");
     }
@@ -971,6 +1041,13 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->plan_timing && h->plan_timing->plans) {
+        const PlanTiming &t = *h->plan_timing;
+        std::fprintf(stderr, "hpfw plan timing: %ld lengths, %.1f ms in get_plan = %.3f ms each: wait for the host half %.3f, host build %.3f, "
+                             "uploads %.3f (%ld copies, %.2f MB per length), device tables (incl. their uploads) %.3f\n",
+                     t.plans, t.total * 1e3, t.total * 1e3 / t.plans, t.host_wait * 1e3 / t.plans, t.host_build * 1e3 / t.plans,
+                     t.upload * 1e3 / t.plans, t.copies, t.copied / 1e6 / t.plans, t.device_tables * 1e3 / t.plans);
+    }
     h->plans.clear();
     h->plan_bytes = 0;
     for (auto &kv : h->dev_pool) (void)hipFree(kv.second);
@@ -1026,6 +1103,8 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
         (void)hipEventDestroy(e.second);
     }
     if (h->plan_ev) (void)hipEventDestroy(h->plan_ev);
+    if (h->plan_stream) (void)hipStreamDestroy(h->plan_stream);
+    if (h->pin_ring) (void)hipHostFree(h->pin_ring);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->order_ev) (void)hipEventDestroy(h->order_ev);
@@ -1315,6 +1394,7 @@ int hpfw_gpu_chirpz_table(hpfw_gpu *h, int64_t n_samples, int which, float *out,
     int rc = get_plan(h, n_samples, &dp);
     if (rc) return rc;
     if (!dp->hp.bluestein) return fail(HPFW_E_INVALID, "clip length takes the mixed-radix transform: no chirp-z tables");
+    HIP_TRY(hipStreamSynchronize(h->plan_stream)); // the tables are generated on the handle's table stream
     const hpfw::BzArgs &bz = dp->bz;
     const void *tab[4] = {bz.wp, bz.tl, bz.bhat, bz.wk};
     if (which < 0 || which > 3) return fail(HPFW_E_INVALID, "table index out of range");
