@@ -666,8 +666,10 @@ def bench_ffi(torch, pcm, n_samples, filt, hp_dev, n_files):
         out["note"] = ("par_collector_calc_hashprints / par_collector_prepare through ctypes (hpfw_amd.ParallelCollector, the twin of "
                        "pyhpfw.py); prepare with HPFW_PREPARE_KEEP_FILTERS=1 (no learning), spectrogram cache written to tmpfs; "
                        "distinct lengths: every file a different sample count (chirp-z forward transform, tables per length); "
-                       "in the full run the distinct-length rates come out 15-20 % under this section run alone "
-                       "(--no-pcie: 1.9-2.2 k files/s); bisected to the pcie section before it, cause not found")
+                       "(until round 4 these rates came out 15-20 % lower behind the host-buffer section than alone: the tables of a "
+                       "new length were copied synchronously on the default stream, which waited behind the collector's extraction "
+                       "stream when the two shared a hardware queue; they now go on a stream of the handle's own from a pinned "
+                       "ring -- tools/ffi_interaction.sh)")
     finally:
         os.environ.pop("HPFW_PREPARE_KEEP_FILTERS", None)
         shutil.rmtree(d, ignore_errors=True)
