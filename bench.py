@@ -269,13 +269,13 @@ def main():
                          "v_mfma_i32_32x32x32_i8, exact; one rounding; sample digits in registers, twiddle digits by "
                          "global_load_lds)", cols_bytes, "fwd_cols_hbm_bytes_per_clip",
                          f"also {6 * 2 * 2 * hq * geo.n1 * geo.n2 / 1e9:.2f} G int8 operations per clip on the matrix pipe "
-                         "(38 % of its cycles busy: profiles/r03_sq.json); the twiddle digits (147 KB per 128 columns) come "
+                         "(34 % of its cycles busy: profiles/r04_sq.json); the twiddle digits (147 KB per 128 columns) come "
                          "from L2; the kernels of a step share one power budget -- a slower, cooler variant of this kernel "
                          "(2.9 ms) left the step time unchanged within 0.6 % (DESIGN.md section 9)")
     roof_rows = hbm_roof("fwd_rows", "fwd_rows2_kernel (per row: inter-stage twiddles, FFT_n2 in LDS, pruned stores)", rows_bytes,
                          "fwd_rows_hbm_bytes_per_clip",
-                         "not HBM-bound: three fused LDS passes per row with a barrier each, 61 % of wave-cycles parked "
-                         "(profiles/r03_sq.json); three workgroups per CU")
+                         "not HBM-bound: three fused LDS passes per row with a barrier each, 63 % of wave-cycles parked "
+                         "(profiles/r04_sq.json); three workgroups per CU; twiddles of every fused group fetched before the barrier in front of it")
     # the two stages of the forward transform run in chunks of a few clips on two streams (the
     # column stage's output stays in the Infinity Cache), so their launches overlap and the stage is timed as ONE span on
     # the caller's stream, like the chirp-z classes; the per-launch figures above are durations of launches that share the chip
@@ -367,8 +367,10 @@ def main():
                             "one_thread": {"clips_per_s": round(n_one / one_dt, 2), "clips": n_one,
                                            "ms_per_clip_by_stage": {k: round(v * 1e3 / n_one, 1) for k, v in st.items()}}}
         else:
-            idx = np.array(sorted(set([0, n_clips // 2, n_clips - 1])))
-            want = np.stack([plan.extract(filt, c) for c in pcm[idx].cpu().numpy()])
+            # (N > 1, or no CPU baseline asked for: 32 clips spread over the batch -- with several ranks on a box the kernels of
+            # one run beside the other's, which is where round 3's packed arithmetic went wrong)
+            idx = np.unique(np.linspace(0, n_clips - 1, min(32, n_clips)).astype(np.int64))
+            want = plan.extract_batch(filt, pcm[idx].cpu().numpy(), n_threads=max(1, (os.cpu_count() or 8) // max(world, 1)))
         parity = {"clips_checked": int(len(idx)), "bit_identical": bool(np.array_equal(got_all[idx], want)),
                   "hashprints_differing": int((got_all[idx] != want).sum())}
 

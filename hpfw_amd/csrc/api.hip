@@ -614,13 +614,16 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     // S6 (7-smooth lengths): the column stage's twiddle digits, digit-offset correction and inter-stage twiddles
     hpfw::ColsQArgs &ca = dp->cols;
     std::memset(&ca, 0, sizeof(ca));
-    dp->rows_out = hpfw::Rows2Out{p.n1, p.hq, p.q2lo, p.q2w, nullptr, nullptr, (p.n2 + 3) / 4};
+    dp->rows_out = hpfw::Rows2Out{p.n1, p.hq, p.q2lo, p.q2w, nullptr, nullptr, (p.n2 + 3) / 4, 5 /* kZBlock / 4 = 2^5 pieces */,
+                                  (long long)2 * p.hq * hpfw::kZBlock, hpfw::kZBlock, hpfw::z_floats_per_clip(p.hq, p.n2)};
+    static_assert(hpfw::kZBlock == 128, "Rows2Out::zshift4 above");
     if (!p.bluestein) {
         ca.n1 = p.n1;
         ca.n2 = p.n2;
         ca.hq = p.hq;
         ca.mt = p.cols_mt;
         ca.ks = p.cols_ks;
+        ca.zclip = hpfw::z_floats_per_clip(p.hq, p.n2);
         const int8_t *img = nullptr;
         if ((rc = upload(p.cols_image, &img, dp.get()))) return rc;
         ca.image = img;
@@ -756,7 +759,7 @@ int pass_clips(hpfw_gpu *h, const DevPlan *dp, int64_t n_clips)
     if (p.bluestein)
         per_clip += 2 * hpfw::bz_plane_bytes(dp->bz, 1) + (size_t)(p.kmax - p.kmin) * 8;
     else
-        per_clip += (size_t)p.hq * p.n2 * 8 + (size_t)p.n1 * p.q2w * 8;
+        per_clip += (size_t)hpfw::z_floats_per_clip(p.hq, p.n2) * 4 + (size_t)p.n1 * p.q2w * 8;
     size_t work = 0;
     for (const hpfw::CqClassDev &cd : dp->cls) work = std::max(work, hpfw::cq_big_work_bytes(cd, 1));
     per_clip += work;
@@ -778,7 +781,7 @@ int ensure_ws(hpfw_gpu *h, const DevPlan *dp, int nb, int ns)
     }
     const size_t planar = p.bluestein ? hpfw::bz_plane_bytes(dp->bz, nb) : 0;
     // ws[0]: the column stage's output z [hq][n2] (chirp-z path: a planar buffer); ws[1]: the forward bins (XsView layout)
-    const size_t need[7] = {p.bluestein ? planar : (size_t)nb * p.hq * p.n2 * 8,
+    const size_t need[7] = {p.bluestein ? planar : (size_t)nb * hpfw::z_floats_per_clip(p.hq, p.n2) * 4,
                             p.bluestein ? (size_t)nb * (p.kmax - p.kmin) * 8 : (size_t)nb * p.n1 * p.q2w * 8,
                             (size_t)ns * 121 * p.c * 4, (size_t)ns * 64 * (size_t)std::max(p.n_frames, 1) * 4, // (P: the f32-chain projection only)
                             (size_t)ns * 121 * hpfw::kCqMaxWaves * 4,
@@ -874,7 +877,7 @@ int run_forward(hpfw_gpu *h, DevPlan *dp, const int16_t *d_pcm, int nb, hpfw::cf
             for (int k = 0; k + 1 < lanes; ++k) HIP_TRY(hipStreamWaitEvent(h->cq_side[k], h->cq_fork, 0));
         }
         // a stream's chunks follow each other in order, so every stream has one region of z of its own
-        const int64_t region = (int64_t)h->fwd_chunk * dp->rows_out.hq * 2 * p.n2;
+        const int64_t region = (int64_t)h->fwd_chunk * dp->rows_out.zclip;
         int i = 0;
         for (int c0 = 0; c0 < nb; c0 += h->fwd_chunk, ++i) {
             const int nc = std::min(nb - c0, h->fwd_chunk);

@@ -344,6 +344,10 @@ HPFW_DEVICE void cq_transform(Lds &lds, const CqTwiddles &tw, int nthreads, int 
 }
 
 #if !defined(HPFW_SIMT_EMU)
+// (-DHPFW_CQ_PREFETCH; off: measured 2.5 % SLOWER than the loads where they are used -- eight runs on one box, the stage's
+// time over the hashprint kernel's of the same run 1.472 against 1.436 -- unlike the row stage, where the same change took a
+// quarter out of the first group: here the compiler already issues a group's loads together, other workgroups and
+// classes cover the wait, and the 16 more registers cost more than the L2 round trip.)
 // The same sequence with the twiddles of every outer group fetched BEFORE the barrier in front of it (one butterfly per
 // thread in those groups: N / 16 or N / 12 of them for cq_threads(N) threads): they arrive while the workgroup waits at
 // the barrier, where otherwise every group began with an L2 round trip.  `mine`: this level's pairs, fetched by the
@@ -432,7 +436,7 @@ HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const Xs &xs, co
         if (!prune)
             for (int i = lg + tid; i < P::N; i += nthreads) lds[pad16(i)] = {0.0f, 0.0f};
     }
-#if !defined(HPFW_SIMT_EMU)
+#if !defined(HPFW_SIMT_EMU) && defined(HPFW_CQ_PREFETCH)
     if constexpr (GroupOf<NP>::REST != 1) {
         using G0 = GroupOf<NP>;
         constexpr int NB0 = NP / (G0::R1 * G0::R2), M20 = NP / (G0::R1 * G0::R2);

@@ -500,15 +500,21 @@ struct Rows2Out {
     // [hq][4] steps T_N[q1 e]; element 4 m + e is seed (e = 0) or seed * step[e] (S1)
     const cf *seed, *step;
     int nq;
+    // where z lies (kernels.h ColsQArgs::zclip): blocks of 2^zshift4 four-column pieces, zpitch floats from block to block,
+    // zrow floats from a row's Re to its Im inside a block; the emulation passes one contiguous row (zshift4 = 30)
+    int zshift4;
+    long long zpitch;
+    int zrow;
+    long long zclip;
 };
 
 struct alignas(16) f4 {
     float x, y, z, w;
 };
 
-// zrow: the row's Re values, then its Im values (n2 floats each), the column stage's integers rounded to f32
+// zre: the row's Re values in the blocked layout of Rows2Out (its Im values o.zrow floats on), the column stage's integers rounded to f32
 template <class Groups, class Lds>
-HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const float *__restrict__ zrow, int q1, const Rows2Out &o,
+HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const float *__restrict__ zre, int q1, const Rows2Out &o,
                             cf *__restrict__ xclip)
 {
     const int n2 = Groups::kProduct ? Groups::kProduct : a.n2;
@@ -517,7 +523,10 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
     {
         constexpr int kLd = 4; // loads in batches so that their latencies overlap
         if ((n2 & 3) == 0) {   // both planes start 16-byte aligned: four elements per pair of loads
-            const f4 *__restrict__ sr = reinterpret_cast<const f4 *>(zrow), *__restrict__ si = reinterpret_cast<const f4 *>(zrow + n2);
+            const float *__restrict__ zim = zre + o.zrow;
+            const int bmask = (1 << o.zshift4) - 1;
+            // piece t (columns 4 t .. 4 t + 3) of the row: block t >> zshift4, piece t & bmask inside it
+            auto piece = [&](const float *row, int t) { return *reinterpret_cast<const f4 *>(row + (int64_t)(t >> o.zshift4) * o.zpitch + 4 * (t & bmask)); };
             const cf *__restrict__ seeds = o.seed + (int64_t)q1 * o.nq;
             const cf s1 = o.step[q1 * 4 + 1], s2 = o.step[q1 * 4 + 2], s3 = o.step[q1 * 4 + 3];
             const int nq = n2 / 4;
@@ -527,8 +536,8 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
 #pragma unroll
                 for (int e = 0; e < kLd; ++e) {
                     const int t = t0 + e * nthreads;
-                    vr[e] = sr[t < nq ? t : 0];
-                    vi[e] = si[t < nq ? t : 0];
+                    vr[e] = piece(zre, t < nq ? t : 0);
+                    vi[e] = piece(zim, t < nq ? t : 0);
                     w0[e] = seeds[t < nq ? t : 0];
                 }
 #pragma unroll
@@ -545,7 +554,8 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
         } else {
             for (int t = tid; t < n2; t += nthreads) {
                 const cf w0 = o.seed[(int64_t)q1 * o.nq + (t >> 2)];
-                lds[t] = c_mul(cf{zrow[t], zrow[n2 + t]}, (t & 3) ? c_mul(w0, o.step[q1 * 4 + (t & 3)]) : w0);
+                const int64_t at = (int64_t)(t >> (o.zshift4 + 2)) * o.zpitch + (t & ((4 << o.zshift4) - 1));
+                lds[t] = c_mul(cf{zre[at], zre[o.zrow + at]}, (t & 3) ? c_mul(w0, o.step[q1 * 4 + (t & 3)]) : w0);
             }
         }
     }

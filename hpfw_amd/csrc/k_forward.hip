@@ -277,7 +277,8 @@ __global__ __launch_bounds__(kCqThreads, 2) void fwd_cols_q_kernel(ColsQArgs a, 
         }
         CQ_STAMP(6);
         if (live) {
-            float *zrow = z + (((int64_t)clip * a.hq + q1) * 2 + (row & 1)) * a.n2;
+            // (blocked layout: this workgroup's column block, row `row`, kZBlock floats per row)
+            float *zrow = z + (int64_t)clip * a.zclip + ((int64_t)blockIdx.y * 2 * a.hq + row) * kZBlock - col0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = cbase + 8 * g;
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(kCqThreads, 2) void fwd_cols_q_kernel(ColsQArgs a, 
 // one of two buffers while the results of the previous tile are converted and stored: 43 KB + 8 KB per workgroup
 // and at most 168 registers, so three workgroups = twelve waves share a CU, one barrier (behind a full vmcnt(0)) per tile.
 constexpr int kCq3ScratchBytes = 2 * 2 * 32 * 16;                         // per wave: [plane][unit][slot][16 bytes]
-constexpr int cq3_lds_bytes(int waves) { return 2 * kCqABytes + waves * kCq3ScratchBytes; }
+constexpr int kCq3CorrRows = 256;                                         // row corrections of every tile (n1 <= 224: at most 226 rows), doubles
+constexpr int cq3_lds_bytes(int waves) { return 2 * kCqABytes + waves * kCq3ScratchBytes + kCq3CorrRows * 8; }
 
 __device__ __forceinline__ int cq3_w_addr(int c, int rq) { return (rq >> 2) * 512 + cq_slot(c) * 16 + 4 * (rq & 3); }
 
@@ -443,16 +445,23 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
     // the samples first (they come from HBM), the first tile's digits (from L2) behind them
     cq3_load_samples<LOADW>(a, clip_pcm, col0 + wave * 32, sc, lane, x, [&] { issue_a(0, 0); });
     CQ_STAMP(0);
-    const int cbase = col0 + wave * 32 + 4 * h;      // D: registers 4 g .. 4 g + 3 are columns cbase + 8 g + (0..3), tile column = lane & 31
-    const bool vec4 = (a.n2 & 3) == 0;
-    auto corr_of = [&](int mt) {
-        const int row = 32 * mt + nl, q1 = row >> 1;
-        return a.corr[2 * (q1 < a.hq ? q1 : a.hq - 1) + (row & 1)];
-    };
-    double corr = corr_of(0);
+    // D[tile row = output row][tile column = column]: the twiddle digits are the A operand and the samples the B operand,
+    // so a lane holds ONE column (col0 + 32 wave + (lane & 31)) and its register r the output row
+    // 32 mt + 8 (r >> 2) + (r & 3) + 4 h; a 4 x 4 exchange inside the quads of lanes then gives every lane four consecutive
+    // columns of one row, so that a store instruction writes eight whole 128-byte lines, 16 bytes per lane.  (Until round 4
+    // the operands were the other way round -- a lane held a row and wrote 16-byte pieces of it, 32 lines touched per
+    // instruction: the vector-memory path, not HBM, bound the kernel.)
+    const int c = col0 + wave * 32 + nl;
+    const bool c_in = c < a.n2;
+    const bool vec4 = (a.n2 & 3) == 0;               // rows of z then start 16-byte aligned and columns come in whole fours
+    // z [clip][column block cb][row = 2 q1 + (Re: 0, Im: 1)][kZBlock]: this workgroup's block, the wave's 32 columns of it
+    static_assert(32 * kCq3Waves == kZBlock, "a workgroup's columns are one block of z");
+    float *zblk = z + (int64_t)clip * a.zclip + (int64_t)cb * 2 * a.hq * kZBlock + wave * 32;
+    const int rows_live = 2 * a.hq;
+    // what the samples' +128 digit offset adds to every element of a row, for the rows of every tile: in LDS, 16 per lane and tile
+    double *corr_lds = reinterpret_cast<double *>(smem_raw + 2 * kCqABytes + kCq3Waves * kCq3ScratchBytes);
+    for (int i = tid; i < kCq3CorrRows; i += 64 * kCq3Waves) corr_lds[i] = a.corr[i < rows_live ? i : rows_live - 1];
     for (int mt = 0; mt < a.mt; ++mt) {
-        const int row = 32 * mt + nl, q1 = row >> 1;
-        const bool live = q1 < a.hq;
         // this wave's pieces of the tile's digits have landed; after the barrier everybody's have, and everybody is done
         // with the other buffer.  A full wait: loads and stores share the counter and are not guaranteed to retire in
         // order with respect to each other, so "at most four outstanding" (the previous tile's stores) would not prove
@@ -461,8 +470,6 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
         // this kernel's output was never wrong in any of the runs that localised it: tools/rows_error_shape.py.)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         CQ_STAMP(1);
-        double corr_next = 0.0;
-        if (mt + 1 < a.mt) corr_next = corr_of(mt + 1);   // here long before the next tile asks for it
         const v4i *wb = reinterpret_cast<const v4i *>(abytes + (mt & 1) * kCqABytes) + lane;
         v16i acc[4];
         const v16i zero = v16i{0};
@@ -470,12 +477,12 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
             // sample digit i (0 lo, 1 hi) times twiddle digit j goes to accumulator i + j; the first products of a tile
             // start from the instruction's zero operand instead of a cleared register
             const v4i w0 = wb[(s * 3 + 0) * 64], w1 = wb[(s * 3 + 1) * 64], w2 = wb[(s * 3 + 2) * 64];
-            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][0], w0, s == 0 ? zero : acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][0], w1, s == 0 ? zero : acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][0], w2, s == 0 ? zero : acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][1], w2, s == 0 ? zero : acc[3], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][1], w0, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(x[s][1], w1, acc[2], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, x[s][0], s == 0 ? zero : acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, x[s][0], s == 0 ? zero : acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w2, x[s][0], s == 0 ? zero : acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w2, x[s][1], s == 0 ? zero : acc[3], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, x[s][1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, x[s][1], acc[2], 0, 0, 0);
         };
         if (steps == kCqKSteps) {                // the usual case, straight through: the operand reads run ahead of the products
 #pragma unroll
@@ -486,39 +493,52 @@ __global__ __launch_bounds__(64 * kCq3Waves, 3) void fwd_cols_q3_kernel(ColsQArg
                 if (s < steps) step(s);
         }
         CQ_STAMP(2);
-        // the next tile's digits, on their way under the conversion and the stores below (corr_next is here by now: no
-        // wait for an ordinary load may follow while they are in flight, the compiler would make it a wait for everything)
-        asm volatile("" : "+v"(corr_next) : : "memory");
+        // the next tile's digits, on their way under the conversion and the stores (no wait for a vector-memory LOAD may
+        // follow while they are in flight -- the compiler would make it a wait for everything: the row corrections come from LDS)
         CQ_STAMP(3);
         if (mt + 1 < a.mt) issue_a(mt + 1, (mt + 1) & 1);
         asm volatile("" ::: "memory");
         CQ_STAMP(4);
-        // D[tile row = column][tile column = output row]: this lane holds output row `row`, register r = column
-        // cbase + 8 (r >> 2) + (r & 3).  G = sum_c acc_c 2^(8c) + corr: n1 <= 224, so the digit-product sums pair up
-        // in int32 (|.| < 2^31) and the rest is exact in double; rounded once.
-        float gm[16];
+        const int row0 = 32 * mt + 4 * h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lo = acc[0][r] + (acc[1][r] << 8), hi = acc[2][r] + (acc[3][r] << 8);
-            gm[r] = (float)(__builtin_fma((double)hi, 65536.0, (double)lo) + corr);
-        }
-        CQ_STAMP(5);
-        if (live) {
-            float *zrow = z + (((int64_t)clip * a.hq + q1) * 2 + (row & 1)) * a.n2;
+        for (int g = 0; g < 4; ++g) {
+            // G = sum_c acc_c 2^(8c) + corr: n1 <= 224, so the digit-product sums pair up in int32 (|.| < 2^31) and the rest
+            // is exact in double; rounded once.  Four rows (registers 4 g .. 4 g + 3) at a time: few live registers.
+            float q[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = cbase + 8 * g;
-                if (vec4 && c + 3 < a.n2) {
-                    *reinterpret_cast<float4 *>(zrow + c) = float4{gm[4 * g], gm[4 * g + 1], gm[4 * g + 2], gm[4 * g + 3]};
-                } else {
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const int lo = acc[0][r] + (acc[1][r] << 8), hi = acc[2][r] + (acc[3][r] << 8);
+                q[e] = (float)(__builtin_fma((double)hi, 65536.0, (double)lo) + corr_lds[row0 + 8 * g + e]);
+            }
+            if (vec4) {
+                // 4 x 4 transposition inside every quad of lanes (two exchange steps on the data-parallel-primitive path):
+                // lane 4 i + j then holds row 8 g + j (+ 4 h), columns 4 i .. 4 i + 3 of the wave's 32 -- one 16-byte store, and
+                // a store instruction covers eight whole 128-byte lines
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c + e < a.n2) zrow[c + e] = gm[4 * g + e];
+                for (int pr = 0; pr < 2; ++pr) {     // lanes differing in bit 0 exchange registers differing in bit 0
+                    const float send = (lane & 1) ? q[2 * pr] : q[2 * pr + 1];
+                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+                    if (lane & 1) q[2 * pr] = got; else q[2 * pr + 1] = got;
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {     // bit 1
+                    const float send = (lane & 2) ? q[pr] : q[pr + 2];
+                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
+                    if (lane & 2) q[pr] = got; else q[pr + 2] = got;
+                }
+                const int row = row0 + 8 * g + (nl & 3);
+                const int c4 = col0 + wave * 32 + (nl & ~3);
+                if (c4 < a.n2 && row < rows_live) *reinterpret_cast<float4 *>(zblk + row * kZBlock + (nl & ~3)) = float4{q[0], q[1], q[2], q[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = row0 + 8 * g + e;
+                    if (c_in && row < rows_live) zblk[row * kZBlock + nl] = q[e];
                 }
             }
         }
         CQ_STAMP(6);
-        corr = corr_next;
     }
 #ifdef HPFW_COLS_STAMPS
     if (a.stamps && tid == 0) {
@@ -550,7 +570,7 @@ __global__ __launch_bounds__(kFwdThreads, WAVES) void fwd_rows2_kernel(RowsArgs 
     // clip is the fast grid index: workgroups resident at the same time run the same row, whose butterfly twiddles
     // they share in L2
     const int clip = blockIdx.x, q1 = blockIdx.y;
-    rows2_body<Groups>(lds, a, kFwdThreads, z + ((int64_t)clip * o.hq + q1) * 2 * a.n2, q1, o, x + (int64_t)clip * o.n1 * o.q2w);
+    rows2_body<Groups>(lds, a, kFwdThreads, z + (int64_t)clip * o.zclip + (int64_t)2 * q1 * o.zrow, q1, o, x + (int64_t)clip * o.n1 * o.q2w);
 }
 
 __global__ __launch_bounds__(256) void gather_bins_kernel(CqPlanDev cp, const cf *__restrict__ x, cf *__restrict__ out)

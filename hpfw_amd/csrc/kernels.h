@@ -37,6 +37,9 @@ constexpr int kFrame = kBins * kCtx;
 // S6, the column stage of the forward transform on the int8 matrix cores (k_forward.hip): the clip as it lies is an
 // [n1][n2] sample matrix; rows q1 <= n1 / 2 of its length-n1 DFT down the columns, exact integers, rounded once to f32
 // (the row stage multiplies them by the twiddles between the stages on its way in).
+constexpr int kZBlock = 128;   // columns per block of the column stage's output (= columns per workgroup of both column kernels)
+inline long long z_floats_per_clip(int hq, int n2) { return (long long)((n2 + kZBlock - 1) / kZBlock) * 2 * hq * kZBlock; }
+
 struct ColsQArgs {
     int n1, n2, hq;      // hq = n1 / 2 + 1 rows
     int mt, ks;          // 32-row tiles of the (Re, Im) interleaved rows; 32-sample steps of k1
@@ -45,6 +48,8 @@ struct ColsQArgs {
     long long *stamps;   // diagnostic builds (-DHPFW_COLS_STAMPS) only: per workgroup 8 cycle sums
     int n_clips;         // set by the launch of the register-resident kernel: its grid is one-dimensional
     int variant;         // HPFW_COLS_VARIANT at handle creation (tests, diagnosis): 1 = the LDS-staged kernel for every n1
+    long long zclip;     // floats of z per clip: z is [clip][block of kZBlock columns][row 2 q1 + (Re: 0, Im: 1)][kZBlock] (round 4: a
+                         // workgroup's stores of a tile are then ONE contiguous 16 KB instead of 32 pieces 25 KB apart)
 };
 
 // Where the forward bins of one clip lie: in natural order from bin q0 on (n1 == 1: the chirp-z forward transform, the

@@ -66,7 +66,8 @@ int main(int argc, char **argv)
     a.pos_n2 = hp.pos_n2.data();
     a.kb_last = hp.kb_last.data();
     const hpfw::Rows2Out o{hp.n1, hp.hq, hp.q2lo, hp.q2w, reinterpret_cast<const cf *>(hp.ts_seed.data()),
-                           reinterpret_cast<const cf *>(hp.ts_step.data()), (hp.n2 + 3) / 4};
+                           reinterpret_cast<const cf *>(hp.ts_step.data()), (hp.n2 + 3) / 4,
+                           28 /* one contiguous row: every piece in block 0 */, 0, hp.n2 /* Im row n2 floats behind Re */, 0};
     std::vector<cf> x((size_t)hp.n1 * hp.q2w, cf{NAN, NAN});
     const size_t lds_n = (size_t)hp.n2;
     std::vector<float> z((size_t)2 * hp.n2); // Re row, Im row

@@ -49,6 +49,7 @@ plan = oracle.Plan(n)
 nk = plan.kmax - plan.kmin
 n1, n2 = plan.n1, plan.n2
 hq = n1 // 2 + 1
+zclip = (n2 + 127) // 128 * 2 * hq * 128   # floats of z per clip: [column block][row][128] (kernels.h kZBlock)
 want_x = np.stack([plan.spectrum(c) for c in clips[:16]])
 d = torch.from_numpy(clips).cuda()
 d_x = torch.zeros((n_clips, nk, 2), dtype=torch.float32, device="cuda")
@@ -59,7 +60,7 @@ torch.cuda.synchronize()
 x_ref = d_x.cpu().numpy().copy()
 assert np.array_equal(x_ref[:16].view(np.uint32), want_x.view(np.uint32)), "the reference run differs from the oracle"
 zp, zb = ref.debug_workspace(0)
-z_ref = fetch(zp, n_clips * hq * 2 * n2).reshape(n_clips, hq, 2, n2)
+z_ref = fetch(zp, n_clips * zclip).reshape(n_clips, -1, 2 * hq, 128)
 # is the reference itself stable?
 for _ in range(2):
     ref.stage_spectrum_dev(d.data_ptr(), n, n_clips, d_x.data_ptr())
@@ -97,14 +98,14 @@ for name, env in CONFIGS:
         # z as the call left it: every clip when launched whole, else the last chunk of each stream
         zp, zb = g.debug_workspace(0)
         if not chunked:
-            z = fetch(zp, n_clips * hq * 2 * n2).reshape(n_clips, hq, 2, n2)
+            z = fetch(zp, n_clips * zclip).reshape(n_clips, -1, 2 * hq, 128)
             pairs = [(c, z[c]) for c in range(n_clips)]
         else:
             n_chunks = (n_clips + 15) // 16
             pairs = []
             for lane in range(lanes):
                 last = max(i for i in range(n_chunks) if i % lanes == lane)
-                zl = fetch(zp + lane * 16 * hq * 2 * n2 * 4, 16 * hq * 2 * n2).reshape(16, hq, 2, n2)
+                zl = fetch(zp + lane * 16 * zclip * 4, 16 * zclip).reshape(16, -1, 2 * hq, 128)
                 pairs += [(16 * last + j, zl[j]) for j in range(min(16, n_clips - 16 * last))]
         for c, zc in pairs:
             nz = zc.view(np.uint32) != z_ref[c].view(np.uint32)

@@ -39,7 +39,7 @@ hip = ctypes.CDLL("libamdhip64.so")
 hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 hq = plan.n1 // 2 + 1
 def fetch_z():
-    out = np.empty((NC, hq, 2, plan.n2), np.float32)
+    out = np.empty((NC, (plan.n2 + 127) // 128, 2 * hq, 128), np.float32)   # [column block][row][128]: kernels.h kZBlock
     assert hip.hipMemcpy(out.ctypes.data, zp, out.nbytes, 2) == 0
     return out
 z_ref = fetch_z()
@@ -59,7 +59,7 @@ for rnd in range(30):
     ne = (x.view(np.uint32) != xr.view(np.uint32)).any(axis=2)
     for c in np.nonzero(ne.any(axis=1))[0]:
         rows = np.unique((np.nonzero(ne[c])[0] + plan.kmin) % plan.n1)
-        zrows = np.nonzero(zne[c].any(axis=(1, 2)))[0]
+        zrows = np.nonzero(zne[c].any(axis=(0, 2)))[0]          # rows 2 q1 + (Re: 0, Im: 1)
         print(f"round {rnd} clip {c}: {int(ne[c].sum())} bins, rows {rows.tolist()[:10]}, z rows differing {zrows.tolist()[:10]}", flush=True)
         if len(kept) < 14:
             kept[f"bad_{rnd}_{c}"] = x[c].copy()
