@@ -125,3 +125,64 @@ def test_two_processes_share_the_gpu(tmp_path, seconds, n_clips, reps):
         assert all(v == 0 for t in r["totals"].values() for v in t.values()), json.dumps(report, indent=1)
     # (the two did run side by side: each took a few seconds of repetitions after a common start)
     assert min(r["elapsed_s"] for r in res) > 0.3, report
+
+
+def test_search_and_other_paths_beside_the_int8_matrix_kernels(torch_cuda, oracle, filters):
+    """The rest of the library beside the same neighbour: the two matrix-core scans (32 queries at once, one query), the
+    chirp-z forward transform (a clip length with a prime factor above 7), the covariance of filter learning.  Each on one
+    stream while hashprint_q_kernel runs on another; every round equals the quiet run, and the quiet run the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    n_idx, n_hp = 2000, 2320
+    db = rng.integers(0, 2 ** 64, size=(n_idx, n_hp), dtype=np.uint64)
+    off = np.arange(n_idx + 1, dtype=np.int64) * n_hp
+    qs = [db[rng.integers(n_idx), 100:405].copy() for _ in range(32)]
+    for q in qs:
+        q[::7] ^= np.uint64(0x0F0F)
+    q_all = np.concatenate(qs)
+    q_off = np.arange(33, dtype=np.int64) * 305
+    vic, nb = hpfw_amd.Gpu(0), hpfw_amd.Gpu(0)
+    for g in (vic, nb):
+        g.set_filters(filters)
+    vic.index_add(db, off)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    d_q = torch.from_numpy(q_all.view(np.int64)).cuda()
+    hits32 = torch.zeros((32, 10, 4), dtype=torch.int32, device="cuda")
+    hits1 = torch.zeros((1, 10, 4), dtype=torch.int32, device="cuda")
+    # the neighbour's input: dB spectrograms of 64 thirty-second clips (any values in [-80, 0] do)
+    c = 2419
+    db_in = (-80.0 * torch.rand((64, 121, c), device="cuda")).contiguous()
+    hp_nb = torch.zeros((64, c - 99), dtype=torch.int64, device="cuda")
+    odd = np.stack([synth.gen_clip(900 + i, 5.0)[:220500 - 7] for i in range(24)])
+    plan_odd = oracle.Plan(odd.shape[1])
+    want_odd = plan_odd.extract_batch(filters, odd, n_threads=8)
+    d_odd = torch.from_numpy(odd).cuda()
+    hp_odd = torch.zeros((24, plan_odd.n_hp), dtype=torch.int64, device="cuda")
+
+    def run(beside):
+        out = []
+        for rnd in range(6 if beside else 1):
+            if beside:
+                nb.hashprints_from_db_dev(db_in.data_ptr(), 64, c, hp_nb.data_ptr(), sb.cuda_stream)
+            vic.search_topk_dev(d_q.data_ptr(), q_off, 10, hits32.data_ptr(), sa.cuda_stream)
+            vic.search_topk_dev(d_q.data_ptr(), q_off[:2], 10, hits1.data_ptr(), sa.cuda_stream)
+            if beside:
+                nb.hashprints_from_db_dev(db_in.data_ptr(), 64, c, hp_nb.data_ptr(), sb.cuda_stream)
+            vic.extract_dev(d_odd.data_ptr(), odd.shape[1], 24, hp_odd.data_ptr(), sa.cuda_stream)
+            if beside:
+                nb.hashprints_from_db_dev(db_in.data_ptr(), 64, c, hp_nb.data_ptr(), sb.cuda_stream)
+            vic.cov_reset()
+            vic.cov_accumulate_dev(d_odd.data_ptr(), odd.shape[1], 24, sa.cuda_stream)
+            torch.cuda.synchronize()
+            out.append((hits32.cpu().numpy().copy(), hits1.cpu().numpy().copy(), hp_odd.cpu().numpy().view(np.uint64).copy(), vic.cov_get()[0]))
+        return out
+
+    quiet = run(False)[0]
+    ref = oracle.search_topk(db.ravel(), off, q_all, q_off, 10)
+    assert np.array_equal(quiet[0].reshape(32, 10, 4).view(hpfw_amd.HIT_DTYPE).reshape(32, 10), ref)
+    assert np.array_equal(quiet[2], want_odd)
+    for rnd, got in enumerate(run(True)):
+        for name, a, b in zip(("scan of 32 queries", "scan of one query", "chirp-z forward extraction", "covariance"), got, quiet):
+            assert np.array_equal(a, b), f"round {rnd}: {name} differs from the quiet run"
+    vic.close()
+    nb.close()
