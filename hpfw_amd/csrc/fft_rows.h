@@ -544,10 +544,22 @@ HPFW_DEVICE void rows2_body(Lds &lds, const RowsArgs &a, int nthreads, const flo
                 for (int e = 0; e < kLd; ++e) {
                     const int t = t0 + e * nthreads;
                     if (t < nq) {
-                        lds[4 * t] = c_mul(cf{vr[e].x, vi[e].x}, w0[e]);
-                        lds[4 * t + 1] = c_mul(cf{vr[e].y, vi[e].y}, c_mul(w0[e], s1));
-                        lds[4 * t + 2] = c_mul(cf{vr[e].z, vi[e].z}, c_mul(w0[e], s2));
-                        lds[4 * t + 3] = c_mul(cf{vr[e].w, vi[e].w}, c_mul(w0[e], s3));
+                        const cf o0 = c_mul(cf{vr[e].x, vi[e].x}, w0[e]), o1 = c_mul(cf{vr[e].y, vi[e].y}, c_mul(w0[e], s1));
+                        const cf o2 = c_mul(cf{vr[e].z, vi[e].z}, c_mul(w0[e], s2)), o3 = c_mul(cf{vr[e].w, vi[e].w}, c_mul(w0[e], s3));
+#if defined(HPFW_SIMT_EMU)
+                        lds[4 * t] = o0;
+                        lds[4 * t + 1] = o1;
+                        lds[4 * t + 2] = o2;
+                        lds[4 * t + 3] = o3;
+#else
+                        // two 16-byte stores per lane, 32 bytes from lane to lane: a store instruction is served in groups of
+                        // eight lanes over 32 banks, and lanes l and l + 4 of a group would meet on the same banks -- so the
+                        // second four of every eight write their halves in the other order
+                        const bool sw = (tid >> 2) & 1;
+                        cf *at = &lds[4 * t];
+                        *reinterpret_cast<cf2 *>(at + (sw ? 2 : 0)) = sw ? cf2{o2, o3} : cf2{o0, o1};
+                        *reinterpret_cast<cf2 *>(at + (sw ? 0 : 2)) = sw ? cf2{o0, o1} : cf2{o2, o3};
+#endif
                     }
                 }
             }
