@@ -370,7 +370,9 @@ def main():
             # (N > 1, or no CPU baseline asked for: 32 clips spread over the batch -- with several ranks on a box the kernels of
             # one run beside the other's, which is where round 3's packed arithmetic went wrong)
             idx = np.unique(np.linspace(0, n_clips - 1, min(32, n_clips)).astype(np.int64))
-            want = plan.extract_batch(filt, pcm[idx].cpu().numpy(), n_threads=max(1, (os.cpu_count() or 8) // max(world, 1)))
+            from hpfw_amd import hostinfo
+            threads = max(1, hostinfo.cpu_budget()["usable"] // max(world, 1))   # (the cgroup's CPUs, not the machine's)
+            want = plan.extract_batch(filt, pcm[idx].cpu().numpy(), n_threads=threads)
         parity = {"clips_checked": int(len(idx)), "bit_identical": bool(np.array_equal(got_all[idx], want)),
                   "hashprints_differing": int((got_all[idx] != want).sum())}
 
