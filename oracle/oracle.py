@@ -126,7 +126,10 @@ class Plan:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().hpfw_oracle_plan_destroy(self._h)
+            try:                                   # (at interpreter exit the module's globals may be gone already)
+                lib().hpfw_oracle_plan_destroy(self._h)
+            except TypeError:
+                pass
             self._h = None
 
     def chirpz_table(self, which):

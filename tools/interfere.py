@@ -97,6 +97,24 @@ def a_hashq():
     hpfw_amd._lib.check(lib.hpfw_gpu_hashprints_from_db(agg._h, db_ref.data_ptr(), NC, plan.c, hp_b.data_ptr(), sb.cuda_stream))
 
 
+# two more LDS-fed matrix kernels of the library as neighbours: the fp4 scan and the f32 projection
+rng = np.random.default_rng(5)
+idx_hp = rng.integers(0, 2 ** 63, size=(4000, 2320), dtype=np.int64)
+agg.index_add(idx_hp.view(np.uint64), np.arange(4001, dtype=np.int64) * 2320)
+q_dev = torch.from_numpy(idx_hp[:32, 100:405].copy()).cuda()
+q_off = np.arange(33, dtype=np.int64) * 305
+hits_b = torch.zeros((32, 10, 4), dtype=torch.int32, device="cuda")
+proj_b = torch.zeros((NC, 64, plan.n_frames), dtype=torch.float32, device="cuda")
+
+
+def a_scan_fp4():
+    agg.search_topk_dev(q_dev.data_ptr(), q_off, 10, hits_b.data_ptr(), sb.cuda_stream)
+
+
+def a_project_f32():
+    agg.stage_project_dev(db_ref.data_ptr(), NC, plan.c, proj_b.data_ptr(), sb.cuda_stream)
+
+
 outs_x = [torch.zeros_like(x_ref) for _ in range(3)]
 outs_m = [torch.zeros_like(mag_ref) for _ in range(3)]
 outs_h = [torch.zeros_like(hp_ref) for _ in range(3)]
@@ -118,7 +136,8 @@ def v_hashq(i):
 
 
 AGG = [("none", a_none), ("hbm copy 1 GB", a_copy), ("bf16 matmul 8192^3", a_matmul), ("spectrum (q3 cols + rows)", a_spectrum),
-       ("spectrum (lds-staged cols + rows)", a_spectrum_v1), ("cqmag", a_cqmag), ("hashprint_q", a_hashq)]
+       ("spectrum (lds-staged cols + rows)", a_spectrum_v1), ("cqmag", a_cqmag), ("hashprint_q", a_hashq),
+       ("fp4 scan (hamming_mfma_kernel)", a_scan_fp4), ("f32 projection (project_kernel)", a_project_f32)]
 VIC = [("spectrum", v_spectrum), ("cqmag", v_cqmag), ("hashprint_q", v_hashq)]
 print("# lib", hpfw_amd._lib.LIB_PATH, file=sys.stderr)
 for vn, vf in VIC:
