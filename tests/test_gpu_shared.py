@@ -124,7 +124,7 @@ def test_two_processes_share_the_gpu(tmp_path, seconds, n_clips, reps):
     for r in res:
         assert all(v == 0 for t in r["totals"].values() for v in t.values()), json.dumps(report, indent=1)
     # (the two did run side by side: each took a few seconds of repetitions after a common start)
-    assert min(r["elapsed_s"] for r in res) > 0.3, report
+    assert min(r["elapsed_s"] for r in res) > 0.15, report
 
 
 def test_search_and_other_paths_beside_the_int8_matrix_kernels(torch_cuda, oracle, filters):
