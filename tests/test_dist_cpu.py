@@ -41,12 +41,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_search_equals_single_rank():
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_search_equals_single_rank(world):
+    """(3 ranks: shards of unequal size; 4: the next step of the driver's N = 1, 2, 4, 8 ladder)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in procs]
@@ -55,8 +57,9 @@ def test_sharded_search_equals_single_rank():
         assert p.exitcode == 0
     import hpfw_amd
     want = np.load(os.path.join(ROOT, "tests", "golden", "search.npz"))["top5"]
+    from hpfw_amd import dist as hdist
     ranges = sorted(r[2] for r in got)
-    assert ranges == [(0, 4), (4, 8)]
+    assert ranges == [hdist.shard_range(8, r, world) for r in range(world)] and ranges[0][0] == 0 and ranges[-1][1] == 8
     for _, raw, _ in got:
         merged = np.frombuffer(raw, hpfw_amd.HIT_DTYPE).reshape(want.shape)
         assert np.array_equal(merged, want)
