@@ -31,10 +31,11 @@ constexpr int cq_threads(int n)
 // DBT: store the dB term t(m^2) = (float)(10 log10(max(m^2, 1e-10))) of each magnitude instead of the
 // magnitude (extraction: the dB conversion then is S = max(t - t_max, -80) wherever S is read, and
 // no separate pass over the spectrogram is needed; the chirp-z has VALU slots to spare for it).
-// Registers: 98 VGPRs as compiled, which the allocation granule of 8 turns into four waves per SIMD; the classes of
-// at most 256 threads (one wave per SIMD and workgroup) are held to five waves = 96 VGPRs, which costs no scratch and
-// lets a fifth workgroup onto the CU where the LDS has room (P = 3072 and below).  Held to six -- 80 VGPRs, 44-84 bytes
-// of scratch -- the classes whose LDS footprint admits six measured slower, 4.0 against 3.85 ms per 1000 clips.
+// Registers (round 4, scalar complex arithmetic): 70-91 VGPRs as compiled, no scratch (8192: 73, 6144: 70, 12288: 76,
+// 4096: 91, 3072: 76) -- what holds the large classes to 3-4 waves per SIMD is their LDS (70-104 KB per workgroup), not
+// registers.  The classes of at most 128 threads (at most two waves per workgroup) are held to five waves = 96 VGPRs, which
+// costs no scratch and lets a fifth workgroup onto the CU where the LDS has room.  Held to six -- 80 VGPRs, 44-84 bytes of
+// scratch in round 3's build -- the classes whose LDS footprint admits six measured slower, 4.0 against 3.85 ms per 1000 clips.
 constexpr int cq_waves(int n) { return cq_threads(n) <= 128 ? 5 : 1; }
 
 template <int NP, bool DBT>
