@@ -262,7 +262,8 @@ class Gpu:
         return p.value or 0, b.value
 
     def chirpz_table(self, n_samples, which):
-        """device-generated table of the chirp-z forward transform as complex64 (0 w, 1 T_L, 2 Bhat, 3 w[k] / L)"""
+        """device-generated table as complex64: 0 w, 1 T_L, 2 Bhat, 3 w[k] / L of the chirp-z forward transform; 4 (every
+        length) the constant-Q stage's windows, bands concatenated"""
         count = ctypes.c_int64(0)
         check(lib().hpfw_gpu_chirpz_table(self._h, n_samples, which, None, 0, ctypes.byref(count)))
         out = np.zeros(count.value, np.float32)

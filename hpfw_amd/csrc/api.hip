@@ -105,7 +105,7 @@ constexpr size_t kPlanChunk = (size_t)4 << 20;
 
 // HPFW_PLAN_TIMING=1: where the first use of a clip length spends the host's time (printed when the handle goes)
 struct PlanTiming {
-    double host_wait = 0, host_build = 0, upload = 0, device_tables = 0, total = 0;
+    double host_wait = 0, host_build = 0, upload = 0, device_tables = 0, alloc = 0, evict = 0, total = 0;
     long plans = 0, copies = 0;
     size_t copied = 0;
 };
@@ -136,6 +136,7 @@ int plan_flush(DevPlan *dp)
 
 int plan_alloc(DevPlan *dp, size_t bytes, void **out)
 {
+    PlanTimer t(&PlanTiming::alloc);
     bytes = (bytes + 255) / 256 * 256;
     if (bytes >= kPlanChunk / 4) { // a block of its own, in 64 KB steps (equal sizes recur: lengths near each other share n1 and n2)
         const size_t size = (bytes + 65535) / 65536 * 65536;
@@ -509,7 +510,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     // HPFW_FORCE_BLUESTEIN=1 (tests): the chirp-z forward transform for 7-smooth lengths too
     if (!have_host) {
         PlanTimer t(&PlanTiming::host_build);
-        if (!hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions))
+        if (!hpfw::build_plan(n, dp->hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions, false))
             return fail(HPFW_E_UNSUPPORTED, "clip length " + std::to_string(n) + ": " + why);
     }
     const hpfw::HostPlan &p = dp->hp;
@@ -652,7 +653,14 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     if ((rc = upload(start, &c.start, dp.get()))) return rc;
     if ((rc = upload(lg, &c.lg, dp.get()))) return rc;
     if ((rc = upload(p.g_off, &c.g_off, dp.get()))) return rc;
-    if ((rc = upload(p.g, reinterpret_cast<const hpfw::HostCf **>(&c.g), dp.get()))) return rc;
+    // the window table itself is generated on the device, behind the uploads (below): S5, k_cq_tables.hip
+    {
+        void *d = nullptr;
+        if ((rc = plan_alloc(dp.get(), (size_t)std::max<int64_t>(p.g_total, 1) * sizeof(cf), &d))) return rc;
+        g_uploaded += (size_t)p.g_total * sizeof(cf);
+        c.g = static_cast<const cf *>(d);
+    }
+    int g2_max_entries = 0;
     c.g2 = nullptr;
     c.g2_off = nullptr;
     c.q2a = c.nq2 = nullptr;
@@ -670,14 +678,13 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
             g2_off[j] = total;
             total += (int64_t)p.n1 * nq2[j];
         }
-        std::vector<hpfw::HostCf> g2((size_t)total, hpfw::HostCf{0.0f, 0.0f});
-        for (int j = 0; j < 121; ++j)
-            for (int q1 = 0; q1 < p.n1; ++q1)
-                for (int tq = 0; tq < nq2[j]; ++tq) {
-                    const int64_t i = q1 + (int64_t)p.n1 * (q2a[j] + tq) - p.start[j];
-                    if (i >= 0 && i < p.lg[j]) g2[(size_t)(g2_off[j] + (int64_t)q1 * nq2[j] + tq)] = p.g[(size_t)(p.g_off[j] + i)];
-                }
-        if ((rc = upload(g2, reinterpret_cast<const hpfw::HostCf **>(&c.g2), dp.get()))) return rc;
+        for (int j = 0; j < 121; ++j) g2_max_entries = std::max(g2_max_entries, p.n1 * nq2[j]);
+        {
+            void *d = nullptr;
+            if ((rc = plan_alloc(dp.get(), (size_t)std::max<int64_t>(total, 1) * sizeof(cf), &d))) return rc;
+            g_uploaded += (size_t)total * sizeof(cf);
+            c.g2 = static_cast<const cf *>(d);
+        }
         if ((rc = upload(g2_off, &c.g2_off, dp.get()))) return rc;
         if ((rc = upload(q2a, &c.q2a, dp.get()))) return rc;
         if ((rc = upload(nq2, &c.nq2, dp.get()))) return rc;
@@ -722,6 +729,7 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     size_t budget = (size_t)16 << 30;
     if (const char *e = std::getenv("HPFW_PLAN_CACHE_GB")) budget = (size_t)(std::max(0.0, std::atof(e)) * 1073741824.0);
     if (h->plan_bytes + dp->bytes > budget && !h->plans.empty()) {
+        PlanTimer t(&PlanTiming::evict);
         (void)hipDeviceSynchronize();
         // room for a quarter of the budget at once: every round of evictions costs this synchronisation, and a corpus of
         // distinct lengths larger than the cache would otherwise pay it with every file
@@ -741,6 +749,21 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     }
     if ((rc = plan_flush(dp.get()))) return rc;
     std::vector<char>().swap(dp->stage);
+    // the constant-Q windows, generated behind the uploads of the band tables they read (S5, k_cq_tables.hip)
+    {
+        PlanTimer t(&PlanTiming::device_tables);
+        hpfw::CqWindowBands wb;
+        int lg_max = 0;
+        for (int j = 0; j < 121; ++j) {
+            wb.scale[j] = hpfw::cq_window_scale(h->conventions, p.big_m, p.psize[j]);
+            wb.hann_den[j] = (int)hpfw::cq_hann_den(h->conventions, p.lg[j]);
+            lg_max = std::max(lg_max, p.lg[j]);
+        }
+        hpfw::launch_cq_windows(c, wb, p.big_m, lg_max, const_cast<cf *>(c.g), h->plan_stream);
+        if (c.g2) hpfw::launch_cq_windows_rows(c, p.n1, g2_max_entries, const_cast<cf *>(c.g2), h->plan_stream);
+        const hipError_t launched = hipGetLastError();
+        if (launched != hipSuccess) return fail(HPFW_E_HIP, std::string("constant-Q window tables: ") + hipGetErrorString(launched));
+    }
     // every table of the length is on its way on the table stream: whoever uses them first waits for this (Ordered)
     HIP_TRY(hipEventRecord(h->plan_ev, h->plan_stream));
     h->plan_ev_pending = true;
@@ -1047,9 +1070,11 @@ void hpfw_gpu_destroy(hpfw_gpu *h)
     if (h->plan_timing && h->plan_timing->plans) {
         const PlanTiming &t = *h->plan_timing;
         std::fprintf(stderr, "hpfw plan timing: %ld lengths, %.1f ms in get_plan = %.3f ms each: wait for the host half %.3f, host build %.3f, "
-                             "uploads %.3f (%ld copies, %.2f MB per length), device tables (incl. their uploads) %.3f\n",
+                             "uploads %.3f (%ld copies, %.2f MB per length), device tables (incl. their uploads) %.3f, device memory %.3f, "
+                             "evictions %.3f\n",
                      t.plans, t.total * 1e3, t.total * 1e3 / t.plans, t.host_wait * 1e3 / t.plans, t.host_build * 1e3 / t.plans,
-                     t.upload * 1e3 / t.plans, t.copies, t.copied / 1e6 / t.plans, t.device_tables * 1e3 / t.plans);
+                     t.upload * 1e3 / t.plans, t.copies, t.copied / 1e6 / t.plans, t.device_tables * 1e3 / t.plans, t.alloc * 1e3 / t.plans,
+                     t.evict * 1e3 / t.plans);
     }
     h->plans.clear();
     h->plan_bytes = 0;
@@ -1360,7 +1385,7 @@ int hpfw_gpu_prepare_length(hpfw_gpu *h, int64_t n_samples)
     bool ok;
     {
         hpfw::PlanSerial serial;
-        ok = hpfw::build_plan(n_samples, *hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions);
+        ok = hpfw::build_plan(n_samples, *hp, why, false, std::getenv("HPFW_FORCE_BLUESTEIN") != nullptr, h->conventions, false);
     }
     if (!ok) *hp = hpfw::HostPlan(); // n = 0: get_plan builds it again and reports why
     {
@@ -1396,8 +1421,15 @@ int hpfw_gpu_chirpz_table(hpfw_gpu *h, int64_t n_samples, int which, float *out,
     DevPlan *dp;
     int rc = get_plan(h, n_samples, &dp);
     if (rc) return rc;
-    if (!dp->hp.bluestein) return fail(HPFW_E_INVALID, "clip length takes the mixed-radix transform: no chirp-z tables");
     HIP_TRY(hipStreamSynchronize(h->plan_stream)); // the tables are generated on the handle's table stream
+    if (which == 4) { // the constant-Q stage's windows (every length): bands concatenated
+        *count = 2 * dp->hp.g_total;
+        if (!out) return 0;
+        if (capacity < *count) return fail(HPFW_E_INVALID, "table buffer too small");
+        HIP_TRY(hipMemcpy(out, dp->cq.g, (size_t)*count * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (!dp->hp.bluestein) return fail(HPFW_E_INVALID, "clip length takes the mixed-radix transform: no chirp-z tables");
     const hpfw::BzArgs &bz = dp->bz;
     const void *tab[4] = {bz.wp, bz.tl, bz.bhat, bz.wk};
     if (which < 0 || which > 3) return fail(HPFW_E_INVALID, "table index out of range");

@@ -149,6 +149,16 @@ struct CqPlanDev {
     int rows_min;          // bands whose slice holds fewer than this many bins per row are walked element by element
 };
 
+// per-band constants of the window table (S5; plan.h cq_window_scale / cq_hann_den), by value into cq_window_kernel
+struct CqWindowBands {
+    double scale[121];
+    int hann_den[121];
+};
+// the window table g [sum lg] and its rows-layout twin g2 (7-smooth lengths) generated on the device; c.lg, c.g_off (and
+// c.start, c.q2a, c.nq2, c.g2_off, c.g for the twin) must be in place on the stream
+void launch_cq_windows(const CqPlanDev &c, const CqWindowBands &b, int64_t big_m, int lg_max, cf *d_g, hipStream_t s);
+void launch_cq_windows_rows(const CqPlanDev &c, int n1, int max_entries, cf *d_g2, hipStream_t s);
+
 // S6 column stage: pcm [n_clips][n1][n2] (clips `clip_samples` apart) -> z [n_clips][hq][Re row, Im row][n2]
 void launch_fwd_cols_q(const ColsQArgs &a, const int16_t *d_pcm, int64_t clip_samples, int n_clips, float *d_z, hipStream_t s);
 // S6 row stage: z -> x [n_clips][n1][q2w] (XsView layout)

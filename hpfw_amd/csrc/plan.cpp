@@ -8,6 +8,7 @@
 // posit_j = floor(f_j / fftres), Lg_j = max(round(bw_j / fftres), 96), M = max_j Lg_j.
 // hpfw keeps ceil(M / 3) columns (cqt.h:73-81).
 #include "plan.h"
+#include "trig_d.h"
 
 #include <algorithm>
 #include <atomic>
@@ -73,13 +74,16 @@ std::vector<HostCf> twiddle_table(int64_t n)
     return t;
 }
 
-// e^{+i pi 3 m^2 / M}: phase reduced exactly in integers before the double evaluation
+// e^{+i pi 3 m^2 / M} = conj(e^{-2 pi i r / 2M}), r = 3 m^2 mod 2M reduced exactly in integers, by S2b (trig_d.h): the same
+// bits as the device's generation of the window table (k_cq_tables.hip) and as the oracle
 void chirp_d(int64_t m, int64_t big_m, double &c, double &s)
 {
     const int64_t mm = m < 0 ? -m : m;
     const int64_t r = (int64_t)(((__int128)3 * mm * mm) % (2 * big_m));
-    const double ang = M_PI * (double)r / (double)big_m;
-    sincos(ang, &s, &c);
+    double re, im;
+    unit_d(r, 2 * big_m, re, im);
+    c = re;
+    s = -im;
 }
 
 // S5: iterative radix-2 decimation-in-time FFT in double, twiddles from twiddle_d, butterfly
@@ -276,7 +280,7 @@ static void parallel_rows(int64_t n, F fn)
 PlanSerial::PlanSerial() : before(g_plan_serial) { g_plan_serial = true; }
 PlanSerial::~PlanSerial() { g_plan_serial = before; }
 
-bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bool force_bluestein, unsigned conv)
+bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bool force_bluestein, unsigned conv, bool host_windows)
 {
     if (n < 2) {
         why = "clip too short";
@@ -571,25 +575,19 @@ bool build_plan(int64_t n, HostPlan &p, std::string &why, bool geometry_only, bo
         why = "internal: too many fused groups";
         return false;
     }
-    // G_j[i] = hann_Lg[i] e^{+i pi 3 i^2 / M} / (M P)
+    // G_j[i] = hann_Lg[i] e^{+i pi 3 i^2 / M} / (M P): S5, trig_d.h cq_window_d -- the product generates this table on the
+    // device (k_cq_tables.hip: a corpus of tracks brings a new length with every file, and the table was most of a length's
+    // host cost and of its upload); the host builds it for the emulation of tests/emu and for the table checksums only
+    p.g_total = goff;
+    p.big_m = big_m;
+    if (!host_windows) return true;
     p.g.resize((size_t)goff);
-    // the chirp factor of index i is the same in every band: evaluated once per i (a quarter of a million sincos less per
-    // length -- a corpus of tracks brings a new length with every file, and this table was most of a length's host cost)
-    int64_t lg_max = 0;
-    for (int j = 0; j < kBins; ++j) lg_max = std::max<int64_t>(lg_max, p.lg[j]);
-    std::vector<double> chirp_c((size_t)lg_max), chirp_s((size_t)lg_max);
-    parallel_rows((lg_max + 1023) / 1024, [&](int64_t blk) {
-        for (int64_t i = 1024 * blk; i < std::min<int64_t>(lg_max, 1024 * (blk + 1)); ++i) chirp_d(i, big_m, chirp_c[(size_t)i], chirp_s[(size_t)i]);
-    });
     parallel_rows(kBins, [&](int64_t j) {
         const int64_t lg = p.lg[j];
-        const double scale = 1.0 / (((conv & kConvNoIfftScale) ? 1.0 : (double)big_m) * (double)p.psize[j]);
-        const double hann_den = (conv & kConvHannPeriodic) ? (double)lg : (double)(lg - 1);
+        const double scale = cq_window_scale(conv, big_m, p.psize[j]);
+        const int64_t hann_den = cq_hann_den(conv, lg);
         HostCf *gj = p.g.data() + p.g_off[(size_t)j];
-        for (int64_t i = 0; i < lg; ++i) {
-            const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * (double)i / hann_den);
-            gj[i] = {(float)(w * chirp_c[(size_t)i] * scale), (float)(w * chirp_s[(size_t)i] * scale)};
-        }
+        for (int64_t i = 0; i < lg; ++i) cq_window_d(i, hann_den, big_m, scale, gj[i].r, gj[i].i);
     });
     return true;
 }

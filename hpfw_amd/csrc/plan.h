@@ -53,7 +53,8 @@ struct HostPlan {
     std::vector<int> kb_last;               // last group's block b holds outputs kb_last[b] + (n2 / len) f
     int start[121], lg[121], psize[121];
     std::vector<int64_t> g_off;             // [121]
-    std::vector<HostCf> g;                  // window * chirp / (M P), concatenated
+    int64_t g_total = 0, big_m = 0;         // sum of lg; M (the longest band: every band's output length)
+    std::vector<HostCf> g;                  // window * chirp / (M P), concatenated (empty when the device generates it)
     std::vector<BluesteinClass> classes;
     // clip lengths with a prime factor above 7: the forward DFT as a chirp-z (Bluestein) convolution of
     // length bz_l = n1 * n2 >= N + (kmax - kmin) - 1, n2 = 6300; n1 need not be smooth
@@ -82,8 +83,15 @@ struct PlanSerial {
     bool before;
 };
 // force_bluestein: take the chirp-z forward transform even when the length is 7-smooth (tests)
+// host_windows: build the constant-Q window table g on the host too (the product generates it on the device)
 bool build_plan(int64_t n_samples, HostPlan &out, std::string &why, bool geometry_only = false,
-                bool force_bluestein = false, unsigned conventions = 0);
+                bool force_bluestein = false, unsigned conventions = 0, bool host_windows = true);
+// the two per-band constants of the window table (S5): shared by plan.cpp and the device generator's launch
+inline double cq_window_scale(unsigned conventions, int64_t big_m, int psize)
+{
+    return 1.0 / (((conventions & kConvNoIfftScale) ? 1.0 : (double)big_m) * (double)psize);
+}
+inline int64_t cq_hann_den(unsigned conventions, int64_t lg) { return (conventions & kConvHannPeriodic) ? lg : lg - 1; }
 
 // the row transform alone for frames of n2 samples (STFT of the Mel front-end): radix, groups, rows_gtw,
 // pos_n2 of `out`, and tw_big = two rows of ones

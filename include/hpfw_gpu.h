@@ -312,7 +312,9 @@ int hpfw_gpu_prepare_length(hpfw_gpu *h, int64_t n_samples);
 /* ---- diagnostic: the tables of the chirp-z forward transform (clip lengths with a prime factor above 7), which are
  * generated on the device.  which: 0 = chirp w [n1][n2], 1 = T_L [n1][n2], 2 = Bhat [n1][n2],
  * 3 = w[k] / L [kmax - kmin]; complex as (re, im) float pairs.  *count = floats in the table; out may be NULL to
- * ask for the count only.  HPFW_E_INVALID for a 7-smooth length (unless HPFW_FORCE_BLUESTEIN is set). */
+ * ask for the count only.  HPFW_E_INVALID for a 7-smooth length (unless HPFW_FORCE_BLUESTEIN is set).
+ * which = 4, for EVERY length: the constant-Q stage's window table (121 bands concatenated, sum of Lg values), which is
+ * generated on the device too (reference cqt.h:54-61: essentia builds these windows per file). */
 int hpfw_gpu_chirpz_table(hpfw_gpu *h, int64_t n_samples, int which, float *out, int64_t capacity, int64_t *count);
 
 /* ---- diagnostic: the handle's extraction workspaces as the last call left them (device pointers; valid until the next

@@ -454,13 +454,19 @@ static int64_t chirpz_length(int64_t need)
     return p3 < p2 ? p3 : p2;
 }
 
+static void bz_unit(int64_t m, int64_t n, double *re, double *im); /* S2b, below */
+
+/* e^{+i pi 3 m^2 / M} = conj(e^{-2 pi i r / 2M}), r = 3 m^2 mod 2M reduced exactly in integers; S2b (own cosine / sine on
+ * the reduced octant) so that the product can generate the constant-Q tables on the device with the same bits
+ * (csrc/trig_d.h; until round 4: glibc's sincos of pi r / M) */
 static void chirp_d(int64_t m, int64_t big_m, double *c, double *s)
 {
-    /* e^{+i pi 3 m^2 / M}; the phase is reduced exactly in integers first */
     int64_t mm = m < 0 ? -m : m;
     int64_t r = (int64_t)(((__int128)3 * mm * mm) % (2 * big_m));
-    double ang = M_PI * (double)r / (double)big_m;
-    sincos(ang, s, c);
+    double re, im;
+    bz_unit(r, 2 * big_m, &re, &im);
+    *c = re;
+    *s = -im;
 }
 
 static int make_bluestein(hpfw_oracle_plan *p)
@@ -505,9 +511,11 @@ static int make_bluestein(hpfw_oracle_plan *p)
         int64_t lg = p->lg[j];
         p->g[j] = (cf *)malloc(sizeof(cf) * (size_t)lg);
         double scale = 1.0 / (((p->conv & HPFW_O_CONV_NO_IFFT_SCALE) ? 1.0 : (double)big_m) * (double)ps);
-        double hann_den = (p->conv & HPFW_O_CONV_HANN_PERIODIC) ? (double)lg : (double)(lg - 1);
+        int64_t hann_den = (p->conv & HPFW_O_CONV_HANN_PERIODIC) ? lg : lg - 1;
         for (int64_t i = 0; i < lg; ++i) {
-            double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / hann_den);
+            double hc, hs; /* cos(2 pi i / den) by S2b (csrc/trig_d.h cq_window_d) */
+            bz_unit(i % hann_den, hann_den, &hc, &hs);
+            double w = 0.5 - 0.5 * hc;
             double cc, ss;
             chirp_d(i, big_m, &cc, &ss);
             p->g[j][i].r = (float)(w * cc * scale);
@@ -1587,8 +1595,17 @@ static uint64_t fnv1a(const void *data, size_t bytes, uint64_t h)
 
 /* the chirp-z tables (0 w, 1 T_L, 2 Bhat: [n1][n2]; 3 w[k] / L: [kmax - kmin]) as (re, im) floats; returns the
  * number of floats, 0 for a plan without them; out may be NULL */
+/* which = 4 (every plan): the constant-Q stage's windows G_j, bands concatenated (S5: sum of lg values) */
 int64_t hpfw_oracle_chirpz_table(const hpfw_oracle_plan *p, int which, float *out)
 {
+    if (which == 4) {
+        int64_t count = 0;
+        for (int j = 0; j < HPFW_O_BINS; ++j) {
+            if (out) memcpy(out + count, p->g[j], sizeof(cf) * (size_t)p->lg[j]);
+            count += 2 * (int64_t)p->lg[j];
+        }
+        return count;
+    }
     if (!p->bluestein || which < 0 || which > 3) return 0;
     const cf *tab[4] = {p->bz_w, p->bz_tl, p->bz_bhat, p->bz_wk};
     int64_t count = 2 * (which == 3 ? p->info.kmax - p->info.kmin : p->bz_l);

@@ -133,7 +133,8 @@ class Plan:
             self._h = None
 
     def chirpz_table(self, which):
-        """S15 table of a chirp-z plan as complex64: 0 w, 1 T_L, 2 Bhat ([n1 * n2]), 3 w[k] / L ([kmax - kmin])"""
+        """S15 table of a chirp-z plan as complex64: 0 w, 1 T_L, 2 Bhat ([n1 * n2]), 3 w[k] / L ([kmax - kmin]); 4 (every
+        plan): the constant-Q stage's windows G_j, bands concatenated (S5)"""
         count = lib().hpfw_oracle_chirpz_table(self._h, which, None)
         if count == 0:
             raise ValueError("no chirp-z tables: the length takes the mixed-radix transform")

@@ -534,6 +534,18 @@ def test_chirpz_tables_generated_on_device(gpu, oracle, n):
         gpu.chirpz_table(132300, 0)                               # a 7-smooth length has none
 
 
+@pytest.mark.parametrize("n", [1323000, 1323001, 220500, 99991, 54254])
+def test_constant_q_windows_generated_on_device(gpu, oracle, n):
+    """S5: the window table of a clip length -- 121 bands of hann_Lg[i] e^{+i pi 3 i^2 / M} / (M P) -- is generated on the
+    device (k_cq_tables.hip; double arithmetic with the own cosine / sine of S2b, csrc/trig_d.h), for 7-smooth lengths and
+    the others alike: identical to the oracle's table, bit for bit.  (hpfw_gpu_plan_checksum_ex, tests/test_library.py,
+    pins the host's restatement of the same text to the oracle without a GPU.)"""
+    got, want = gpu.chirpz_table(n, 4), oracle.Plan(n).chirpz_table(4)
+    assert got.shape == want.shape
+    bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
+    assert bad.size == 0, (bad.size, bad[:5], got[bad[:5]], want[bad[:5]])
+
+
 def test_three_minute_clip_of_a_non_smooth_length(gpu, torch_cuda, oracle, filters):
     """3 minutes + 1 sample (n1 = 1392: six row tiles of the two-stage column transform; constant-Q classes above the
     LDS, k_cq_big.hip): the device-generated tables, the forward bins and the hashprints, bit for bit"""
