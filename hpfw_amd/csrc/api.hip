@@ -212,6 +212,10 @@ struct hpfw_gpu {
     std::set<int64_t> host_seen; // lengths being prepared, prepared, or resident on the device (not prepared again while they are)
     size_t plan_bytes = 0;
     uint64_t plan_clock = 0;
+    // plans last used at or before this value of plan_clock are known to be idle: the caller has waited for all the work it
+    // queued on this handle since (hpfw_internal_note_idle: the file collectors, once per window of files) -- such plans
+    // are evicted without the device-wide wait that an eviction otherwise needs
+    uint64_t idle_clock = 0;
     std::multimap<size_t, void *> dev_pool; // free chunks and blocks of evicted plans, by size
     size_t dev_pool_bytes = 0;
     unsigned conventions = 0; // hpfw_gpu_set_conventions: essentia conventions that cannot be checked offline
@@ -730,14 +734,20 @@ int get_plan(hpfw_gpu *h, int64_t n, DevPlan **out)
     if (const char *e = std::getenv("HPFW_PLAN_CACHE_GB")) budget = (size_t)(std::max(0.0, std::atof(e)) * 1073741824.0);
     if (h->plan_bytes + dp->bytes > budget && !h->plans.empty()) {
         PlanTimer t(&PlanTiming::evict);
-        (void)hipDeviceSynchronize();
-        // room for a quarter of the budget at once: every round of evictions costs this synchronisation, and a corpus of
-        // distinct lengths larger than the cache would otherwise pay it with every file
-        const size_t target = budget - budget / 4;
-        while (h->plan_bytes + dp->bytes > target && !h->plans.empty()) {
+        // Plans known to be idle go one at a time, as many as the new one needs: their blocks pass through the pool to the
+        // next length's tables (sizes of neighbouring lengths recur), no hipMalloc, no hipFree.  A plan that queued work may
+        // still read costs a device-wide wait first: then room for a quarter of the budget is made at once, so that a corpus
+        // of distinct lengths larger than the cache does not pay that wait with every file.
+        size_t goal = budget;
+        while (h->plan_bytes + dp->bytes > goal && !h->plans.empty()) {
             auto lru = h->plans.begin();
             for (auto q = h->plans.begin(); q != h->plans.end(); ++q)
                 if (q->second->last_use < lru->second->last_use) lru = q;
+            if (lru->second->last_use > h->idle_clock) {
+                (void)hipDeviceSynchronize();
+                h->idle_clock = h->plan_clock;
+                goal = budget - budget / 4;
+            }
             h->plan_bytes -= lru->second->bytes;
             {
                 // an evicted length may be prepared ahead again by the reader threads the next time a file brings it
@@ -1028,6 +1038,11 @@ extern "C" {
 const char *hpfw_gpu_last_error(void) { return g_err.c_str(); }
 // used by legacy.cpp so that the file entry points report through the same thread-local message
 void hpfw_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }
+// (legacy.cpp, after it has waited for the stream that carried everything it queued on the handle)
+void hpfw_internal_note_idle(hpfw_gpu *h)
+{
+    if (h) h->idle_clock = h->plan_clock;
+}
 const char *hpfw_gpu_version(void) { return "hpfw-gpu 0.1 (gfx950)"; }
 
 int hpfw_gpu_create(int device, hpfw_gpu **out)

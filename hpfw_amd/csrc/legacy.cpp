@@ -35,6 +35,7 @@
 #include "legacy_internal.h" // the extern "C" signatures multi.cpp sees, checked against the definitions below
 
 extern "C" void hpfw_internal_set_error(const char *msg); // api.hip: feeds hpfw_gpu_last_error()
+extern "C" void hpfw_internal_note_idle(hpfw_gpu *h);      // api.hip: every plan used so far is idle (evictable without a device wait)
 
 namespace {
 
@@ -732,6 +733,10 @@ static void prepare_pass(hpfw_legacy_collector *c, const char **filenames, hpfw_
         if (c->win_stream && hipStreamSynchronize(c->win_stream) != hipSuccess) {
             hpfw_internal_set_error("prepare: the window's kernels failed");
             pend.ok = false;
+        } else if (c->win_stream) {
+            // everything this collector has queued on its handle ran on that stream (the tables' stream and the side streams
+            // are joined into it), and the next window's groups are queued only after this point
+            hpfw_internal_note_idle(c->gpu);
         }
         for (size_t k = 0; pend.ok && k < pend.parts.size(); ++k) {
             const Part &pt = pend.parts[k];

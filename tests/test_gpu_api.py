@@ -91,6 +91,31 @@ def test_calc_hashprints_a_new_length_with_every_file(wav_set, oracle, filters, 
             assert np.array_equal(hp, oracle.Plan(pcm.size).extract(filters, pcm))
 
 
+def test_more_lengths_than_the_table_cache_holds(wav_set, oracle, filters, tmp_path, monkeypatch):
+    """a corpus of distinct lengths larger than the cache of per-length tables (HPFW_PLAN_CACHE_GB; here room for a handful
+    of 2 s lengths), in more than one window of files: tables are evicted while the collector runs -- least recently used
+    first; without a device-wide wait where the collector has already waited for the window that used them, with one
+    otherwise -- and their memory goes to the next lengths.  Every 9th file against the oracle, twice (the second call
+    meets every length again after its eviction)"""
+    d, clips, _, _ = wav_set
+    monkeypatch.setenv("HPFW_PLAN_CACHE_GB", "0.03")
+    pc = hpfw_amd.ParallelCollector()
+    pc.load(str(d / "cache") + "/")
+    base = synth.gen_clip(1300, 2.0)
+    paths, pcms = [], []
+    for i in range(300):                                           # 256 files make a window
+        pcm = np.roll(base, 131 * i)[: base.size - 3 * i]
+        p = str(tmp_path / f"len{i:03d}.wav")
+        synth.write_wav(p, pcm)
+        paths.append(p)
+        pcms.append(pcm)
+    for rounds in range(2):
+        got = pc.calc_hashprints(paths)
+        assert [n for _, n in got] == [f"len{i:03d}" for i in range(300)]
+        for i in range(rounds, 300, 9):
+            assert np.array_equal(got[i][0], oracle.Plan(pcms[i].size).extract(filters, pcms[i])), (rounds, i)
+
+
 def test_stereo_and_unsupported_wav(wav_set, filters, tmp_path):
     d, clips, _, _ = wav_set
     pc = hpfw_amd.ParallelCollector()
