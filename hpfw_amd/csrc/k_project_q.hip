@@ -76,6 +76,14 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
     if (t >= (unsigned)(n_tiles_x * n_clips)) return;
     const int clip = t / n_tiles_x;
     const int n0 = (t - clip * n_tiles_x) * kQTileN;
+#if defined(HPFW_Q_STAMPS)
+    // diagnosis build (tools/q_stamps.py): s_memtime of wave 0 at the phase boundaries, written to dbg [workgroup][8]
+    long long st[6];
+    st[0] = __builtin_amdgcn_s_memtime();
+#define Q_STAMP(k) st[k] = __builtin_amdgcn_s_memtime()
+#else
+#define Q_STAMP(k) ((void)0)
+#endif
     const float *S = sdb + (int64_t)clip * kBins * c;
     const float ref = FROM_T ? tmax[clip] : 0.0f;
     // the wave's filter digits of the first two steps are on their way while the slab is quantised
@@ -98,12 +106,30 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
             const int q = unit / kQCols, col = unit - q * kQCols;
             const int gc = n0 + col;
             const bool in = r0 + rr < kUnits && unit < kQChunks * kQCols && gc + kLag < c;
+            // EVERY load is issued, from a valid address, and what lies outside the slab is zeroed afterwards: written as
+            // `ok ? S[..] : 0` the loads sat in 64 branches of their own, and the compiler, short of registers for so many
+            // merged values, waited for all but one of the loads in flight after every fourth -- seven memory round trips
+            // in a row per round, 21 per workgroup: the staging took as long as the matrix loop (tools/q_stamps.py:
+            // 69 k of a workgroup's 147 k cycles)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int bin = 16 * q + e;
                 const bool ok = in && bin < kBins;
-                va[rr][e] = ok ? S[(int64_t)bin * c + gc] : 0.0f;
-                vb[rr][e] = ok ? S[(int64_t)bin * c + gc + kLag] : 0.0f;
+                const unsigned idx = ok ? (unsigned)(bin * c + gc) : 0u; // (clip-relative: < 121 * c, 32 bits; S[0] and S[kLag] exist)
+                va[rr][e] = S[idx];
+                vb[rr][e] = S[idx + kLag];
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int unit = tid + (r0 + rr) * kQThreads;
+            const int q = unit / kQCols, col = unit - q * kQCols;
+            const bool in = r0 + rr < kUnits && unit < kQChunks * kQCols && n0 + col + kLag < c;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool ok = in && 16 * q + e < kBins;
+                va[rr][e] = ok ? va[rr][e] : 0.0f;
+                vb[rr][e] = ok ? vb[rr][e] : 0.0f;
             }
         }
 #pragma unroll
@@ -131,7 +157,9 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
             dst[2] = v4i{(int)w2[0], (int)w2[1], (int)w2[2], (int)w2[3]};
         }
     }
+    Q_STAMP(1);
     __syncthreads(); // the only barrier before the epilogue: the slab is read-only from here on
+    Q_STAMP(2);
     // tiles of 16 hashprints that hold any (the last workgroup of a clip); the products of the others are skipped
     const int n_tiles = min(8, (nhp - n0 + 15) / 16);
     v4i acc[8][5];
@@ -179,10 +207,12 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
         }
         step(kQSteps - 1, a[0]);
     }
+    Q_STAMP(3);
     // S10q: D = sum_c acc_c 2^(8c); D layout of the 16x16 tile: column (hashprint) = lane & 15, row (filter) = 4 (lane >> 4) + reg
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
         const int n = n0 + 16 * f + cl;
+        (void)n;
         unsigned bits = 0; // this wave's 16 filters of hashprint n, filter 16 wave + row at bit 15 - row
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -191,18 +221,29 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
 #pragma unroll
             for (int cls = 3; cls >= 0; --cls) v = v * 256 + acc[f][cls][reg];
             bits |= (unsigned)(v >= 0) << (15 - row);
+#if !defined(HPFW_Q_STAMPS)
             if (dbg && f < n_tiles && n < nhp) dbg[((int64_t)clip * kFilters + 16 * wave + row) * nhp + n] = v;
+#endif
         }
         // the four lanes of a column hold four filters each
         bits |= (unsigned)__shfl_xor((int)bits, 16);
         bits |= (unsigned)__shfl_xor((int)bits, 32);
         if (kg == 0) parts[(16 * f + cl) * 4 + wave] = (unsigned short)bits;
     }
+    Q_STAMP(4);
     __syncthreads();
     if (tid < kQTileN && n0 + tid < nhp) {
         const unsigned short *p = parts + tid * 4;
         hp[(int64_t)clip * nhp + n0 + tid] = ((uint64_t)p[0] << 48) | ((uint64_t)p[1] << 32) | ((uint64_t)p[2] << 16) | (uint64_t)p[3];
     }
+#if defined(HPFW_Q_STAMPS)
+    Q_STAMP(5);
+    if (dbg && tid == 0) {
+        for (int k = 0; k < 6; ++k) dbg[(int64_t)t * 8 + k] = st[k];
+        dbg[(int64_t)t * 8 + 6] = __builtin_amdgcn_s_getreg((15 << 11) | 4); // HW_ID: wave, SIMD, CU, SH, SE
+        dbg[(int64_t)t * 8 + 7] = blockIdx.x;
+    }
+#endif
 }
 
 // host: the filters' digits as the A operand of v_mfma_i32_16x16x64_i8, [wave][step s = 2 t + p][digit][lane][16 bytes]:
