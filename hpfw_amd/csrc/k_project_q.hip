@@ -273,6 +273,11 @@ void pack_filters_q(const float *f, std::vector<int8_t> &image)
                     }
 }
 
+#if defined(HPFW_Q_STAMPS)
+static long long *g_q_stamps = nullptr;
+extern "C" void hpfw_gpu_debug_set_q_stamps(void *d) { g_q_stamps = static_cast<long long *>(d); }
+#endif
+
 size_t project_q_image_bytes() { return (size_t)4 * kQSteps * kQStepBytes; }
 
 // dB terms (d_tmax != NULL) or dB spectrograms -> hashprints [n_clips][c - 99]; d_dbg: NULL, or D [n_clips][64][c - 99] (tests)
@@ -289,6 +294,9 @@ void launch_hashprints_q(const void *d_fq_image, const float *d_db, const float 
     }
     const int nhp = c - (kCtx - 1) - kLag;
     if (nhp <= 0 || n_clips <= 0) return;
+#if defined(HPFW_Q_STAMPS)
+    if (!d_dbg) d_dbg = g_q_stamps; // (tools/q_stamps.py extract: the stamps of the extraction's own launches)
+#endif
     const int tiles = (nhp + kQTileN - 1) / kQTileN;
     const dim3 grid(8 * (unsigned)(((int64_t)tiles * n_clips + 7) / 8)); // one-dimensional, in XCD-aware order
     if (d_tmax)

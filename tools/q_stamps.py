@@ -1,6 +1,8 @@
 """q_stamps.py -- where a workgroup of hashprint_q_kernel spends its time (build: make OUT=../lib_qst EXTRA=-DHPFW_Q_STAMPS):
 s_memtime ticks (= shader cycles) of wave 0 at the phase boundaries, over the workgroups of one launch (dB spectrograms in).
-    HPFW_GPU_LIB=hpfw_amd/lib_qst/libhpfw_gpu.so python tools/q_stamps.py [clips]"""
+    HPFW_GPU_LIB=hpfw_amd/lib_qst/libhpfw_gpu.so python tools/q_stamps.py [clips] [extract]
+"extract": the launches of a whole extraction (dB terms fresh from the chirp-z stage) instead of the dB-input entry point on
+random values from HBM"""
 import os
 import sys
 
@@ -13,6 +15,7 @@ import hpfw_amd  # noqa: E402
 from hpfw_amd import synth  # noqa: E402
 
 n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+EXTRACT = len(sys.argv) > 2 and sys.argv[2] == "extract"   # the extraction's own launches (dB terms fresh from the chirp-z stage)
 c = 2419
 nhp = c - 99
 tiles = (nhp + 127) // 128
@@ -21,8 +24,20 @@ g.set_filters(synth.make_filters())
 db = (-80.0 * torch.rand((n_clips, 121, c), device="cuda")).contiguous()
 hp = torch.zeros((n_clips, nhp), dtype=torch.int64, device="cuda")
 st = torch.zeros((tiles * n_clips + 8, 8), dtype=torch.int64, device="cuda")
-for _ in range(3):
-    g.stage_delta_q_dev(db.data_ptr(), n_clips, c, st.data_ptr(), hp.data_ptr())
+if EXTRACT:
+    import ctypes
+    n = 1323000
+    g.set_batch(n_clips)                                   # one pass: workgroup ids = (clip, tile) of the whole batch
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    pcm = (torch.randn(n_clips, n, device="cuda", generator=gen) * 3000).to(torch.int16)
+    L = hpfw_amd.lib()
+    L.hpfw_gpu_debug_set_q_stamps.argtypes = [ctypes.c_void_p]
+    L.hpfw_gpu_debug_set_q_stamps(st.data_ptr())
+    for _ in range(3):
+        g.extract_dev(pcm.data_ptr(), n, n_clips, hp.data_ptr())
+else:
+    for _ in range(3):
+        g.stage_delta_q_dev(db.data_ptr(), n_clips, c, st.data_ptr(), hp.data_ptr())
 torch.cuda.synchronize()
 a = st.cpu().numpy()[: tiles * n_clips]
 d = np.diff(a[:, :6], axis=1).astype(np.float64)
