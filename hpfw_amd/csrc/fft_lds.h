@@ -422,11 +422,21 @@ struct XsPtr {
     }
 };
 
+// stp: diagnosis builds (-DHPFW_CQ_STAMPS, tools/cq_stamps.py) only -- s_memtime of thread 0 at the phase boundaries
+#if defined(HPFW_CQ_STAMPS) && !defined(HPFW_SIMT_EMU)
+#define HPFW_CQ_STAMP(k)                                                                  \
+    do {                                                                                  \
+        if (stp && threadIdx.x == 0) stp[k] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define HPFW_CQ_STAMP(k) ((void)0)
+#endif
 template <int NP, class Lds, class Red, class Xs, class Fin>
 HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const Xs &xs, const cf *__restrict__ g,
                               int lg, const CqTwiddles &tw, const cf *__restrict__ vrev, int c,
-                              float *__restrict__ out_mag, Fin fin)
+                              float *__restrict__ out_mag, Fin fin, long long *stp = nullptr)
 {
+    HPFW_CQ_STAMP(0);
     using P = Size<NP>;
     static_assert(cq_size_ok(NP), "chirp-z lengths are 2^a or 3 * 2^a");
     const bool prune = lg <= P::N / 4; // the first pass is radix 4 for every admitted length
@@ -452,8 +462,11 @@ HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const Xs &xs, co
     } else
 #endif
     {
+        HPFW_CQ_STAMP(1);
         HPFW_BARRIER();
+        HPFW_CQ_STAMP(2);
         cq_transform<NP, NP, 0>(lds, tw, nthreads, lg, c, vrev);
+        HPFW_CQ_STAMP(3);
     }
     HPFW_FOR_THREADS(tid, nthreads)
     {
@@ -466,6 +479,8 @@ HPFW_DEVICE void cq_band_body(Lds &lds, Red &red, int nthreads, const Xs &xs, co
         }
         red[tid] = mx;
     }
+    HPFW_CQ_STAMP(4);
+    (void)stp;
 }
 
 } // namespace hpfw

@@ -38,6 +38,18 @@ constexpr int cq_threads(int n)
 // scratch in round 3's build -- the classes whose LDS footprint admits six measured slower, 4.0 against 3.85 ms per 1000 clips.
 constexpr int cq_waves(int n) { return cq_threads(n) <= 128 ? 5 : 1; }
 
+#if defined(HPFW_CQ_STAMPS)
+static __device__ long long *g_cq_stamps = nullptr; // [clip][121][8]
+extern "C" void hpfw_gpu_debug_set_cq_stamps(void *d)
+{
+    long long *p = static_cast<long long *>(d);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cq_stamps), &p, sizeof(p));
+}
+#define HPFW_CQ_STP (g_cq_stamps ? g_cq_stamps + ((int64_t)clip * kBins + j) * 8 : nullptr)
+#else
+#define HPFW_CQ_STP nullptr
+#endif
+
 template <int NP, bool DBT>
 __global__ __launch_bounds__(cq_threads(NP), cq_waves(NP)) void cq_kernel(CqPlanDev cp, CqClassDev cc,
                                                               const cf *__restrict__ x, float *__restrict__ mag,
@@ -54,11 +66,11 @@ __global__ __launch_bounds__(cq_threads(NP), cq_waves(NP)) void cq_kernel(CqPlan
     if (cp.xn1 == 1 || cp.nq2[j] < cp.rows_min) {
         const XsBand xs{cp.view(x, clip), cp.start[j]};
         cq_band_body<NP>(lds, red, cq_threads(NP), xs, cp.g + cp.g_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
-                           [](float m) { return DBT ? db_term(m * m) : m; });
+                           [](float m) { return DBT ? db_term(m * m) : m; }, HPFW_CQ_STP);
     } else {           // rows k mod n1, as the row stage of S6 leaves them
         const XsBandRows xs{x + (int64_t)clip * cp.xclip, cp.xn1, cp.xw, cp.xq0, cp.start[j], cp.q2a[j], cp.nq2[j], cp.nq2_magic[j]};
         cq_band_body<NP>(lds, red, cq_threads(NP), xs, cp.g2 + cp.g2_off[j], cp.lg[j], cc.gtw, cc.vrev, cp.c, out,
-                           [](float m) { return DBT ? db_term(m * m) : m; });
+                           [](float m) { return DBT ? db_term(m * m) : m; }, HPFW_CQ_STP);
     }
     // wave maximum -> wavemax[clip][band][wave]: plain stores (clipmax_kernel reduces them); one
     // atomicMax per wave on a per-clip word cost 0.4 ms per 1000 clips in contention
@@ -66,6 +78,14 @@ __global__ __launch_bounds__(cq_threads(NP), cq_waves(NP)) void cq_kernel(CqPlan
     float *slot = wavemax + ((int64_t)clip * kBins + j) * kCqMaxWaves;
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = mx;
     if (threadIdx.x < kCqMaxWaves && threadIdx.x >= (blockDim.x >> 6)) slot[threadIdx.x] = -INFINITY; // slots of absent waves
+#if defined(HPFW_CQ_STAMPS)
+    if (g_cq_stamps && threadIdx.x == 0) {
+        long long *stp = HPFW_CQ_STP;
+        stp[5] = __builtin_amdgcn_s_memtime();
+        stp[6] = NP;
+        stp[7] = __builtin_amdgcn_s_getreg((15 << 11) | 4);
+    }
+#endif
 }
 
 // band maxima for the stage entry point that starts from given magnitudes: one workgroup per (band, clip)

@@ -54,6 +54,10 @@ struct ColsQArgs {
 
 // Where the forward bins of one clip lie: in natural order from bin q0 on (n1 == 1: the chirp-z forward transform, the
 // stage entry points), or as the row stage of S6 leaves them, x[k mod n1][k / n1 - q0] in rows of w elements.
+#ifndef HPFW_XS_BATCH
+#define HPFW_XS_BATCH 4
+#endif
+constexpr int kXsBatch = HPFW_XS_BATCH; // elements per thread whose loads are in flight together in the band loaders below
 struct XsView {
     const cf *base;
     int n1, w, q0;
@@ -71,10 +75,26 @@ struct XsBand {
     int start;
     HPFW_DEVICE_MEMBER cf operator()(int i) const { return v(start + i); }
     // every element of the slice times its window value, in natural order: f(i, x[i] g[i])
+    // (kXsBatch elements per thread at a time, all their loads issued before the first product: one element per trip left
+    // one memory round trip per element in a row -- tools/cq_stamps.py: a fifth to a third of a band's time)
     template <class F>
     HPFW_DEVICE_MEMBER void for_each(int tid, int nthreads, int lg, const cf *__restrict__ g, F f) const
     {
-        for (int i = tid; i < lg; i += nthreads) f(i, c_mul(v(start + i), g[i]));
+        for (int i0 = tid; i0 < lg; i0 += kXsBatch * nthreads) {
+            cf xv[kXsBatch], gv[kXsBatch];
+#pragma unroll
+            for (int u = 0; u < kXsBatch; ++u) {
+                const int i = i0 + u * nthreads;
+                const int ic = i < lg ? i : lg - 1; // (a valid element again: loaded, not used)
+                xv[u] = v(start + ic);
+                gv[u] = g[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < kXsBatch; ++u) {
+                const int i = i0 + u * nthreads;
+                if (i < lg) f(i, c_mul(xv[u], gv[u]));
+            }
+        }
     }
 };
 // the same slice walked in the order the rows layout stores it (row q1 = k mod n1, then the q2 of the slice, which are
@@ -89,12 +109,27 @@ struct XsBandRows {
     template <class F>
     HPFW_DEVICE_MEMBER void for_each(int tid, int nthreads, int lg, const cf *__restrict__ g2, F f) const
     {
+        // every t < total names an element of the clip's rows (inside or outside the band) and an entry of g2: the loads
+        // are unconditional and issued kXsBatch at a time, only the use is guarded (written as `if (inside) f(.., load ..)`
+        // every element cost a memory round trip of its own: tools/cq_stamps.py)
         const int total = n1 * nq2;
-        for (int t = tid; t < total; t += nthreads) {
-            const int q1 = nq2 == 1 ? t : (int)(((unsigned long long)(unsigned)t * magic) >> 32);
-            const int tq = t - q1 * nq2;
-            const int i = q1 + n1 * (q2a + tq) - start;
-            if (i >= 0 && i < lg) f(i, c_mul(base[(int64_t)q1 * w + (q2a - q0 + tq)], g2[t]));
+        for (int t0 = tid; t0 < total; t0 += kXsBatch * nthreads) {
+            cf xv[kXsBatch], gv[kXsBatch];
+            int ii[kXsBatch];
+#pragma unroll
+            for (int u = 0; u < kXsBatch; ++u) {
+                const int t = t0 + u * nthreads;
+                const int tc = t < total ? t : total - 1;
+                const int q1 = nq2 == 1 ? tc : (int)(((unsigned long long)(unsigned)tc * magic) >> 32);
+                const int tq = tc - q1 * nq2;
+                const int i = q1 + n1 * (q2a + tq) - start;
+                ii[u] = (t < total && i >= 0 && i < lg) ? i : -1;
+                xv[u] = base[(int64_t)q1 * w + (q2a - q0 + tq)];
+                gv[u] = g2[tc];
+            }
+#pragma unroll
+            for (int u = 0; u < kXsBatch; ++u)
+                if (ii[u] >= 0) f(ii[u], c_mul(xv[u], gv[u]));
         }
     }
 };
