@@ -13,11 +13,24 @@ namespace hpfw {
 
 extern __shared__ __align__(16) unsigned char smem_raw[];
 
+// the maximum over the wave, in every lane: inside the rows of sixteen lanes on the data-parallel-primitive path (two quad
+// permutes, two row rotations -- a permute through the LDS hardware per step cost the workgroup 1.1-1.6 k cycles,
+// tools/cq_stamps.py), then the four rows' values read as scalars.  (max is exact and does not depend on the order.)
+template <int CTRL>
+__device__ __forceinline__ float wave_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
-    return v;
+    v = fmaxf(v, wave_dpp<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = fmaxf(v, wave_dpp<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = fmaxf(v, wave_dpp<0x124>(v)); // row_ror:4
+    v = fmaxf(v, wave_dpp<0x128>(v)); // row_ror:8
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 constexpr int cq_threads(int n)
