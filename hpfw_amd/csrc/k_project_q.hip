@@ -171,11 +171,23 @@ __global__ __launch_bounds__(kQThreads, 2) void hashprint_q_kernel(const v4i *__
     const unsigned char *bl = slab + (size_t)(kg * kQPitch + cl) * kQUnit;
     auto step = [&](int s, const v4i (&aw)[3]) {
         const unsigned char *bs = bl + (size_t)((4 * (s & 1)) * kQPitch + (s >> 1)) * kQUnit;
+        // the operand reads of tile f + 1 are issued BEFORE the nine products of tile f: read right where they are used, a
+        // wave alone on its SIMD left the matrix pipe idle for an LDS round trip per tile (tools/q_stamps.py: 46 k cycles of
+        // matrix instructions in a 69 k cycle loop)
+        v4i nb0, nb1, nb2;
+        {
+            const v4i *bu = reinterpret_cast<const v4i *>(bs);
+            nb0 = bu[0], nb1 = bu[1], nb2 = bu[2];
+        }
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             if (f < n_tiles) {
-                const v4i *bu = reinterpret_cast<const v4i *>(bs + (size_t)(16 * f) * kQUnit);
-                const v4i b0 = bu[0], b1 = bu[1], b2 = bu[2];
+                const v4i b0 = nb0, b1 = nb1, b2 = nb2;
+                if (f + 1 < 8) { // (tile f + 1 of the slab exists whether or not it holds hashprints)
+                    const v4i *bu = reinterpret_cast<const v4i *>(bs + (size_t)(16 * (f + 1)) * kQUnit);
+                    nb0 = bu[0], nb1 = bu[1], nb2 = bu[2];
+                }
+                __builtin_amdgcn_sched_barrier(0); // (the scheduler would sink the reads back to where they are used)
                 // filter digit i times spectrogram digit j goes to accumulator i + j
                 acc[f][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[0], b0, acc[f][0], 0, 0, 0);
                 acc[f][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(aw[0], b1, acc[f][1], 0, 0, 0);
